@@ -1,0 +1,338 @@
+"""Generate tests/golden/*.npz by running the CLiMB reference itself.  BUILD-CONTAINER ONLY.
+
+Usage:  python oracle/gen_golden.py            (needs /root/reference; ~2 min on 8 cores)
+
+Every fixture is DATA: outputs of the reference's own `ViltContinualLearner`, `*Trainer.train_step`,
+`EWC.compute_ewc_loss` and `EWC.save_task_parameters` on seeded synthetic inputs.  Weights and inputs
+are regenerated on the consumer side from `oracle/vilt_oracle.py` (`init_params`, `synthetic_*`),
+so only outputs are stored.  While generating, the script also asserts that the oracle restatement
+agrees with the reference (tolerances below), which is what pins the oracle.
+"""
+from __future__ import annotations
+
+import os
+import random
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import ref_import as ri          # noqa: E402
+import vilt_oracle as vo         # noqa: E402
+
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+SLICE = 8
+
+
+def tensor_summary(named):
+    """per-tensor L2 norm + first SLICE elements, in dict order."""
+    names = list(named.keys())
+    norms = np.array([float(named[n].double().norm()) for n in names], dtype=np.float64)
+    heads = np.zeros((len(names), SLICE), dtype=np.float32)
+    for i, n in enumerate(names):
+        f = named[n].detach().reshape(-1)[:SLICE].float().numpy()
+        heads[i, :f.size] = f
+    return norms, heads
+
+
+def check(name, a, b, rtol):
+    a = torch.as_tensor(a).double()
+    b = torch.as_tensor(b).double()
+    err = float((a - b).abs().max())
+    scale = float(b.abs().max()) + 1e-30
+    print(f"  oracle-vs-reference {name:34s} max|d|={err:.3e} scale={scale:.3e} rel={err / scale:.2e}")
+    assert err <= rtol * scale, (name, err, scale)
+
+
+def ref_grads(model):
+    return {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+
+
+def run_ref_step(model, trainer, enc, batch, optimizer=None, scheduler=None, ewc=None):
+    ri.bypass_processor(model, enc)
+    torch.manual_seed(0)      # only affects the reference's patch shuffle (HF:153-159)
+    return trainer.train_step(model, batch, optimizer, scheduler, ewc)
+
+
+def case_single_image(task, tasks, B, fname, ragged=False, wseed=42, dseed=1):
+    print(f"[{fname}] task={task} tasks={tasks} B={B} ragged={ragged}")
+    P = vo.init_params(tasks, wseed)
+    enc = vo.synthetic_encodings(B, seed=dseed, ragged_text=ragged)
+    model = ri.build_reference_learner(tasks, P)
+    model.train()
+    trainer = ri.make_trainer(task)
+    if task == "vqa":
+        target = vo.synthetic_vqa_targets(B, seed=dseed)
+        batch = {"raw_texts": [""] * B, "images": None, "target_scores": target}
+    else:
+        rng = np.random.default_rng([dseed, 13])
+        target = torch.from_numpy(rng.integers(0, vo.TASKS[task]["num_labels"], size=(B,), dtype=np.int64))
+        batch = {"raw_texts": [""] * B, "images": None, "labels": target}
+    model.zero_grad()
+    loss, (pooled, logits), _, _ = run_ref_step(model, trainer, enc, batch)
+    G = ref_grads(model)
+    # oracle agreement
+    o_loss, (o_pooled, o_logits), _, o_G = vo.train_step(P, task, enc, target)
+    check("pooled", o_pooled, pooled, 2e-5)
+    check("logits", o_logits, logits, 2e-5)
+    check("loss", o_loss, loss, 2e-5)
+    assert torch.equal(o_logits.argmax(-1), logits.argmax(-1))
+    for n in G:
+        check("grad " + n[-28:], o_G[n], G[n], 2e-4) if n.endswith(("query.weight", "cls_token", "3.weight", "word_embeddings.weight", "projection.weight")) else None
+    gn, gh = tensor_summary(G)
+    on, _ = tensor_summary({n: o_G[n] for n in G})
+    check("grad norms (all tensors)", on, gn, 1e-4)
+    np.savez_compressed(os.path.join(OUT, fname), pooled=pooled.detach().numpy(), logits=logits.detach().numpy(),
+                        loss=np.float64(loss.item()), grad_names=np.array(list(G.keys())), grad_norms=gn, grad_heads=gh,
+                        meta=np.array([f"task={task};tasks={','.join(tasks)};B={B};wseed={wseed};dseed={dseed};ragged={int(ragged)}"]))
+    return model, P
+
+
+def case_steps(fname, steps=10, B=2, tasks=("vqa", "nlvr2"), wseed=42):
+    """BASELINE config 1: ViLT sequential-FT on VQAv2, batch=2, 10 steps, with the reference's optimizer + schedule
+    (REF/train/visionlanguage_tasks/train_vqa.py:197-205; max_steps=steps so warm-up = 1 step)."""
+    print(f"[{fname}] {steps} reference AdamW steps, B={B}")
+    tasks = list(tasks)
+    P = vo.init_params(tasks, wseed)
+    P0 = {n: t.clone() for n, t in P.items()}
+    model = ri.build_reference_learner(tasks, P)
+    model.train()
+    trainer = ri.make_trainer("vqa")
+    ns = ri.import_reference()
+    opt = model.create_optimizer(trainer.hparams)
+    sched = ns.get_poly(opt, num_warmup_steps=int(steps * 0.1), num_training_steps=steps, lr_end=0, power=1)
+    model.zero_grad()
+    losses, o_losses = [], []
+    state = {}
+    warm = int(steps * 0.1)
+    for s in range(steps):
+        enc = vo.synthetic_encodings(B, seed=100 + s)
+        target = vo.synthetic_vqa_targets(B, seed=100 + s)
+        batch = {"raw_texts": [""] * B, "images": None, "target_scores": target}
+        loss, _, _, _ = run_ref_step(model, trainer, enc, batch, opt, sched)
+        losses.append(loss.item())
+        lr = vo.poly_lr(s, 1e-4, warm, steps)
+        o_loss, _, _, _ = vo.train_step(P, "vqa", enc, target, opt_state=state, lr=lr)
+        o_losses.append(o_loss.item())
+    check("loss curve", np.array(o_losses), np.array(losses), 1e-4)
+    after = {n: p.detach().clone() for n, p in model.named_parameters()}
+    delta = {n: after[n] - P0[n] for n in after}
+    o_delta = {n: P[n] - P0[n] for n in after}
+    dn, dh = tensor_summary(delta)
+    odn, _ = tensor_summary(o_delta)
+    check("param-delta norms", odn, dn, 2e-3)
+    _, ah = tensor_summary(after)
+    np.savez_compressed(os.path.join(OUT, fname), losses=np.array(losses), names=np.array(list(after.keys())),
+                        delta_norms=dn, delta_heads=dh, after_heads=ah,
+                        meta=np.array([f"task=vqa;tasks={','.join(tasks)};B={B};steps={steps};wseed={wseed};dseed=100+s;lr=1e-4"]))
+
+
+def synthetic_ewc_state(P, seed=5):
+    """theta* = weights + small seeded noise, F ~ U(0,1)*1e-4, encoder-relative names."""
+    fisher, star = {}, {}
+    for n in vo.encoder_names(P):
+        k = n[len("vilt_encoder."):]
+        rng = np.random.default_rng([seed, vo.zlib.crc32(k.encode())])
+        fisher[k] = torch.from_numpy((rng.random(P[n].shape, dtype=np.float32) * 1e-4).astype(np.float32))
+        star[k] = P[n] + torch.from_numpy((0.01 * rng.standard_normal(P[n].shape, dtype=np.float32)).astype(np.float32))
+    return fisher, star
+
+
+def case_ewc(fname, B=2, tasks=("vqa", "nlvr2"), wseed=42, dseed=1):
+    print(f"[{fname}] EWC penalty + train_step with ewc")
+    tasks = list(tasks)
+    P = vo.init_params(tasks, wseed)
+    fisher, star = synthetic_ewc_state(P)
+    model = ri.build_reference_learner(tasks, P)
+    model.train()
+    ns = ri.import_reference()
+    args = types.SimpleNamespace(ewc_fisher_sample_percentage=0.01, ewc_loss_weight=100.0)
+    ewc = ns.ewc.EWC(args)
+    ewc.task_keys = ["nlvr2"]
+    ewc.fisher_dict = {"nlvr2": fisher}
+    ewc.param_dict = {"nlvr2": star}
+    ewc.device = torch.device("cpu")
+    trainer = ri.make_trainer("vqa")
+    enc = vo.synthetic_encodings(B, seed=dseed)
+    target = vo.synthetic_vqa_targets(B, seed=dseed)
+    batch = {"raw_texts": [""] * B, "images": None, "target_scores": target}
+    model.zero_grad()
+    random.seed(0)
+    loss, _, ewc_task, ewc_loss = run_ref_step(model, trainer, enc, batch, ewc=ewc)
+    G = ref_grads(model)
+    o_loss, _, o_el, o_G = vo.train_step(P, "vqa", enc, target, ewc=(fisher, star, 100.0))
+    check("ewc_loss", o_el, ewc_loss, 1e-5)
+    check("loss", o_loss, loss, 2e-5)
+    gn, gh = tensor_summary(G)
+    on, _ = tensor_summary({n: o_G[n] for n in G})
+    check("grad norms with EWC", on, gn, 1e-4)
+    np.savez_compressed(os.path.join(OUT, fname), loss=np.float64(loss.item()), ewc_loss=np.float64(ewc_loss.item()),
+                        grad_names=np.array(list(G.keys())), grad_norms=gn, grad_heads=gh,
+                        meta=np.array([f"task=vqa;tasks={','.join(tasks)};B={B};wseed={wseed};dseed={dseed};ewc_seed=5;lam=100"]))
+
+
+def case_fisher(fname, B=2, nb=3, tasks=("vqa", "nlvr2"), wseed=42):
+    """EWC.save_task_parameters (REF/cl_algorithms/ewc.py:28-73) over 3 accumulating batches."""
+    print(f"[{fname}] Fisher from {nb} accumulating batches")
+    tasks = list(tasks)
+    P = vo.init_params(tasks, wseed)
+    model = ri.build_reference_learner(tasks, P)
+    model.train()
+    ns = ri.import_reference()
+    trainer = ri.make_trainer("vqa")
+    encs = [vo.synthetic_encodings(B, seed=200 + i) for i in range(nb)]
+    tgts = [vo.synthetic_vqa_targets(B, seed=200 + i) for i in range(nb)]
+
+    class _Loader(list):
+        pass
+    loader = _Loader()
+    for i in range(nb):
+        loader.append({"raw_texts": [""] * B, "images": None, "target_scores": tgts[i], "_i": i})
+    loader.dataset = list(range(int(nb * B / 0.01)))          # 1 % of it == nb*B samples
+    trainer.get_train_dataloader = lambda: loader
+    orig = trainer.train_step
+
+    def step(model, batch, *a, **k):
+        ri.bypass_processor(model, encs[batch["_i"]])
+        torch.manual_seed(0)
+        return orig(model, batch, *a, **k)
+    trainer.train_step = step
+    args = types.SimpleNamespace(ewc_fisher_sample_percentage=0.01, ewc_loss_weight=100.0)
+    ewc = ns.ewc.EWC(args)
+    ewc.save_task_parameters(task_key="vqa", model=model, task_trainer=trainer, device=torch.device("cpu"))
+    fisher = {k: v for k, v in ewc.fisher_dict["vqa"].items()}
+    # oracle
+    grads = []
+    for i in range(nb):
+        _, _, _, G = vo.train_step(P, "vqa", encs[i], tgts[i])
+        grads.append({n[len("vilt_encoder."):]: g for n, g in G.items() if n.startswith(vo.ENC)})
+    o_fisher = vo.fisher_from_batch_grads(grads, [B] * nb)
+    fn, fh = tensor_summary(fisher)
+    ofn, _ = tensor_summary({k: o_fisher[k] for k in fisher})
+    check("fisher norms", ofn, fn, 5e-4)
+    np.savez_compressed(os.path.join(OUT, fname), names=np.array(list(fisher.keys())), fisher_norms=fn, fisher_heads=fh,
+                        meta=np.array([f"task=vqa;tasks={','.join(tasks)};B={B};batches={nb};wseed={wseed};dseed=200+i"]))
+
+
+def case_nlvr2(fname, b=2, tasks=("vqa", "nlvr2"), wseed=42, dseed=3):
+    print(f"[{fname}] NLVR2 two-image forward/backward")
+    tasks = list(tasks)
+    P = vo.init_params(tasks, wseed)
+    e1 = vo.synthetic_encodings(2 * b, seed=dseed)
+    enc = dict(input_ids=e1["input_ids"][:b], token_type_ids=e1["token_type_ids"][:b],
+               attention_mask=e1["attention_mask"][:b], pixel_values=e1["pixel_values"], pixel_mask=e1["pixel_mask"])
+    labels = torch.tensor([1, 0][:b])
+    model = ri.build_reference_learner(tasks, P)
+    model.train()
+    trainer = ri.make_trainer("nlvr2")
+    batch = {"raw_texts": [""] * b, "images": [[None, None]] * b, "labels": labels}
+    model.zero_grad()
+    loss, (pooled, logits), _, _ = run_ref_step(model, trainer, enc, batch)
+    G = ref_grads(model)
+    o_loss, (o_pooled, o_logits), _, o_G = vo.train_step(P, "nlvr2", enc, labels)
+    check("pooled", o_pooled, pooled, 2e-5)
+    check("logits", o_logits, logits, 2e-5)
+    check("loss", o_loss, loss, 2e-5)
+    gn, gh = tensor_summary(G)
+    on, _ = tensor_summary({n: o_G[n] for n in G})
+    check("grad norms", on, gn, 1e-4)
+    np.savez_compressed(os.path.join(OUT, fname), pooled=pooled.detach().numpy(), logits=logits.detach().numpy(),
+                        loss=np.float64(loss.item()), labels=labels.numpy(),
+                        grad_names=np.array(list(G.keys())), grad_norms=gn, grad_heads=gh,
+                        meta=np.array([f"task=nlvr2;tasks={','.join(tasks)};b={b};wseed={wseed};dseed={dseed}"]))
+
+
+def case_vcr(fname, b=2, tasks=("snli-ve", "vcr"), wseed=42, dseed=4):
+    """VCR multi-choice, eval mode (the head's Dropout(0.1) is the only stochastic op on the path)."""
+    print(f"[{fname}] VCR four-choice forward/backward (eval mode)")
+    tasks = list(tasks)
+    P = vo.init_params(tasks, wseed)
+    e1 = vo.synthetic_encodings(4 * b, seed=dseed, ragged_text=True)
+    enc = dict(input_ids=e1["input_ids"], token_type_ids=e1["token_type_ids"], attention_mask=e1["attention_mask"],
+               pixel_values=e1["pixel_values"][:b], pixel_mask=e1["pixel_mask"][:b])
+    labels = torch.tensor([2, 0][:b])
+    model = ri.build_reference_learner(tasks, P)
+    model.eval()
+    trainer = ri.make_trainer("vcr")
+    batch = {"raw_texts": [[""] * 4] * b, "images": [None] * b, "labels": labels}
+    model.zero_grad()
+    loss, (pooled, logits), _, _ = run_ref_step(model, trainer, enc, batch)
+    G = ref_grads(model)
+    leaves = {n: P[n].clone().requires_grad_(True) for n in P}
+    o_pooled, o_logits = vo.learner_forward(leaves, "vcr", enc, training=False)
+    o_loss = vo.ce_loss(o_logits, labels)
+    o_loss.backward()
+    o_G = {n: leaves[n].grad for n in G}
+    check("pooled", o_pooled, pooled, 2e-5)
+    check("logits", o_logits, logits, 2e-5)
+    check("loss", o_loss, loss, 2e-5)
+    gn, gh = tensor_summary(G)
+    on, _ = tensor_summary(o_G)
+    check("grad norms", on, gn, 1e-4)
+    np.savez_compressed(os.path.join(OUT, fname), pooled=pooled.detach().numpy(), logits=logits.detach().numpy(),
+                        loss=np.float64(loss.item()), labels=labels.numpy(),
+                        grad_names=np.array(list(G.keys())), grad_norms=gn, grad_heads=gh,
+                        meta=np.array([f"task=vcr;tasks={','.join(tasks)};b={b};wseed={wseed};dseed={dseed};ragged=1;eval=1"]))
+
+
+def case_replay(fname, B=2, tasks=("vqa", "nlvr2"), wseed=42, dseed=6):
+    """ExperienceReplayMemory.run_replay_step (REF/cl_algorithms/experience_replay.py:53-67): a FRESH AdamW
+    (zero moments, base lr, no scheduler) and one train_step on the replayed task."""
+    print(f"[{fname}] ER replay step with a fresh optimizer")
+    tasks = list(tasks)
+    P = vo.init_params(tasks, wseed)
+    P0 = {n: t.clone() for n, t in P.items()}
+    model = ri.build_reference_learner(tasks, P)
+    model.train()
+    ns = ri.import_reference()
+    trainer = ri.make_trainer("vqa")
+    enc = vo.synthetic_encodings(B, seed=dseed)
+    target = vo.synthetic_vqa_targets(B, seed=dseed)
+    batch = {"raw_texts": [""] * B, "images": None, "target_scores": target}
+    orig = trainer.train_step
+
+    def step(model, b, *a, **k):
+        ri.bypass_processor(model, enc)
+        torch.manual_seed(0)
+        return orig(model, b, *a, **k)
+    trainer.train_step = step
+    mem = ns.er.ExperienceReplayMemory()
+    buf = types.SimpleNamespace(task_config=ns.task_configs["vqa"], task_trainer=trainer,
+                                sample_replay_batch=lambda: batch)
+    mem.memory_buffers["vqa"] = buf
+    model.zero_grad()
+    loss = mem.run_replay_step(task_key="vqa", model=model)
+    after = {n: p.detach().clone() for n, p in model.named_parameters()}
+    state = {}
+    o_loss, _, _, _ = vo.train_step(P, "vqa", enc, target, opt_state=state, lr=1e-4)
+    check("loss", o_loss, loss, 2e-5)
+    delta = {n: after[n] - P0[n] for n in after}
+    dn, dh = tensor_summary(delta)
+    odn, _ = tensor_summary({n: P[n] - P0[n] for n in after})
+    check("param-delta norms", odn, dn, 1e-3)
+    np.savez_compressed(os.path.join(OUT, fname), loss=np.float64(loss.item()), names=np.array(list(after.keys())),
+                        delta_norms=dn, delta_heads=dh,
+                        meta=np.array([f"task=vqa;tasks={','.join(tasks)};B={B};wseed={wseed};dseed={dseed};lr=1e-4;fresh_adamw=1"]))
+
+
+def main():
+    assert ri.reference_available(), "needs /root/reference (build container only)"
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(os.cpu_count() or 8)
+    case_single_image("vqa", ["vqa", "nlvr2"], 2, "vqa_b2.npz")
+    case_single_image("vqa", ["vqa", "nlvr2"], 3, "vqa_b3_ragged.npz", ragged=True, dseed=2)
+    case_single_image("snli-ve", ["snli-ve", "vcr"], 2, "snlive_b2.npz", dseed=8)
+    case_nlvr2("nlvr2_b2.npz")
+    case_vcr("vcr_b2.npz")
+    case_ewc("ewc_b2.npz")
+    case_fisher("fisher_3x2.npz")
+    case_replay("replay_b2.npz")
+    case_steps("vqa_b2_10steps.npz")
+    print("golden fixtures written to", OUT)
+
+
+if __name__ == "__main__":
+    main()

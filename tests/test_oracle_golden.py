@@ -1,0 +1,185 @@
+"""The CPU oracle (oracle/vilt_oracle.py) against the golden vectors the reference itself produced
+(tests/golden/*.npz, written by oracle/gen_golden.py in the build container).  No GPU, no reference tree."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import vilt_oracle as vo
+
+
+def _meta(z):
+    return dict(kv.split("=", 1) for kv in str(z["meta"][0]).split(";"))
+
+
+def _summary(named, names, k=8):
+    norms = np.array([float(named[n].double().norm()) for n in names])
+    heads = np.zeros((len(names), k), dtype=np.float32)
+    for i, n in enumerate(names):
+        f = named[n].detach().reshape(-1)[:k].float().numpy()
+        heads[i, :f.size] = f
+    return norms, heads
+
+
+def _close(a, b, rtol, what=""):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    scale = np.abs(b).max() + 1e-30
+    err = np.abs(a - b).max()
+    assert err <= rtol * scale, f"{what}: max|d|={err:.3e} scale={scale:.3e}"
+
+
+@pytest.mark.parametrize("fname", ["vqa_b2.npz", "vqa_b3_ragged.npz", "snlive_b2.npz"])
+def test_single_image_forward_backward(golden_dir, fname):
+    z = np.load(os.path.join(golden_dir, fname))
+    m = _meta(z)
+    tasks = m["tasks"].split(",")
+    B = int(m["B"])
+    P = vo.init_params(tasks, int(m["wseed"]))
+    enc = vo.synthetic_encodings(B, seed=int(m["dseed"]), ragged_text=bool(int(m["ragged"])))
+    if m["task"] == "vqa":
+        target = vo.synthetic_vqa_targets(B, seed=int(m["dseed"]))
+    else:
+        rng = np.random.default_rng([int(m["dseed"]), 13])
+        target = torch.from_numpy(rng.integers(0, vo.TASKS[m["task"]]["num_labels"], size=(B,), dtype=np.int64))
+    loss, (pooled, logits), _, G = vo.train_step(P, m["task"], enc, target)
+    _close(pooled, z["pooled"], 2e-5, "pooled")
+    _close(logits, z["logits"], 2e-5, "logits")
+    _close(loss, z["loss"], 2e-5, "loss")
+    assert np.array_equal(logits.argmax(-1).numpy(), z["logits"].argmax(-1))
+    names = [str(n) for n in z["grad_names"]]
+    norms, heads = _summary(G, names)
+    _close(norms, z["grad_norms"], 1e-4, "grad norms")
+    _close(heads, z["grad_heads"], 1e-4, "grad heads")
+
+
+def test_nlvr2_two_images(golden_dir):
+    z = np.load(os.path.join(golden_dir, "nlvr2_b2.npz"))
+    m = _meta(z)
+    b = int(m["b"])
+    P = vo.init_params(m["tasks"].split(","), int(m["wseed"]))
+    e1 = vo.synthetic_encodings(2 * b, seed=int(m["dseed"]))
+    enc = dict(input_ids=e1["input_ids"][:b], token_type_ids=e1["token_type_ids"][:b],
+               attention_mask=e1["attention_mask"][:b], pixel_values=e1["pixel_values"], pixel_mask=e1["pixel_mask"])
+    loss, (pooled, logits), _, G = vo.train_step(P, "nlvr2", enc, torch.from_numpy(z["labels"]))
+    _close(pooled, z["pooled"], 2e-5, "pooled")
+    _close(logits, z["logits"], 2e-5, "logits")
+    _close(loss, z["loss"], 2e-5, "loss")
+    names = [str(n) for n in z["grad_names"]]
+    norms, heads = _summary(G, names)
+    _close(norms, z["grad_norms"], 1e-4, "grad norms")
+    _close(heads, z["grad_heads"], 1e-4, "grad heads")
+
+
+def test_vcr_four_choices_eval(golden_dir):
+    z = np.load(os.path.join(golden_dir, "vcr_b2.npz"))
+    m = _meta(z)
+    b = int(m["b"])
+    P = vo.init_params(m["tasks"].split(","), int(m["wseed"]))
+    e1 = vo.synthetic_encodings(4 * b, seed=int(m["dseed"]), ragged_text=True)
+    enc = dict(input_ids=e1["input_ids"], token_type_ids=e1["token_type_ids"], attention_mask=e1["attention_mask"],
+               pixel_values=e1["pixel_values"][:b], pixel_mask=e1["pixel_mask"][:b])
+    with torch.no_grad():
+        pooled, logits = vo.learner_forward(P, "vcr", enc, training=False)
+    _close(pooled, z["pooled"], 2e-5, "pooled")
+    _close(logits, z["logits"], 2e-5, "logits")
+    _close(vo.ce_loss(logits, torch.from_numpy(z["labels"])), z["loss"], 2e-5, "loss")
+
+
+def _ewc_state(P, seed=5):
+    import zlib
+    fisher, star = {}, {}
+    for n in vo.encoder_names(P):
+        k = n[len("vilt_encoder."):]
+        rng = np.random.default_rng([seed, zlib.crc32(k.encode())])
+        fisher[k] = torch.from_numpy((rng.random(P[n].shape, dtype=np.float32) * 1e-4).astype(np.float32))
+        star[k] = P[n] + torch.from_numpy((0.01 * rng.standard_normal(P[n].shape, dtype=np.float32)).astype(np.float32))
+    return fisher, star
+
+
+def test_ewc_penalty(golden_dir):
+    z = np.load(os.path.join(golden_dir, "ewc_b2.npz"))
+    m = _meta(z)
+    B = int(m["B"])
+    P = vo.init_params(m["tasks"].split(","), int(m["wseed"]))
+    fisher, star = _ewc_state(P, int(m["ewc_seed"]))
+    enc = vo.synthetic_encodings(B, seed=int(m["dseed"]))
+    target = vo.synthetic_vqa_targets(B, seed=int(m["dseed"]))
+    loss, _, el, G = vo.train_step(P, "vqa", enc, target, ewc=(fisher, star, float(m["lam"])))
+    _close(el, z["ewc_loss"], 1e-5, "ewc loss")
+    _close(loss, z["loss"], 2e-5, "loss")
+    names = [str(n) for n in z["grad_names"]]
+    norms, heads = _summary(G, names)
+    _close(norms, z["grad_norms"], 1e-4, "grad norms")
+    _close(heads, z["grad_heads"], 1e-4, "grad heads")
+
+
+def test_fisher_accumulating_quirk(golden_dir):
+    z = np.load(os.path.join(golden_dir, "fisher_3x2.npz"))
+    m = _meta(z)
+    B, nb = int(m["B"]), int(m["batches"])
+    P = vo.init_params(m["tasks"].split(","), int(m["wseed"]))
+    grads = []
+    for i in range(nb):
+        _, _, _, G = vo.train_step(P, "vqa", vo.synthetic_encodings(B, seed=200 + i), vo.synthetic_vqa_targets(B, seed=200 + i))
+        grads.append({n[len("vilt_encoder."):]: g for n, g in G.items() if n.startswith(vo.ENC)})
+    fisher = vo.fisher_from_batch_grads(grads, [B] * nb)
+    names = [str(n) for n in z["names"]]
+    norms, heads = _summary(fisher, names)
+    _close(norms, z["fisher_norms"], 5e-4, "fisher norms")
+    _close(heads, z["fisher_heads"], 5e-4, "fisher heads")
+
+
+def test_replay_fresh_adamw(golden_dir):
+    z = np.load(os.path.join(golden_dir, "replay_b2.npz"))
+    m = _meta(z)
+    B = int(m["B"])
+    P = vo.init_params(m["tasks"].split(","), int(m["wseed"]))
+    P0 = {n: t.clone() for n, t in P.items()}
+    loss, _, _, _ = vo.train_step(P, "vqa", vo.synthetic_encodings(B, seed=int(m["dseed"])),
+                                  vo.synthetic_vqa_targets(B, seed=int(m["dseed"])), opt_state={}, lr=float(m["lr"]))
+    _close(loss, z["loss"], 2e-5, "loss")
+    names = [str(n) for n in z["names"]]
+    norms, _ = _summary({n: P[n] - P0[n] for n in names}, names)
+    _close(norms, z["delta_norms"], 2e-3, "param delta norms")
+
+
+def test_ten_steps_config1(golden_dir):
+    """BASELINE.json configs[0]: ViLT sequential-FT on VQAv2, batch=2, 10 steps, CPU."""
+    z = np.load(os.path.join(golden_dir, "vqa_b2_10steps.npz"))
+    m = _meta(z)
+    B, steps = int(m["B"]), int(m["steps"])
+    P = vo.init_params(m["tasks"].split(","), int(m["wseed"]))
+    P0 = {n: t.clone() for n, t in P.items()}
+    state, losses = {}, []
+    for s in range(steps):
+        lr = vo.poly_lr(s, float(m["lr"]), int(steps * 0.1), steps)
+        loss, _, _, _ = vo.train_step(P, "vqa", vo.synthetic_encodings(B, seed=100 + s),
+                                      vo.synthetic_vqa_targets(B, seed=100 + s), opt_state=state, lr=lr)
+        losses.append(loss.item())
+    _close(losses, z["losses"], 1e-4, "loss curve")
+    names = [str(n) for n in z["names"]]
+    norms, _ = _summary({n: P[n] - P0[n] for n in names}, names)
+    _close(norms, z["delta_norms"], 3e-3, "param delta norms")
+
+
+def test_decay_grouping_quirk():
+    """REF/modeling/vilt.py:209-213 substring grouping: only text_embeddings.LayerNorm.weight is exempt among gains."""
+    names = list(vo.param_shapes(["vqa", "nlvr2"]).keys())
+    nd = [n for n in names if vo.no_decay(n)]
+    gains_exempt = [n for n in nd if not n.endswith("bias")]
+    assert gains_exempt == [vo.ENC + "embeddings.text_embeddings.LayerNorm.weight"]
+    assert not vo.no_decay(vo.ENC + "encoder.layer.0.layernorm_before.weight")
+    assert not vo.no_decay(vo.ENC + "embeddings.cls_token")
+
+
+def test_poly_schedule_matches_transformers():
+    from transformers import get_polynomial_decay_schedule_with_warmup
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.AdamW([p], lr=1e-4)
+    sch = get_polynomial_decay_schedule_with_warmup(opt, num_warmup_steps=3, num_training_steps=30, lr_end=0, power=1)
+    for s in range(32):
+        assert abs(opt.param_groups[0]["lr"] - vo.poly_lr(s, 1e-4, 3, 30)) < 1e-12
+        opt.step()
+        sch.step()
