@@ -1,0 +1,79 @@
+"""ctypes binding of libclimb_hip.so.  `include/climb_hip.h` is the single source of truth: prototypes are parsed
+from it, so the Python side cannot drift from the C ABI.  There is NO fallback: if the library is missing the
+product path raises."""
+from __future__ import annotations
+
+import ctypes
+import os
+import re
+from typing import Dict, List, Tuple
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+HEADER = os.path.join(os.path.dirname(_HERE), "include", "climb_hip.h")
+LIB_PATH = os.path.join(_HERE, "csrc", "libclimb_hip.so")
+
+_PROTO = re.compile(r"^\s*(int|const char\*)\s+(climb_\w+)\s*\(([^)]*)\)\s*;", re.M)
+
+
+def parse_header(path: str = HEADER) -> Dict[str, Tuple[str, List[str]]]:
+    """name -> (return type, [argument C types])."""
+    with open(path) as f:
+        txt = re.sub(r"/\*.*?\*/", "", f.read(), flags=re.S)
+    out = {}
+    for ret, name, args in _PROTO.findall(txt):
+        args = args.strip()
+        types = []
+        if args and args != "void":
+            for a in args.split(","):
+                a = a.strip()
+                types.append("ptr" if "*" in a else a.split()[-2] if len(a.split()) > 1 else a)
+        out[name] = (ret, types)
+    return out
+
+
+_CT = {"ptr": ctypes.c_void_p, "long": ctypes.c_long, "int": ctypes.c_int, "float": ctypes.c_float}
+_lib = None
+_protos = None
+
+
+def load():
+    global _lib, _protos
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"climb_amd: HIP library not built ({LIB_PATH} missing). Run `python -m climb_amd.build` "
+            "(hipcc --offload-arch=gfx950). There is no CPU/PyTorch fallback for the device path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    _protos = parse_header()
+    for name, (ret, types) in _protos.items():
+        fn = getattr(lib, name)   # AttributeError here == header/library mismatch
+        fn.restype = ctypes.c_int if ret == "int" else ctypes.c_char_p
+        fn.argtypes = [_CT[t] for t in types]
+    _lib = lib
+    return lib
+
+
+def error_string(code: int) -> str:
+    s = load().climb_error_string(code)
+    return s.decode() if s else f"error {code}"
+
+
+def _conv(a):
+    if a is None:
+        return None
+    if hasattr(a, "data_ptr"):
+        return a.data_ptr()
+    return a
+
+
+def call(name: str, *args):
+    """Invoke an `int climb_*` launcher; tensors are passed as raw device pointers; non-zero -> RuntimeError."""
+    fn = getattr(load(), name)
+    rc = fn(*[_conv(a) for a in args])
+    if rc != 0:
+        raise RuntimeError(f"{name} failed: {error_string(rc)} (code {rc})")
+
+
+def query(name: str) -> int:
+    return getattr(load(), name)()

@@ -1,0 +1,128 @@
+"""Elastic Weight Consolidation with the reference's plugin surface (REF/cl_algorithms/ewc.py:16-89), device-resident.
+
+The reference keeps theta* and the Fisher diagonal on the CPU and re-uploads 0.89 GB of them on EVERY training step
+(ewc.py:84-85), then runs 206 x (sub, pow, mul, sum) tiny kernels.  Here both live in HBM as flat fp32 vectors laid out
+exactly like the encoder range of the parameter buffer, so the penalty and its gradient are ONE streaming kernel
+(20 B per encoder parameter), and the Fisher estimate never leaves the device.  `fisher_dict` / `param_dict` keep the
+reference's shape (task -> {encoder-relative name `vilt.*` -> tensor}) as views of those vectors."""
+from __future__ import annotations
+
+import argparse
+import logging
+import random
+from typing import Dict
+
+import torch
+
+from .. import _lib
+
+logger = logging.getLogger(__name__)
+
+
+def _views(flat: torch.Tensor, eng) -> Dict[str, torch.Tensor]:
+    lay = eng.layout
+    out = {}
+    for n in lay.shapes:
+        if n.startswith("vilt_encoder."):
+            o = lay.offset[n]
+            out[n[len("vilt_encoder."):]] = flat[o:o + lay.numel(n)].view(lay.shapes[n])
+    return out
+
+
+class _EwcLossFn(torch.autograd.Function):
+    """`compute_ewc_loss` result that participates in autograd, for reference-style trainers that do
+    `(loss + ewc_loss).backward()` (REF train_vqa.py:159-162)."""
+
+    @staticmethod
+    def forward(ctx, sentinel, ewc, model, task_key):
+        eng = model._host.engine()
+        ctx.args = (ewc, model, task_key)
+        return eng.ewc_penalty(ewc.param_flat[task_key], ewc.fisher_flat[task_key], ewc.ewc_loss_weight, add_grad=False)
+
+    @staticmethod
+    def backward(ctx, gout):
+        ewc, model, task_key = ctx.args
+        host = model._host
+        eng = host.engine()
+        host.before_backward()
+        eng.ewc_penalty(ewc.param_flat[task_key], ewc.fisher_flat[task_key], ewc.ewc_loss_weight, add_grad=True, gscale=float(gout))
+        eng.touched.append((0, eng.layout.encoder_end))
+        host.after_backward()
+        return None, None, None, None
+
+
+class EWC:
+    def __init__(self, args: argparse.Namespace):
+        self.fisher_sample_percentage = args.ewc_fisher_sample_percentage
+        self.ewc_loss_weight = args.ewc_loss_weight
+        self.fisher_dict = {}
+        self.param_dict = {}
+        self.fisher_flat: Dict[str, torch.Tensor] = {}
+        self.param_flat: Dict[str, torch.Tensor] = {}
+        self.task_keys = []
+
+    def save_task_parameters(self, task_key: str, model, task_trainer, device: torch.device):
+        """REF ewc.py:28-73, including its quirk: `train_step` is called WITHOUT an optimizer, so gradients keep
+        accumulating across batches and batch k contributes (sum_{j<=k} g_j)^2."""
+        model.to(device) if next(model.parameters()).device != torch.device(device) else None
+        host = model._host
+        eng = host.engine()
+        n = eng.layout.encoder_end
+        self.param_flat[task_key] = eng.flat[:n].clone()
+        fisher = torch.zeros(n, dtype=torch.float32, device=eng.device)
+        assert task_key not in self.task_keys
+        self.task_keys.append(task_key)
+        dataloader = task_trainer.get_train_dataloader()
+        fisher_sample_size = int(self.fisher_sample_percentage * len(dataloader.dataset))
+        self.device = task_trainer.device
+        optimizer = model.create_optimizer(task_trainer.hparams)
+        optimizer.zero_grad()
+        num_samples_completed = 0
+        for step, batch in enumerate(dataloader):
+            task_trainer.train_step(model, batch)
+            eng = host.engine()
+            eng.fisher_accumulate(fisher)
+            num_samples_completed += len(batch["raw_texts"])
+            if num_samples_completed >= fisher_sample_size:
+                break
+        _lib.call("climb_scale", fisher, n, 1.0 / max(1, num_samples_completed), torch.cuda.current_stream().cuda_stream)
+        self.fisher_flat[task_key] = fisher
+        self.fisher_dict[task_key] = _views(fisher, eng)
+        self.param_dict[task_key] = _views(self.param_flat[task_key], eng)
+        logger.info("Saved encoder parameters for {} task!".format(task_key))
+
+    def set_task_state(self, task_key: str, model, fisher_named: Dict[str, torch.Tensor], param_named: Dict[str, torch.Tensor]):
+        """Install an externally computed Fisher / theta* (dicts keyed like the reference's: `vilt.*`)."""
+        eng = model._host.engine()
+        n = eng.layout.encoder_end
+        f = torch.zeros(n, dtype=torch.float32, device=eng.device)
+        s = eng.flat[:n].clone()
+        fv, sv = _views(f, eng), _views(s, eng)
+        for k in fv:
+            fv[k].copy_(fisher_named[k])
+            sv[k].copy_(param_named[k])
+        self.fisher_flat[task_key], self.param_flat[task_key] = f, s
+        self.fisher_dict[task_key], self.param_dict[task_key] = fv, sv
+        if task_key not in self.task_keys:
+            self.task_keys.append(task_key)
+
+    def compute_ewc_loss(self, model):
+        """REF ewc.py:75-87: one previous task sampled with Python's `random`; returns (task, lambda * sum F (theta-theta*)^2)."""
+        ewc_task_key = random.choice(self.task_keys)
+        sentinel = next(p for p in model.get_encoder().parameters())
+        if torch.is_grad_enabled() and any(p.requires_grad for p in model.get_encoder().parameters()):
+            return ewc_task_key, _EwcLossFn.apply(sentinel, self, model, ewc_task_key)
+        eng = model._host.engine()
+        return ewc_task_key, eng.ewc_penalty(self.param_flat[ewc_task_key], self.fisher_flat[ewc_task_key], self.ewc_loss_weight, add_grad=False)
+
+    def add_penalty_gradient(self, model):
+        """Fused-step form: penalty value AND its gradient 2*lambda*F*(theta-theta*) added into the flat grad buffer in one
+        pass.  Under data parallelism this runs AFTER the gradient all-reduce (the term is identical on every rank)."""
+        ewc_task_key = random.choice(self.task_keys)
+        eng = model._host.engine()
+        loss = eng.ewc_penalty(self.param_flat[ewc_task_key], self.fisher_flat[ewc_task_key], self.ewc_loss_weight, add_grad=True)
+        eng.touched.append((0, eng.layout.encoder_end))
+        return ewc_task_key, loss
+
+    def do_ewc(self):
+        return True if len(self.task_keys) > 0 else False

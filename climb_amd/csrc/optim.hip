@@ -1,0 +1,180 @@
+// HBM-bound flat-buffer kernels: fused multi-tensor AdamW, the EWC Fisher-weighted penalty (value + gradient in one
+// pass), Fisher square-accumulate, and the fp32 -> bf16 weight shadow.  Every parameter of the learner lives in ONE
+// flat fp32 buffer (each tensor 64-element aligned), so each of these is a single launch streaming at HBM rate.
+#include "common.h"
+
+struct AdamGroup { float lr, wd, beta1, beta2, eps, bc1, bc2, pad; };
+struct AdamGroups { AdamGroup g[8]; };
+
+// seg_start[nseg+1]: element offsets of the tensors (ascending, multiples of 4); seg_group[nseg]: group id or -1 (skip).
+__device__ __forceinline__ int find_seg(const long* __restrict__ seg_start, int nseg, long e) {
+  int lo = 0, hi = nseg;  // largest i with seg_start[i] <= e
+  while (hi - lo > 1) {
+    int mid = (lo + hi) >> 1;
+    if (seg_start[mid] <= e) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+// torch.optim.AdamW semantics (decoupled decay), REF/modeling/vilt.py:205-215:
+//   p *= 1 - lr*wd;  m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;  p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
+template <bool SHADOW>
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, bf16_t* __restrict__ shadow, long n, const long* __restrict__ seg_start,
+                                                    const signed char* __restrict__ seg_group, int nseg, AdamGroups groups, float gscale) {
+  for (long e = ((long)blockIdx.x * 256 + threadIdx.x) * 4; e < n; e += (long)gridDim.x * 1024) {
+    const int sg = seg_group[find_seg(seg_start, nseg, e)];
+    if (sg < 0) continue;
+    const AdamGroup G = groups.g[sg];
+    float4 pp = ld4(p + e), gg = ld4(g + e), mm = ld4(m + e), vv = ld4(v + e);
+    float pa[4] = {pp.x, pp.y, pp.z, pp.w}, ga[4] = {gg.x, gg.y, gg.z, gg.w}, ma[4] = {mm.x, mm.y, mm.z, mm.w}, va[4] = {vv.x, vv.y, vv.z, vv.w};
+    const float isb2 = rsqrtf(G.bc2), step = G.lr / G.bc1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float gr = ga[j] * gscale;
+      pa[j] *= 1.f - G.lr * G.wd;
+      ma[j] = G.beta1 * ma[j] + (1.f - G.beta1) * gr;
+      va[j] = G.beta2 * va[j] + (1.f - G.beta2) * gr * gr;
+      pa[j] -= step * ma[j] / (sqrtf(va[j]) * isb2 + G.eps);
+    }
+    st4(p + e, make_float4(pa[0], pa[1], pa[2], pa[3]));
+    st4(m + e, make_float4(ma[0], ma[1], ma[2], ma[3]));
+    st4(v + e, make_float4(va[0], va[1], va[2], va[3]));
+    if (SHADOW) st4(shadow + e, make_float4(pa[0], pa[1], pa[2], pa[3]));
+  }
+}
+
+extern "C" int climb_adamw(float* p, const float* g, float* m, float* v, void* shadow_bf16, long n, const long* seg_start,
+                           const signed char* seg_group, int nseg, const float* groups, int ngroups, float gscale, void* stream) {
+  if (n <= 0 || n % 4 || nseg <= 0 || ngroups <= 0 || ngroups > 8) return CLIMB_EINVAL;
+  AdamGroups G;
+  for (int i = 0; i < 8; ++i) {
+    const float* s = groups + (i < ngroups ? i : 0) * 8;
+    G.g[i] = AdamGroup{s[0], s[1], s[2], s[3], s[4], s[5], s[6], 0.f};
+  }
+  long nb = (n / 4 + 255) / 256;
+  dim3 grid((unsigned)(nb < 16384 ? nb : 16384)), blk(256);
+  if (shadow_bf16)
+    hipLaunchKernelGGL((adamw_kernel<true>), grid, blk, 0, (hipStream_t)stream, p, g, m, v, (bf16_t*)shadow_bf16, n, seg_start, seg_group, nseg, G, gscale);
+  else
+    hipLaunchKernelGGL((adamw_kernel<false>), grid, blk, 0, (hipStream_t)stream, p, g, m, v, (bf16_t*)nullptr, n, seg_start, seg_group, nseg, G, gscale);
+  LAUNCH_CHECK();
+  return CLIMB_OK;
+}
+
+// EWC (REF/cl_algorithms/ewc.py:75-87): loss = lam * sum F (theta - theta*)^2 ;  dloss/dtheta = 2 lam F (theta - theta*).
+// One pass over the encoder range: block partial sums -> partials[grid]; grad (optional) accumulated in place.
+__global__ __launch_bounds__(256) void ewc_kernel(const float* __restrict__ theta, const float* __restrict__ star, const float* __restrict__ fisher,
+                                                  float* __restrict__ grad, long n, float two_lam_gs, float* __restrict__ partials) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  for (long e = ((long)blockIdx.x * 256 + threadIdx.x) * 4; e < n; e += (long)gridDim.x * 1024) {
+    float4 t = ld4(theta + e), s = ld4(star + e), f = ld4(fisher + e);
+    float dx = t.x - s.x, dy = t.y - s.y, dz = t.z - s.z, dw = t.w - s.w;
+    acc += f.x * dx * dx + f.y * dy * dy + f.z * dz * dz + f.w * dw * dw;
+    if (grad) {
+      float4 g = ld4(grad + e);
+      st4(grad + e, make_float4(g.x + two_lam_gs * f.x * dx, g.y + two_lam_gs * f.y * dy, g.z + two_lam_gs * f.z * dz, g.w + two_lam_gs * f.w * dw));
+    }
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ partials, int n, float scale, float* __restrict__ out) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) acc += partials[i];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) *out = scale * ((red[0] + red[1]) + (red[2] + red[3]));
+}
+#define EWC_BLOCKS 2048
+extern "C" int climb_ewc_workspace_floats() { return EWC_BLOCKS; }
+// loss_out = lam * sum F (theta-theta*)^2 ; if grad != NULL: grad += gscale * 2 lam F (theta - theta*)
+extern "C" int climb_ewc_penalty(const float* theta, const float* star, const float* fisher, float* grad, long n, float lam, float gscale,
+                                 float* partials, float* loss_out, void* stream) {
+  if (n <= 0 || n % 4) return CLIMB_EINVAL;
+  long nb = (n / 4 + 255) / 256;
+  int grid = (int)(nb < EWC_BLOCKS ? nb : EWC_BLOCKS);
+  hipLaunchKernelGGL(ewc_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, theta, star, fisher, grad, n, 2.f * lam * gscale, partials);
+  LAUNCH_CHECK();
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partials, grid, lam, loss_out);
+  LAUNCH_CHECK();
+  return CLIMB_OK;
+}
+
+// Fisher estimate (REF/cl_algorithms/ewc.py:62-64): F += g^2
+__global__ void fisher_accum_kernel(float* __restrict__ fisher, const float* __restrict__ grad, long n) {
+  for (long e = ((long)blockIdx.x * 256 + threadIdx.x) * 4; e < n; e += (long)gridDim.x * 1024) {
+    float4 f = ld4(fisher + e), g = ld4(grad + e);
+    st4(fisher + e, make_float4(f.x + g.x * g.x, f.y + g.y * g.y, f.z + g.z * g.z, f.w + g.w * g.w));
+  }
+}
+extern "C" int climb_fisher_accum(float* fisher, const float* grad, long n, void* stream) {
+  if (n <= 0 || n % 4) return CLIMB_EINVAL;
+  long nb = (n / 4 + 255) / 256;
+  hipLaunchKernelGGL(fisher_accum_kernel, dim3((unsigned)(nb < 16384 ? nb : 16384)), dim3(256), 0, (hipStream_t)stream, fisher, grad, n);
+  LAUNCH_CHECK();
+  return CLIMB_OK;
+}
+
+// x *= s   (Fisher / num_samples; gradient averaging under data parallelism)
+__global__ void scale_kernel(float* __restrict__ x, long n, float s) {
+  for (long e = ((long)blockIdx.x * 256 + threadIdx.x) * 4; e < n; e += (long)gridDim.x * 1024) {
+    float4 v = ld4(x + e);
+    st4(x + e, make_float4(v.x * s, v.y * s, v.z * s, v.w * s));
+  }
+}
+extern "C" int climb_scale(float* x, long n, float s, void* stream) {
+  if (n <= 0 || n % 4) return CLIMB_EINVAL;
+  long nb = (n / 4 + 255) / 256;
+  hipLaunchKernelGGL(scale_kernel, dim3((unsigned)(nb < 16384 ? nb : 16384)), dim3(256), 0, (hipStream_t)stream, x, n, s);
+  LAUNCH_CHECK();
+  return CLIMB_OK;
+}
+
+// fp32 master -> bf16 shadow (round-to-nearest-even), flat
+__global__ void cast_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, long n) {
+  for (long e = ((long)blockIdx.x * 256 + threadIdx.x) * 4; e < n; e += (long)gridDim.x * 1024) st4(y + e, ld4(x + e));
+}
+extern "C" int climb_cast_bf16(const float* x, void* y, long n, void* stream) {
+  if (n <= 0 || n % 4) return CLIMB_EINVAL;
+  long nb = (n / 4 + 255) / 256;
+  hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned)(nb < 16384 ? nb : 16384)), dim3(256), 0, (hipStream_t)stream, x, (bf16_t*)y, n);
+  LAUNCH_CHECK();
+  return CLIMB_OK;
+}
+
+// bf16 [R, C] -> [C, R] (weight shadows for the dX GEMMs), 64x64 tiles through LDS
+__global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out, int R, int C) {
+  __shared__ bf16_t tile[64][66];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+    int r = e >> 6, c = e & 63;
+    tile[r][c] = (r0 + r < R && c0 + c < C) ? in[(long)(r0 + r) * C + c0 + c] : (bf16_t)0;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+    int c = e >> 6, r = e & 63;
+    if (r0 + r < R && c0 + c < C) out[(long)(c0 + c) * R + r0 + r] = tile[r][c];
+  }
+}
+extern "C" int climb_transpose_bf16(const void* in, void* out, int R, int C, void* stream) {
+  if (R <= 0 || C <= 0) return CLIMB_EINVAL;
+  hipLaunchKernelGGL(transpose_bf16_kernel, dim3((C + 63) / 64, (R + 63) / 64), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in, (bf16_t*)out, R, C);
+  LAUNCH_CHECK();
+  return CLIMB_OK;
+}
+
+extern "C" int climb_version() { return 100; }
+extern "C" const char* climb_arch() { return "gfx950"; }
+extern "C" const char* climb_error_string(int code) {
+  if (code == CLIMB_OK) return "ok";
+  if (code == CLIMB_EINVAL) return "climb: invalid argument";
+  if (code == CLIMB_EUNSUPPORTED) return "climb: unsupported shape";
+  return hipGetErrorString((hipError_t)code);
+}
+extern "C" int climb_device_sync() { return (int)hipDeviceSynchronize(); }

@@ -1,0 +1,582 @@
+// HBM-bound row-wise kernels of the ViLT step: LayerNorm fwd/bwd, embeddings, im2col, column sums,
+// activations and losses.  One wave (64 lanes) owns one row; each lane keeps NV float4 of it in registers,
+// so every row is read from HBM exactly once per kernel.  gfx950 only.
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm forward:  y = (x - mean) * rstd * gamma + beta      (HF modeling_vilt.py:430-451 uses it twice
+// per layer with eps=1e-12; REF/modeling/vilt.py:192 head LN with eps=1e-5)
+// x is the fp32 residual stream; y has the GEMM operand type TO.  Optional `add` [C] is added after the affine
+// (text rows add the modality-type embedding, HF:208-210).
+template <typename TO, int NV>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, long ldx, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float eps, TO* __restrict__ y, long ldy,
+                                                            float* __restrict__ mean_out, float* __restrict__ rstd_out, int M, int C) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const float* xr = x + (long)row * ldx;
+  float4 v[NV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    int c = (i * 64 + lane) * 4;
+    v[i] = (c < C) ? ld4(xr + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    s += v[i].x + v[i].y + v[i].z + v[i].w;
+  }
+  const float mean = wave_sum(s) / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    int c = (i * 64 + lane) * 4;
+    if (c < C) {
+      float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
+      q += a * a + b * b + cc * cc + d * d;
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+  if (lane == 0) {
+    if (mean_out) mean_out[row] = mean;
+    if (rstd_out) rstd_out[row] = rstd;
+  }
+  TO* yr = y + (long)row * ldy;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    int c = (i * 64 + lane) * 4;
+    if (c < C) {
+      float4 g = ld4(gamma + c), b = ld4(beta + c);
+      float4 o = make_float4((v[i].x - mean) * rstd * g.x + b.x, (v[i].y - mean) * rstd * g.y + b.y,
+                             (v[i].z - mean) * rstd * g.z + b.z, (v[i].w - mean) * rstd * g.w + b.w);
+      st4(yr + c, o);
+    }
+  }
+}
+
+template <typename TO>
+static int layernorm_fwd_launch(const float* x, long ldx, const float* g, const float* b, float eps, TO* y, long ldy, float* mean,
+                                float* rstd, int M, int C, hipStream_t st) {
+  if (C % 4 || M <= 0) return CLIMB_EINVAL;
+  dim3 grid((M + 3) / 4), blk(256);
+  if (C <= 768) hipLaunchKernelGGL((layernorm_fwd_kernel<TO, 3>), grid, blk, 0, st, x, ldx, g, b, eps, y, ldy, mean, rstd, M, C);
+  else if (C <= 1536) hipLaunchKernelGGL((layernorm_fwd_kernel<TO, 6>), grid, blk, 0, st, x, ldx, g, b, eps, y, ldy, mean, rstd, M, C);
+  else return CLIMB_EUNSUPPORTED;
+  LAUNCH_CHECK();
+  return CLIMB_OK;
+}
+
+extern "C" int climb_layernorm_fwd(const float* x, long ldx, const float* gamma, const float* beta, float eps, void* y, long ldy,
+                                   int y_dtype, float* mean, float* rstd, int M, int C, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (y_dtype == CLIMB_DT_F32) return layernorm_fwd_launch<float>(x, ldx, gamma, beta, eps, (float*)y, ldy, mean, rstd, M, C, st);
+  if (y_dtype == CLIMB_DT_BF16) return layernorm_fwd_launch<bf16_t>(x, ldx, gamma, beta, eps, (bf16_t*)y, ldy, mean, rstd, M, C, st);
+  return CLIMB_EINVAL;
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm backward fused with the residual-gradient stream:
+//   dxo = dres_in + rstd * (g - mean_c(g) - xhat * mean_c(g * xhat)),  g = dy * gamma, xhat = (x - mean) * rstd
+// Writes dxo (fp32, may alias dres_in), an optional cast of it (next GEMM operand), and per-block partial column
+// sums  part[blk][0]=dgamma, [1]=dbeta, [2]=colsum(dxo)  (reduced deterministically by climb_colreduce).
+#define LNB_ROWS 32  // rows per block (4 waves x 8 rows)
+template <typename TI, typename TO, int NV>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TI* __restrict__ dy, long lddy, const float* __restrict__ x, long ldx,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            const float* __restrict__ gamma, const float* dres_in, long ldr,
+                                                            float* dxo, long ldo, TO* __restrict__ dcast, long ldc,
+                                                            float* __restrict__ part, int M, int C) {
+  __shared__ __attribute__((aligned(16))) float red[4][NV * 256];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  float4 ag[NV], ab[NV], as[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) ag[i] = ab[i] = as[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 gm[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    int c = (i * 64 + lane) * 4;
+    gm[i] = (c < C) ? ld4(gamma + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  for (int rr = 0; rr < LNB_ROWS / 4; ++rr) {
+    const int row = blockIdx.x * LNB_ROWS + rr * 4 + wid;
+    if (row >= M) break;
+    const float mu = mean[row], rs = rstd[row];
+    float4 xh[NV], g[NV], d[NV];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      int c = (i * 64 + lane) * 4;
+      if (c < C) {
+        float4 xv = ld4(x + (long)row * ldx + c);
+        d[i] = ld4(dy + (long)row * lddy + c);
+        xh[i] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
+        g[i] = make_float4(d[i].x * gm[i].x, d[i].y * gm[i].y, d[i].z * gm[i].z, d[i].w * gm[i].w);
+        s1 += g[i].x + g[i].y + g[i].z + g[i].w;
+        s2 += g[i].x * xh[i].x + g[i].y * xh[i].y + g[i].z * xh[i].z + g[i].w * xh[i].w;
+      } else {
+        xh[i] = g[i] = d[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+    const float m1 = wave_sum(s1) / (float)C, m2 = wave_sum(s2) / (float)C;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      int c = (i * 64 + lane) * 4;
+      if (c < C) {
+        float4 r = dres_in ? ld4(dres_in + (long)row * ldr + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 o = make_float4(r.x + rs * (g[i].x - m1 - xh[i].x * m2), r.y + rs * (g[i].y - m1 - xh[i].y * m2),
+                               r.z + rs * (g[i].z - m1 - xh[i].z * m2), r.w + rs * (g[i].w - m1 - xh[i].w * m2));
+        st4(dxo + (long)row * ldo + c, o);
+        if (dcast) st4(dcast + (long)row * ldc + c, o);
+        ag[i].x += d[i].x * xh[i].x; ag[i].y += d[i].y * xh[i].y; ag[i].z += d[i].z * xh[i].z; ag[i].w += d[i].w * xh[i].w;
+        ab[i].x += d[i].x; ab[i].y += d[i].y; ab[i].z += d[i].z; ab[i].w += d[i].w;
+        as[i].x += o.x; as[i].y += o.y; as[i].z += o.z; as[i].w += o.w;
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    if (k) __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      int c = (i * 64 + lane) * 4;
+      *reinterpret_cast<float4*>(&red[wid][c]) = (k == 0 ? ag[i] : (k == 1 ? ab[i] : as[i]));
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256)
+      part[((long)blockIdx.x * 3 + k) * C + c] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+  }
+}
+
+template <typename TI, typename TO>
+static int layernorm_bwd_launch(const TI* dy, long lddy, const float* x, long ldx, const float* mean, const float* rstd, const float* gamma,
+                                const float* dres_in, long ldr, float* dxo, long ldo, TO* dcast, long ldc, float* part, int M, int C,
+                                hipStream_t st) {
+  if (C % 4 || M <= 0) return CLIMB_EINVAL;
+  dim3 grid((M + LNB_ROWS - 1) / LNB_ROWS), blk(256);
+  if (C <= 768)
+    hipLaunchKernelGGL((layernorm_bwd_kernel<TI, TO, 3>), grid, blk, 0, st, dy, lddy, x, ldx, mean, rstd, gamma, dres_in, ldr, dxo, ldo, dcast, ldc, part, M, C);
+  else if (C <= 1536)
+    hipLaunchKernelGGL((layernorm_bwd_kernel<TI, TO, 6>), grid, blk, 0, st, dy, lddy, x, ldx, mean, rstd, gamma, dres_in, ldr, dxo, ldo, dcast, ldc, part, M, C);
+  else return CLIMB_EUNSUPPORTED;
+  LAUNCH_CHECK();
+  return CLIMB_OK;
+}
+
+// part must hold ceil(M/32)*3*C floats.  dtype applies to dy and dcast.
+extern "C" int climb_layernorm_bwd(const void* dy, long lddy, int dtype, const float* x, long ldx, const float* mean, const float* rstd,
+                                   const float* gamma, const float* dres_in, long ldr, float* dxo, long ldo, void* dcast, long ldc,
+                                   float* part, int M, int C, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == CLIMB_DT_F32)
+    return layernorm_bwd_launch<float, float>((const float*)dy, lddy, x, ldx, mean, rstd, gamma, dres_in, ldr, dxo, ldo, (float*)dcast, ldc, part, M, C, st);
+  if (dtype == CLIMB_DT_BF16)
+    return layernorm_bwd_launch<bf16_t, bf16_t>((const bf16_t*)dy, lddy, x, ldx, mean, rstd, gamma, dres_in, ldr, dxo, ldo, (bf16_t*)dcast, ldc, part, M, C, st);
+  return CLIMB_EINVAL;
+}
+extern "C" int climb_layernorm_bwd_rows_per_block() { return LNB_ROWS; }
+
+// out[c] = beta*out[c] + sum_b part[b*stride + c]     (deterministic second stage of every column reduction)
+__global__ void colreduce_kernel(const float* __restrict__ part, long stride, int nblk, float* __restrict__ out, int ncols, float beta) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ncols) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int b = 0;
+  for (; b + 3 < nblk; b += 4) {
+    s0 += part[(long)b * stride + c];
+    s1 += part[(long)(b + 1) * stride + c];
+    s2 += part[(long)(b + 2) * stride + c];
+    s3 += part[(long)(b + 3) * stride + c];
+  }
+  for (; b < nblk; ++b) s0 += part[(long)b * stride + c];
+  float s = (s0 + s1) + (s2 + s3);
+  out[c] = (beta != 0.f ? beta * out[c] : 0.f) + s;
+}
+extern "C" int climb_colreduce(const float* part, long stride, int nblk, float* out, int ncols, float beta, void* stream) {
+  if (ncols <= 0 || nblk <= 0) return CLIMB_EINVAL;
+  hipLaunchKernelGGL(colreduce_kernel, dim3((ncols + 127) / 128), dim3(128), 0, (hipStream_t)stream, part, stride, nblk, out, ncols, beta);
+  LAUNCH_CHECK();
+  return CLIMB_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Column sums of a [M,C] activation (bias gradients) -> part[rowblk][C]; optional fp32->TO cast of the input.
+#define CS_ROWS 64
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void colsum_kernel(const TI* __restrict__ x, long ldx, TO* __restrict__ cast, long ldc, float* __restrict__ part,
+                                                     int M, int C) {
+  const int c = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (c >= C) return;
+  const int r0 = blockIdx.y * CS_ROWS;
+  const int r1 = min(M, r0 + CS_ROWS);
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int r = r0; r < r1; ++r) {
+    float4 v = ld4(x + (long)r * ldx + c);
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    if (cast) st4(cast + (long)r * ldc + c, v);
+  }
+  *reinterpret_cast<float4*>(part + (long)blockIdx.y * C + c) = s;
+}
+extern "C" int climb_colsum_rows_per_block() { return CS_ROWS; }
+// x dtype in_dtype; optional cast output (bf16) only meaningful for f32 input.  part: ceil(M/64)*C floats.
+extern "C" int climb_colsum(const void* x, long ldx, int in_dtype, void* cast_bf16, long ldc, float* part, int M, int C, void* stream) {
+  if (C % 4 || M <= 0) return CLIMB_EINVAL;
+  dim3 grid((C / 4 + 255) / 256, (M + CS_ROWS - 1) / CS_ROWS), blk(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (in_dtype == CLIMB_DT_F32)
+    hipLaunchKernelGGL((colsum_kernel<float, bf16_t>), grid, blk, 0, st, (const float*)x, ldx, (bf16_t*)cast_bf16, ldc, part, M, C);
+  else if (in_dtype == CLIMB_DT_BF16)
+    hipLaunchKernelGGL((colsum_kernel<bf16_t, bf16_t>), grid, blk, 0, st, (const bf16_t*)x, ldx, (bf16_t*)nullptr, 0L, part, M, C);
+  else return CLIMB_EINVAL;
+  LAUNCH_CHECK();
+  return CLIMB_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Text embeddings (HF:237-269 TextEmbeddings + HF:208-210 modality add):
+//   x[b, t, :] = LN(word[ids[b,t]] + type[tt[b,t]] + pos[t]) * gamma + beta + modality[0]
+// One wave per token row; H <= 768.
+__global__ __launch_bounds__(256) void embed_text_fwd_kernel(const long* __restrict__ ids, const long* __restrict__ tts,
+                                                             const float* __restrict__ word, const float* __restrict__ type,
+                                                             const float* __restrict__ pos, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, const float* __restrict__ mod0, float eps,
+                                                             float* __restrict__ x, int B, int T, int S_pad, int H,
+                                                             float* __restrict__ mean_out, float* __restrict__ rstd_out) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= B * T) return;
+  const int b = row / T, t = row - b * T;
+  const long id = ids[row], tt = tts[row];
+  float4 v[3];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    int c = (i * 64 + lane) * 4;
+    if (c < H) {
+      float4 w = ld4(word + id * H + c), ty = ld4(type + tt * H + c), p = ld4(pos + (long)t * H + c);
+      v[i] = make_float4(w.x + ty.x + p.x, w.y + ty.y + p.y, w.z + ty.z + p.z, w.w + ty.w + p.w);
+      s += v[i].x + v[i].y + v[i].z + v[i].w;
+    } else v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  const float mean = wave_sum(s) / (float)H;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    int c = (i * 64 + lane) * 4;
+    if (c < H) {
+      float a = v[i].x - mean, bb = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
+      q += a * a + bb * bb + cc * cc + d * d;
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)H + eps);
+  if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
+  float* xr = x + ((long)b * S_pad + t) * H;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    int c = (i * 64 + lane) * 4;
+    if (c < H) {
+      float4 g = ld4(gamma + c), be = ld4(beta + c), m = ld4(mod0 + c);
+      st4(xr + c, make_float4((v[i].x - mean) * rstd * g.x + be.x + m.x, (v[i].y - mean) * rstd * g.y + be.y + m.y,
+                              (v[i].z - mean) * rstd * g.z + be.z + m.z, (v[i].w - mean) * rstd * g.w + be.w + m.w));
+    }
+  }
+}
+extern "C" int climb_embed_text_fwd(const long* ids, const long* tts, const float* word, const float* type, const float* pos,
+                                    const float* gamma, const float* beta, const float* mod0, float eps, float* x, int B, int T, int S_pad,
+                                    int H, float* mean, float* rstd, void* stream) {
+  if (H % 4 || H > 768) return CLIMB_EUNSUPPORTED;
+  hipLaunchKernelGGL(embed_text_fwd_kernel, dim3((B * T + 3) / 4), dim3(256), 0, (hipStream_t)stream, ids, tts, word, type, pos, gamma, beta,
+                     mod0, eps, x, B, T, S_pad, H, mean, rstd);
+  LAUNCH_CHECK();
+  return CLIMB_OK;
+}
+
+// Backward of the above.  dres rows [b, t, :] hold d(x).  Scatter-adds (atomics) into the word/type/pos tables;
+// per-block partials part[blk][0]=dgamma, [1]=dbeta, [2]=dmodality0 (colreduce'd by the caller).
+__global__ __launch_bounds__(256) void embed_text_bwd_kernel(const long* __restrict__ ids, const long* __restrict__ tts,
+                                                             const float* __restrict__ word, const float* __restrict__ type,
+                                                             const float* __restrict__ pos, const float* __restrict__ gamma,
+                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                             const float* __restrict__ dres, int B, int T, int S_pad, int H,
+                                                             float* dword, float* dtype_, float* dpos, float* __restrict__ part) {
+  __shared__ __attribute__((aligned(16))) float red[3][4][768];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  float4 ag[3], ab[3], am[3], gm[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    ag[i] = ab[i] = am[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    int c = (i * 64 + lane) * 4;
+    gm[i] = (c < H) ? ld4(gamma + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  for (int rr = 0; rr < 8; ++rr) {
+    const int row = blockIdx.x * 32 + rr * 4 + wid;
+    if (row >= B * T) break;
+    const int b = row / T, t = row - b * T;
+    const long id = ids[row], tt = tts[row];
+    const float mu = mean[row], rs = rstd[row];
+    float4 xh[3], g[3], d[3];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      int c = (i * 64 + lane) * 4;
+      if (c < H) {
+        float4 w = ld4(word + id * H + c), ty = ld4(type + tt * H + c), p = ld4(pos + (long)t * H + c);
+        d[i] = ld4(dres + ((long)b * S_pad + t) * H + c);
+        xh[i] = make_float4((w.x + ty.x + p.x - mu) * rs, (w.y + ty.y + p.y - mu) * rs, (w.z + ty.z + p.z - mu) * rs,
+                            (w.w + ty.w + p.w - mu) * rs);
+        g[i] = make_float4(d[i].x * gm[i].x, d[i].y * gm[i].y, d[i].z * gm[i].z, d[i].w * gm[i].w);
+        s1 += g[i].x + g[i].y + g[i].z + g[i].w;
+        s2 += g[i].x * xh[i].x + g[i].y * xh[i].y + g[i].z * xh[i].z + g[i].w * xh[i].w;
+      } else xh[i] = g[i] = d[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const float m1 = wave_sum(s1) / (float)H, m2 = wave_sum(s2) / (float)H;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      int c = (i * 64 + lane) * 4;
+      if (c < H) {
+        float o[4] = {rs * (g[i].x - m1 - xh[i].x * m2), rs * (g[i].y - m1 - xh[i].y * m2), rs * (g[i].z - m1 - xh[i].z * m2),
+                      rs * (g[i].w - m1 - xh[i].w * m2)};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (dword) atomicAdd(dword + id * H + c + j, o[j]);
+          if (dtype_) atomicAdd(dtype_ + tt * H + c + j, o[j]);
+          if (dpos) atomicAdd(dpos + (long)t * H + c + j, o[j]);
+        }
+        ag[i].x += d[i].x * xh[i].x; ag[i].y += d[i].y * xh[i].y; ag[i].z += d[i].z * xh[i].z; ag[i].w += d[i].w * xh[i].w;
+        ab[i].x += d[i].x; ab[i].y += d[i].y; ab[i].z += d[i].z; ab[i].w += d[i].w;
+        am[i].x += d[i].x; am[i].y += d[i].y; am[i].z += d[i].z; am[i].w += d[i].w;
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    int c = (i * 64 + lane) * 4;
+    *reinterpret_cast<float4*>(&red[0][wid][c]) = ag[i];
+    *reinterpret_cast<float4*>(&red[1][wid][c]) = ab[i];
+    *reinterpret_cast<float4*>(&red[2][wid][c]) = am[i];
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < 3 * H; idx += 256) {
+    int k = idx / H, c = idx - k * H;
+    part[((long)blockIdx.x * 3 + k) * H + c] = red[k][0][c] + red[k][1][c] + red[k][2][c] + red[k][3][c];
+  }
+}
+// part: ceil(B*T/32)*3*H floats
+extern "C" int climb_embed_text_bwd(const long* ids, const long* tts, const float* word, const float* type, const float* pos,
+                                    const float* gamma, const float* mean, const float* rstd, const float* dres, int B, int T, int S_pad, int H,
+                                    float* dword, float* dtype_, float* dpos, float* part, void* stream) {
+  if (H != 768) return CLIMB_EUNSUPPORTED;
+  hipLaunchKernelGGL(embed_text_bwd_kernel, dim3((B * T + 31) / 32), dim3(256), 0, (hipStream_t)stream, ids, tts, word, type, pos, gamma, mean,
+                     rstd, dres, B, T, S_pad, H, dword, dtype_, dpos, part);
+  LAUNCH_CHECK();
+  return CLIMB_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Patch projection operand (HF:292-300 Conv2d(3,768,k=32,s=32) == GEMM after im2col):
+//   out[(b*NP + py*gw + px), c*P*P + ky*P + kx] = pixel[b, c, py*P+ky, px*P+kx]
+template <typename TO>
+__global__ void im2col_kernel(const float* __restrict__ px, TO* __restrict__ out, int B, int Cc, int Hh, int Ww, int P) {
+  const long n4 = (long)B * Cc * Hh * Ww / 4;
+  const int gw = Ww / P, gh = Hh / P;
+  const int K = Cc * P * P;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    long e = i * 4;
+    int xw = (int)(e % Ww); long r = e / Ww;
+    int yh = (int)(r % Hh); r /= Hh;
+    int c = (int)(r % Cc); int b = (int)(r / Cc);
+    int pxi = xw / P, kx = xw - pxi * P, pyi = yh / P, ky = yh - pyi * P;
+    float4 v = ld4(px + e);
+    st4(out + ((long)(b * gh * gw + pyi * gw + pxi)) * K + c * P * P + ky * P + kx, v);
+  }
+}
+extern "C" int climb_im2col(const float* pixels, void* out, int out_dtype, int B, int C, int H, int W, int P, void* stream) {
+  if (P % 4 || H % P || W % P) return CLIMB_EINVAL;
+  long n4 = (long)B * C * H * W / 4;
+  int grid = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
+  hipStream_t st = (hipStream_t)stream;
+  if (out_dtype == CLIMB_DT_F32) hipLaunchKernelGGL((im2col_kernel<float>), dim3(grid), dim3(256), 0, st, pixels, (float*)out, B, C, H, W, P);
+  else if (out_dtype == CLIMB_DT_BF16) hipLaunchKernelGGL((im2col_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, pixels, (bf16_t*)out, B, C, H, W, P);
+  else return CLIMB_EINVAL;
+  LAUNCH_CHECK();
+  return CLIMB_OK;
+}
+
+// Image rows of the embedding (HF:168-173 cls/pos add, HF:211-213 modality add, HF:216 concat):
+//   x[b, T, :]       = cls + pos[0] + modality[type_b]
+//   x[b, T+1+p, :]   = proj[b*NP + p, :] + pos[1+p] + modality[type_b]
+//   x[b, S.., :]     = 0  (rows S..S_pad-1 are padding; masked as keys)
+__global__ void assemble_image_kernel(const float* __restrict__ proj, const float* __restrict__ cls, const float* __restrict__ pos,
+                                      const float* __restrict__ mod, const int* __restrict__ img_type, float* __restrict__ x, int B, int T,
+                                      int NP, int S_pad, int H) {
+  const int rows = S_pad - T;
+  const long n4 = (long)B * rows * H / 4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    long e = i * 4;
+    int c = (int)(e % H); long r = e / H;
+    int rr = (int)(r % rows); int b = (int)(r / rows);
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (rr <= NP) {
+      float4 p = ld4(pos + (long)rr * H + c), m = ld4(mod + (long)img_type[b] * H + c);
+      float4 v = (rr == 0) ? ld4(cls + c) : ld4(proj + ((long)b * NP + rr - 1) * H + c);
+      o = make_float4(v.x + p.x + m.x, v.y + p.y + m.y, v.z + p.z + m.z, v.w + p.w + m.w);
+    }
+    st4(x + ((long)b * S_pad + T + rr) * H + c, o);
+  }
+}
+extern "C" int climb_assemble_image(const float* proj, const float* cls, const float* pos, const float* mod, const int* img_type, float* x, int B,
+                                    int T, int NP, int S_pad, int H, void* stream) {
+  if (H % 4 || T + 1 + NP > S_pad) return CLIMB_EINVAL;
+  long n4 = (long)B * (S_pad - T) * H / 4;
+  int grid = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
+  hipLaunchKernelGGL(assemble_image_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, proj, cls, pos, mod, img_type, x, B, T, NP, S_pad, H);
+  LAUNCH_CHECK();
+  return CLIMB_OK;
+}
+
+// Backward of the image rows.  One thread per (image row rr in [0,NP], 4 columns): loops over the batch.
+//   dproj[b*NP+p, :] = cast(dres[b, T+1+p, :]);  dpos[rr, :] += sum_b dres[b, T+rr, :];  dcls += sum_b dres[b, T, :]
+//   part[rr][type][:] = sum_{b: type_b == type} dres[b, T+rr, :]   (colreduce'd over rr into dmodality by the caller)
+template <typename TO>
+__global__ void image_embed_bwd_kernel(const float* __restrict__ dres, const int* __restrict__ img_type, TO* __restrict__ dproj, float* dpos,
+                                       float* dcls, float* __restrict__ part, int B, int T, int NP, int S_pad, int H, int ntypes) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int per_row = H / 4;
+  if (i >= (NP + 1) * per_row) return;
+  const int rr = i / per_row, c = (i - rr * per_row) * 4;
+  float4 tot = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 pt[3];
+  pt[0] = pt[1] = pt[2] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int b = 0; b < B; ++b) {
+    float4 v = ld4(dres + ((long)b * S_pad + T + rr) * H + c);
+    tot.x += v.x; tot.y += v.y; tot.z += v.z; tot.w += v.w;
+    int ty = img_type[b];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      if (ty == k) { pt[k].x += v.x; pt[k].y += v.y; pt[k].z += v.z; pt[k].w += v.w; }
+    if (rr > 0 && dproj) st4(dproj + ((long)b * NP + rr - 1) * H + c, v);
+  }
+  if (dpos) {
+    float4 o = ld4(dpos + (long)rr * H + c);
+    st4(dpos + (long)rr * H + c, make_float4(o.x + tot.x, o.y + tot.y, o.z + tot.z, o.w + tot.w));
+  }
+  if (rr == 0 && dcls) {
+    float4 o = ld4(dcls + c);
+    st4(dcls + c, make_float4(o.x + tot.x, o.y + tot.y, o.z + tot.z, o.w + tot.w));
+  }
+  for (int k = 0; k < ntypes && k < 3; ++k) st4(part + ((long)rr * ntypes + k) * H + c, pt[k]);
+}
+// part: (NP+1)*ntypes*H floats
+extern "C" int climb_image_embed_bwd(const float* dres, const int* img_type, void* dproj, int dproj_dtype, float* dpos, float* dcls, float* part,
+                                     int B, int T, int NP, int S_pad, int H, int ntypes, void* stream) {
+  if (H % 4 || ntypes > 3) return CLIMB_EINVAL;
+  int n = (NP + 1) * (H / 4);
+  hipStream_t st = (hipStream_t)stream;
+  if (dproj_dtype == CLIMB_DT_F32)
+    hipLaunchKernelGGL((image_embed_bwd_kernel<float>), dim3((n + 127) / 128), dim3(128), 0, st, dres, img_type, (float*)dproj, dpos, dcls, part, B, T, NP, S_pad, H, ntypes);
+  else if (dproj_dtype == CLIMB_DT_BF16)
+    hipLaunchKernelGGL((image_embed_bwd_kernel<bf16_t>), dim3((n + 127) / 128), dim3(128), 0, st, dres, img_type, (bf16_t*)dproj, dpos, dcls, part, B, T, NP, S_pad, H, ntypes);
+  else return CLIMB_EINVAL;
+  LAUNCH_CHECK();
+  return CLIMB_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// small elementwise kernels for the pooler / task heads (fp32, [B, <=1536])
+__global__ void ew_kernel(int op, const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, long n, float s) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float x = a[i], r;
+    switch (op) {
+      case 0: r = gelu_f(x); break;                  // gelu fwd
+      case 1: r = x * dgelu_f(b[i]); break;          // gelu bwd: a=dy, b=pre-activation
+      case 2: r = x * (1.f - b[i] * b[i]); break;    // tanh bwd: a=dy, b=tanh output
+      case 3: r = x * b[i] * s; break;               // dropout: a=x, b=keep mask, s=1/(1-p)
+      case 4: r = x * s; break;                      // scale
+      case 5: r = x + b[i]; break;                   // add
+      default: r = x;
+    }
+    out[i] = r;
+  }
+}
+extern "C" int climb_elementwise(int op, const float* a, const float* b, float* out, long n, float s, void* stream) {
+  if (n <= 0) return CLIMB_EINVAL;
+  long nb = (n + 255) / 256;
+  hipLaunchKernelGGL(ew_kernel, dim3((int)(nb < 8192 ? nb : 8192)), dim3(256), 0, (hipStream_t)stream, op, a, b, out, n, s);
+  LAUNCH_CHECK();
+  return CLIMB_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Losses, fused with their gradient.
+// VQA (REF/train/visionlanguage_tasks/train_vqa.py:95,:157): BCEWithLogits(mean) * N  ==  sum_{b,n} bce / B.
+//   dlogits = gscale * (sigmoid(x) - t) / B.   Single block => deterministic reduction.
+__global__ __launch_bounds__(1024) void bce_logits_kernel(const float* __restrict__ logits, long ldl, const float* __restrict__ target, long ldt,
+                                                          float* __restrict__ dlogits, long ldd, float* __restrict__ loss, int B, int N,
+                                                          float gscale) {
+  __shared__ float red[16];
+  float acc = 0.f;
+  const float invB = 1.f / (float)B;
+  for (long i = threadIdx.x; i < (long)B * N; i += 1024) {
+    int b = (int)(i / N), n = (int)(i - (long)b * N);
+    float x = logits[b * ldl + n], t = target[b * ldt + n];
+    acc += fmaxf(x, 0.f) - x * t + log1pf(__expf(-fabsf(x)));
+    if (dlogits) dlogits[b * ldd + n] = gscale * (1.f / (1.f + __expf(-x)) - t) * invB;
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+    for (int i = 0; i < 16; ++i) s += red[i];
+    *loss = s * invB;
+  }
+}
+extern "C" int climb_bce_logits(const float* logits, long ldl, const float* target, long ldt, float* dlogits, long ldd, float* loss, int B, int N,
+                                float gscale, void* stream) {
+  hipLaunchKernelGGL(bce_logits_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, logits, ldl, target, ldt, dlogits, ldd, loss, B, N, gscale);
+  LAUNCH_CHECK();
+  return CLIMB_OK;
+}
+
+// nn.CrossEntropyLoss() (REF/train/visionlanguage_tasks/train_nlvr2.py:80): mean over rows of -log softmax[label].
+__global__ __launch_bounds__(256) void cross_entropy_kernel(const float* __restrict__ logits, long ldl, const long* __restrict__ labels,
+                                                            float* __restrict__ dlogits, long ldd, float* __restrict__ loss, int B, int N,
+                                                            float gscale) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  for (int b = threadIdx.x; b < B; b += 256) {
+    const float* x = logits + b * ldl;
+    float mx = -3.0e38f;
+    for (int n = 0; n < N; ++n) mx = fmaxf(mx, x[n]);
+    float se = 0.f;
+    for (int n = 0; n < N; ++n) se += __expf(x[n] - mx);
+    float lse = mx + __logf(se);
+    int lab = (int)labels[b];
+    acc += lse - x[lab];
+    if (dlogits)
+      for (int n = 0; n < N; ++n) dlogits[b * ldd + n] = gscale * (__expf(x[n] - lse) - (n == lab ? 1.f : 0.f)) / (float)B;
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) *loss = (red[0] + red[1] + red[2] + red[3]) / (float)B;
+}
+extern "C" int climb_cross_entropy(const float* logits, long ldl, const long* labels, float* dlogits, long ldd, float* loss, int B, int N,
+                                   float gscale, void* stream) {
+  hipLaunchKernelGGL(cross_entropy_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logits, ldl, labels, dlogits, ldd, loss, B, N, gscale);
+  LAUNCH_CHECK();
+  return CLIMB_OK;
+}
+
+// additive key bias from the concatenated [text | image] keep-mask (HF:623-627): 0 keep, -3e38 masked; padding rows masked.
+__global__ void key_bias_kernel(const long* __restrict__ attn_mask, float* __restrict__ bias, int B, int T, int S, int S_pad) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * S_pad) return;
+  int b = i / S_pad, s = i - b * S_pad;
+  float v = 0.f;
+  if (s < T) v = attn_mask[b * T + s] != 0 ? 0.f : -3.0e38f;
+  else if (s >= S) v = -3.0e38f;
+  bias[i] = v;
+}
+extern "C" int climb_key_bias(const long* attn_mask, float* bias, int B, int T, int S, int S_pad, void* stream) {
+  hipLaunchKernelGGL(key_bias_kernel, dim3((B * S_pad + 255) / 256), dim3(256), 0, (hipStream_t)stream, attn_mask, bias, B, T, S, S_pad);
+  LAUNCH_CHECK();
+  return CLIMB_OK;
+}

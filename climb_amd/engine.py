@@ -1,0 +1,523 @@
+"""Host-side step engine: owns the flat parameter / gradient buffers and the activation workspace in HBM and
+sequences the C-ABI HIP launchers for the ViLT forward, backward and update.  PyTorch is used for device memory,
+streams and (elsewhere) torch.distributed only; every FLOP and every byte of the step goes through libclimb_hip.so.
+
+Two arithmetic modes share all of this code:
+  * "fp32": exact-fp32 matrix-core GEMMs (v_mfma_f32_32x32x2_f32) -- the parity mode (<= 1e-3 rel vs the CPU reference,
+            argmax exact) of BASELINE.json's north_star
+  * "bf16": bf16 MFMA operands, fp32 accumulation / statistics / residual stream / master weights -- the throughput mode
+            (BASELINE.json configs[1])
+"""
+from __future__ import annotations
+
+import math
+from typing import Callable, Dict, List, Optional
+
+import torch
+
+from . import _lib
+from .layout import ENC, FlatLayout, VILT_CFG, TASK_ARITH
+
+F32, BF16 = 0, 1
+EPI_NONE, EPI_GELU, EPI_RESID, EPI_DGELU, EPI_TANH = 0, 1, 2, 3, 4
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+class Workspace:
+    """Activation + scratch buffers for one (B, T) shape; allocated once, reused every step."""
+
+    def __init__(self, eng: "ViltEngine", B: int, T: int):
+        cfg = eng.cfg
+        dev = eng.device
+        H, Fd, L, nh = cfg["hidden"], cfg["ffn"], cfg["layers"], cfg["heads"]
+        self.B, self.T = B, T
+        self.NP = (cfg["image"] // cfg["patch"]) ** 2
+        self.S = T + 1 + self.NP
+        self.S_pad = _round_up(self.S, 32)
+        self.M = B * self.S_pad
+        M = self.M
+        adt = torch.float32 if eng.precision == "fp32" else torch.bfloat16
+        f32 = torch.float32
+
+        def buf(shape, dt=f32):
+            return torch.empty(shape, dtype=dt, device=dev)
+        self.key_bias = buf((B, self.S_pad))
+        self.img_type = torch.empty((B,), dtype=torch.int32, device=dev)
+        self.tmean, self.trstd = buf((B * T,)), buf((B * T,))
+        self.a_patch = buf((B * self.NP, cfg["channels"] * cfg["patch"] ** 2), adt)
+        self.proj = buf((B * self.NP, H))
+        self.x = [buf((M, H)) for _ in range(L + 1)]          # residual stream at every layer boundary (fp32)
+        self.h1 = [buf((M, H)) for _ in range(L)]
+        self.xn = [buf((M, H), adt) for _ in range(L)]
+        self.hn = [buf((M, H), adt) for _ in range(L)]
+        self.qkv = [buf((M, 3 * H), adt) for _ in range(L)]
+        self.ctx = [buf((M, H), adt) for _ in range(L)]
+        self.u = [buf((M, Fd), adt) for _ in range(L)]
+        self.a = [buf((M, Fd), adt) for _ in range(L)]
+        self.mean1 = [buf((M,)) for _ in range(L)]
+        self.rstd1 = [buf((M,)) for _ in range(L)]
+        self.mean2 = [buf((M,)) for _ in range(L)]
+        self.rstd2 = [buf((M,)) for _ in range(L)]
+        self.lse = [buf((B, nh, self.S_pad)) for _ in range(L)]
+        self.clsn, self.fmean, self.frstd = buf((B, H)), buf((B,)), buf((B,))
+        self.pooled = buf((B, H))
+        # backward scratch (shared by all layers)
+        self.dres = buf((M, H))
+        self.dres_c = self.dres if eng.precision == "fp32" else buf((M, H), adt)
+        self.du = buf((M, Fd), adt)
+        self.dhn = buf((M, H), adt)
+        self.dctx = buf((M, H), adt)
+        self.dqkv = buf((M, 3 * H), adt)
+        self.dxn = buf((M, H), adt)
+        self.delta = buf((B, nh, self.S_pad))
+        self.dproj = buf((B * self.NP, H), adt)
+        self.dclsn, self.dpre = buf((B, H)), buf((B, H))
+        lnb = _lib.query("climb_layernorm_bwd_rows_per_block")
+        csr = _lib.query("climb_colsum_rows_per_block")
+        npart = max(((M + lnb - 1) // lnb) * 3 * H, ((M + csr - 1) // csr) * max(Fd, 3 * H),
+                    (self.NP + 1) * 3 * H, ((B * T + 31) // 32) * 3 * H)
+        self.part = buf((npart,))
+        self.ones = torch.ones((max(B, 8),), dtype=f32, device=dev)
+
+
+class HeadState:
+    """per-call activations of a task head (fp32, tiny)."""
+    pass
+
+
+class ViltEngine:
+    def __init__(self, layout: FlatLayout, device: torch.device, precision: str = "bf16", task_cfgs: Optional[Dict[str, dict]] = None):
+        assert precision in ("fp32", "bf16")
+        self.layout = layout
+        self.cfg = layout.cfg
+        self.device = torch.device(device)
+        self.precision = precision
+        self.task_cfgs = task_cfgs or TASK_ARITH
+        self.flat: Optional[torch.Tensor] = None        # fp32 master parameters
+        self.grad: Optional[torch.Tensor] = None        # fp32 gradients (accumulating, like .grad)
+        self._ws: Dict[tuple, Workspace] = {}
+        self._shadow = None                             # bf16 copies of the flat buffer (bf16 mode)
+        self._shadow_t = None
+        self._shadow_version = -1
+        self._ewc_ws = None
+        self.requires_grad: Dict[str, bool] = {n: True for n in layout.shapes}
+        self.grad_ready_hook: Optional[Callable[[int, int], None]] = None   # (lo, hi) flat range whose grads are final
+        self.touched: List[tuple] = []                  # flat ranges that received gradients in the last backward
+        self.saved = None
+
+    # ------------------------------------------------------------------ buffers
+    def allocate(self):
+        if self.device.type != "cuda":
+            raise RuntimeError("climb_amd.ViltEngine needs a HIP device (cuda:N); there is no CPU path in the product. "
+                               "Use oracle/ for CPU checking.")
+        _lib.load()
+        self.flat = torch.zeros(self.layout.total, dtype=torch.float32, device=self.device)
+        self.grad = torch.zeros(self.layout.total, dtype=torch.float32, device=self.device)
+        self._ws.clear()
+        self._shadow = None
+        self._shadow_version = -1
+
+    def view(self, base: torch.Tensor, name: str) -> torch.Tensor:
+        o = self.layout.offset[name]
+        return base[o:o + self.layout.numel(name)].view(self.layout.shapes[name])
+
+    def p(self, name: str) -> int:
+        return self.flat.data_ptr() + 4 * self.layout.offset[name]
+
+    def g(self, name: str) -> int:
+        return self.grad.data_ptr() + 4 * self.layout.offset[name]
+
+    def zero_grad(self):
+        self.grad.zero_()
+        self.touched = []
+
+    def is_touched(self, name: str) -> bool:
+        o = self.layout.offset[name]
+        for lo, hi in self.touched:
+            if lo <= o < hi:
+                return True
+        return False
+
+    def shadow_ptr(self):
+        """bf16 weight shadow the fused AdamW refreshes in the same pass (None in fp32 mode)."""
+        return None
+
+    def params_updated(self, shadow_fresh: bool = False):
+        pass
+
+    def workspace(self, B: int, T: int) -> Workspace:
+        key = (B, T)
+        ws = self._ws.get(key)
+        if ws is None:
+            if len(self._ws) >= 3:      # bound HBM use when batch shapes vary (last partial batch, replay batches)
+                self._ws.pop(next(iter(self._ws)))
+            ws = self._ws[key] = Workspace(self, B, T)
+        return ws
+
+    # ------------------------------------------------------------------ GEMM dispatch
+    # forward:  Y[M,N] = X[M,K] W[N,K]^T ; input grad: dX[M,K] = dY[M,N] W[N,K] ; weight grad: dW[N,K] += dY^T X
+    def _fwd(self, X, W_name_or_ptr, bias_ptr, Y, M, N, K, epi=EPI_NONE, aux=None, aux_out=None, ldx=None, ldy=None):
+        st = _stream()
+        ldx = ldx or K
+        ldy = ldy or N
+        if self.precision == "fp32" or not isinstance(X, torch.Tensor) or X.dtype == torch.float32:
+            _lib.call("climb_gemm_f32", X, ldx, 1, W_name_or_ptr, K, 1, Y, ldy, M, N, K, bias_ptr, epi, aux, N, aux_out, N, 0.0, st)
+        else:
+            raise NotImplementedError
+
+    def _gemm_f32(self, A, sam, sak, Bm, sbn, sbk, C, ldc, M, N, K, bias=None, epi=EPI_NONE, aux=None, ldaux=0, aux_out=None, ldauxo=0, beta=0.0):
+        _lib.call("climb_gemm_f32", A, sam, sak, Bm, sbn, sbk, C, ldc, M, N, K, bias, epi, aux, ldaux, aux_out, ldauxo, beta, _stream())
+
+    def linear_fwd(self, X, wname, bname, Y, M, N, K, epi=EPI_NONE, aux=None, aux_out=None):
+        if self.precision == "fp32":
+            self._gemm_f32(X, K, 1, self.p(wname), K, 1, Y, N, M, N, K, self.p(bname) if bname else None, epi, aux, N, aux_out, N)
+        else:
+            self._bf16_fwd(X, wname, bname, Y, M, N, K, epi, aux, aux_out)
+
+    def linear_dx(self, dY, wname, dX, M, N, K, epi=EPI_NONE, aux=None):
+        """dX[M,K] = dY[M,N] @ W[N,K]   (epi DGELU multiplies by gelu'(aux[M,K]))"""
+        if self.precision == "fp32":
+            self._gemm_f32(dY, N, 1, self.p(wname), 1, K, dX, K, M, K, N, None, epi, aux, K)
+        else:
+            self._bf16_dx(dY, wname, dX, M, N, K, epi, aux)
+
+    def linear_dw(self, dY, X, wname, M, N, K):
+        """dW[N,K] += dY[M,N]^T @ X[M,K]"""
+        if not self.requires_grad[wname]:
+            return
+        if self.precision == "fp32":
+            self._gemm_f32(dY, 1, N, X, 1, K, self.g(wname), K, N, K, M, beta=1.0)
+        else:
+            self._bf16_dw(dY, X, wname, M, N, K)
+
+    def bias_grad_from_part(self, part_ptr, stride, nblk, bname, ncols):
+        if bname is not None and self.requires_grad[bname]:
+            _lib.call("climb_colreduce", part_ptr, stride, nblk, self.g(bname), ncols, 1.0, _stream())
+
+    def bias_grad(self, dY, dtype, bname, M, C, ws):
+        """db += colsum(dY)"""
+        if not self.requires_grad[bname]:
+            return
+        csr = _lib.query("climb_colsum_rows_per_block")
+        _lib.call("climb_colsum", dY, C, dtype, None, 0, ws.part, M, C, _stream())
+        _lib.call("climb_colreduce", ws.part, C, (M + csr - 1) // csr, self.g(bname), C, 1.0, _stream())
+
+    # bf16 paths are bound in engine_bf16.py (keeps this file readable)
+    def _bf16_fwd(self, *a, **k):
+        raise NotImplementedError("bf16 GEMM path not linked")
+
+    _bf16_dx = _bf16_dw = _bf16_fwd
+
+    def refresh_shadow(self):
+        pass
+
+    @property
+    def adt(self):
+        return F32 if self.precision == "fp32" else BF16
+
+    # ------------------------------------------------------------------ encoder forward
+    def encoder_forward(self, input_ids, token_type_ids, attention_mask, pixel_values, img_type: torch.Tensor, save: bool = True):
+        """[B,T] int64 ids/types/mask, [B,3,Hh,Ww] fp32 pixels (full-size, unmasked: row F2 is next), img_type int32 [B]
+        (HF `image_token_type_idx` per sequence).  Returns pooled [B,H] fp32 (HF:636-663 pooler_output)."""
+        cfg, L = self.cfg, self.layout
+        B, T = input_ids.shape
+        H, Fd, nh = cfg["hidden"], cfg["ffn"], cfg["heads"]
+        if pixel_values.shape[1:] != (cfg["channels"], cfg["image"], cfg["image"]):
+            raise NotImplementedError(f"fixed-resolution path only: expected [B,{cfg['channels']},{cfg['image']},{cfg['image']}] pixels, "
+                                      f"got {tuple(pixel_values.shape)} (variable-resolution visual_embed is SURVEY.md row F2)")
+        ws = self.workspace(B, T)
+        st = _stream()
+        adt = self.adt
+        self.refresh_shadow()
+        e = ENC + "embeddings."
+        ws.img_type.copy_(img_type)
+        _lib.call("climb_key_bias", attention_mask, ws.key_bias, B, T, ws.S, ws.S_pad, st)
+        x0 = ws.x[0]
+        _lib.call("climb_embed_text_fwd", input_ids, token_type_ids, self.p(e + "text_embeddings.word_embeddings.weight"),
+                  self.p(e + "text_embeddings.token_type_embeddings.weight"), self.p(e + "text_embeddings.position_embeddings.weight"),
+                  self.p(e + "text_embeddings.LayerNorm.weight"), self.p(e + "text_embeddings.LayerNorm.bias"),
+                  self.p(e + "token_type_embeddings.weight"), cfg["ln_eps"], x0, B, T, ws.S_pad, H, ws.tmean, ws.trstd, st)
+        _lib.call("climb_im2col", pixel_values, ws.a_patch, adt, B, cfg["channels"], cfg["image"], cfg["image"], cfg["patch"], st)
+        Kp = cfg["channels"] * cfg["patch"] ** 2
+        self.linear_fwd_f32out(ws.a_patch, e + "patch_embeddings.projection.weight", e + "patch_embeddings.projection.bias", ws.proj,
+                               B * ws.NP, H, Kp)
+        _lib.call("climb_assemble_image", ws.proj, self.p(e + "cls_token"), self.p(e + "position_embeddings"),
+                  self.p(e + "token_type_embeddings.weight"), ws.img_type, x0, B, T, ws.NP, ws.S_pad, H, st)
+        M = ws.M
+        for i in range(cfg["layers"]):
+            l = f"{ENC}encoder.layer.{i}."
+            x = ws.x[i]
+            _lib.call("climb_layernorm_fwd", x, H, self.p(l + "layernorm_before.weight"), self.p(l + "layernorm_before.bias"), cfg["ln_eps"],
+                      ws.xn[i], H, adt, ws.mean1[i], ws.rstd1[i], M, H, st)
+            # fused QKV projection: q/k/v weights are adjacent in the flat buffer (HF:325-327 as one [2304,768] GEMM)
+            self.linear_fwd(ws.xn[i], l + "attention.attention.query.weight", l + "attention.attention.query.bias", ws.qkv[i], M, 3 * H, H)
+            self.attn_fwd(ws.qkv[i], ws.key_bias, ws.ctx[i], ws.lse[i], B, ws.S_pad)
+            self.linear_fwd_resid(ws.ctx[i], l + "attention.output.dense.weight", l + "attention.output.dense.bias", ws.h1[i], M, H, H, x)
+            _lib.call("climb_layernorm_fwd", ws.h1[i], H, self.p(l + "layernorm_after.weight"), self.p(l + "layernorm_after.bias"), cfg["ln_eps"],
+                      ws.hn[i], H, adt, ws.mean2[i], ws.rstd2[i], M, H, st)
+            self.linear_fwd(ws.hn[i], l + "intermediate.dense.weight", l + "intermediate.dense.bias", ws.a[i], M, Fd, H, EPI_GELU, None, ws.u[i])
+            self.linear_fwd_resid(ws.a[i], l + "output.dense.weight", l + "output.dense.bias", ws.x[i + 1], M, H, Fd, ws.h1[i])
+        xL = ws.x[cfg["layers"]]
+        # final LayerNorm only on the row the pooler consumes (token 0 = text [CLS]); `last_hidden_state` is never
+        # used by CLiMB (REF/modeling/vilt.py:123-124), so the other S-1 rows are dead work we skip
+        _lib.call("climb_layernorm_fwd", xL, ws.S_pad * H, self.p(ENC + "layernorm.weight"), self.p(ENC + "layernorm.bias"), cfg["ln_eps"],
+                  ws.clsn, H, F32, ws.fmean, ws.frstd, B, H, st)
+        self._gemm_f32(ws.clsn, H, 1, self.p(ENC + "pooler.dense.weight"), H, 1, ws.pooled, H, B, H, H, self.p(ENC + "pooler.dense.bias"), EPI_TANH)
+        if save:
+            self.saved = dict(ws=ws, input_ids=input_ids, token_type_ids=token_type_ids)
+        return ws.pooled
+
+    def linear_fwd_f32out(self, X, wname, bname, Y, M, N, K):
+        if self.precision == "fp32":
+            self.linear_fwd(X, wname, bname, Y, M, N, K)
+        else:
+            self._bf16_fwd(X, wname, bname, Y, M, N, K, EPI_NONE, None, None, out_f32=True)
+
+    def linear_fwd_resid(self, X, wname, bname, Y, M, N, K, resid):
+        if self.precision == "fp32":
+            self.linear_fwd(X, wname, bname, Y, M, N, K, EPI_RESID, resid)
+        else:
+            self._bf16_fwd(X, wname, bname, Y, M, N, K, EPI_RESID, resid, None, out_f32=True)
+
+    def attn_fwd(self, qkv, key_bias, ctx, lse, B, S_pad):
+        cfg = self.cfg
+        if self.precision == "fp32":
+            _lib.call("climb_attn_fwd_f32", qkv, key_bias, ctx, lse, B, S_pad, cfg["heads"], cfg["head_dim"], _stream())
+        else:
+            _lib.call("climb_attn_fwd_bf16", qkv, key_bias, ctx, lse, B, S_pad, cfg["heads"], cfg["head_dim"], _stream())
+
+    def attn_bwd(self, qkv, key_bias, dctx, ctx, lse, delta, dqkv, B, S_pad):
+        cfg = self.cfg
+        st = _stream()
+        _lib.call("climb_attn_delta", dctx, ctx, self.adt, delta, B, S_pad, cfg["heads"], st)
+        if self.precision == "fp32":
+            _lib.call("climb_attn_bwd_f32", qkv, key_bias, dctx, lse, delta, dqkv, B, S_pad, cfg["heads"], cfg["head_dim"], st)
+        else:
+            _lib.call("climb_attn_bwd_bf16", qkv, key_bias, dctx, lse, delta, dqkv, B, S_pad, cfg["heads"], cfg["head_dim"], st)
+
+    # ------------------------------------------------------------------ encoder backward
+    def _ready(self, lo, hi):
+        self.touched.append((lo, hi))
+        if self.grad_ready_hook is not None:
+            self.grad_ready_hook(lo, hi)
+
+    def encoder_backward(self, dpooled: torch.Tensor, first_layer: int = 0, embeddings: bool = True):
+        """Accumulates parameter gradients into the flat grad buffer.  `first_layer` / `embeddings` let frozen prefixes
+        (REF/modeling/vilt.py:126-144) be skipped entirely."""
+        cfg, lay = self.cfg, self.layout
+        sv = self.saved
+        ws: Workspace = sv["ws"]
+        B, T, M = ws.B, ws.T, ws.M
+        H, Fd = cfg["hidden"], cfg["ffn"]
+        st = _stream()
+        adt = self.adt
+        lnb = _lib.query("climb_layernorm_bwd_rows_per_block")
+        nlnb = (M + lnb - 1) // lnb
+        rg = self.requires_grad
+        # pooler: pooled = tanh(clsn Wp^T + b)
+        _lib.call("climb_elementwise", 2, dpooled, ws.pooled, ws.dpre, B * H, 1.0, st)
+        pw, pb = ENC + "pooler.dense.weight", ENC + "pooler.dense.bias"
+        if rg[pw]:
+            self._gemm_f32(ws.dpre, 1, H, ws.clsn, 1, H, self.g(pw), H, H, H, B, beta=1.0)
+        if rg[pb]:
+            self._gemm_f32(ws.dpre, 1, H, ws.ones, 0, 1, self.g(pb), 1, H, 1, B, beta=1.0)
+        self._gemm_f32(ws.dpre, H, 1, self.p(pw), 1, H, ws.dclsn, H, B, H, H)
+        # final LayerNorm (row 0 of every sequence); all other rows of d(x_L) are zero
+        ws.dres.zero_()
+        xL = ws.x[cfg["layers"]]
+        _lib.call("climb_layernorm_bwd", ws.dclsn, H, F32, xL, ws.S_pad * H, ws.fmean, ws.frstd, self.p(ENC + "layernorm.weight"), None, 0,
+                  ws.dres, ws.S_pad * H, None, 0, ws.part, B, H, st)
+        nb = (B + lnb - 1) // lnb
+        self.bias_grad_from_part(ws.part.data_ptr(), 3 * H, nb, ENC + "layernorm.weight", H)
+        self.bias_grad_from_part(ws.part.data_ptr() + 4 * H, 3 * H, nb, ENC + "layernorm.bias", H)
+        self._ready(*lay.top_range)
+        # d(x_L): cast for the GEMMs (bf16 mode) + column sums for the last layer's output bias
+        csr = _lib.query("climb_colsum_rows_per_block")
+        last = f"{ENC}encoder.layer.{cfg['layers'] - 1}."
+        _lib.call("climb_colsum", ws.dres, H, F32, None if self.precision == "fp32" else ws.dres_c, H, ws.part, M, H, st)
+        if first_layer < cfg["layers"]:
+            self.bias_grad_from_part(ws.part.data_ptr(), H, (M + csr - 1) // csr, last + "output.dense.bias", H)
+        for i in range(cfg["layers"] - 1, first_layer - 1, -1):
+            l = f"{ENC}encoder.layer.{i}."
+            # MLP: x_{i+1} = h1 + W2 gelu(u) + b2,  u = W1 hn + b1
+            self.linear_dx(ws.dres_c, l + "output.dense.weight", ws.du, M, H, Fd, EPI_DGELU, ws.u[i])
+            self.linear_dw(ws.dres_c, ws.a[i], l + "output.dense.weight", M, H, Fd)
+            self.bias_grad(ws.du, adt, l + "intermediate.dense.bias", M, Fd, ws)
+            self.linear_dw(ws.du, ws.hn[i], l + "intermediate.dense.weight", M, Fd, H)
+            self.linear_dx(ws.du, l + "intermediate.dense.weight", ws.dhn, M, Fd, H)
+            _lib.call("climb_layernorm_bwd", ws.dhn, H, adt, ws.h1[i], H, ws.mean2[i], ws.rstd2[i], self.p(l + "layernorm_after.weight"),
+                      ws.dres, H, ws.dres, H, None if self.precision == "fp32" else ws.dres_c, H, ws.part, M, H, st)
+            self.bias_grad_from_part(ws.part.data_ptr(), 3 * H, nlnb, l + "layernorm_after.weight", H)
+            self.bias_grad_from_part(ws.part.data_ptr() + 4 * H, 3 * H, nlnb, l + "layernorm_after.bias", H)
+            self.bias_grad_from_part(ws.part.data_ptr() + 8 * H, 3 * H, nlnb, l + "attention.output.dense.bias", H)
+            # attention: h1 = x + Wo ctx + bo
+            self.linear_dw(ws.dres_c, ws.ctx[i], l + "attention.output.dense.weight", M, H, H)
+            self.linear_dx(ws.dres_c, l + "attention.output.dense.weight", ws.dctx, M, H, H)
+            self.attn_bwd(ws.qkv[i], ws.key_bias, ws.dctx, ws.ctx[i], ws.lse[i], ws.delta, ws.dqkv, B, ws.S_pad)
+            qb = l + "attention.attention.query.bias"
+            if rg[qb]:
+                self.bias_grad(ws.dqkv, adt, qb, M, 3 * H, ws)      # q/k/v biases are adjacent: one [2304] reduction
+            self.linear_dw(ws.dqkv, ws.xn[i], l + "attention.attention.query.weight", M, 3 * H, H)
+            need_dx = i > first_layer or embeddings
+            if need_dx:
+                self.linear_dx(ws.dqkv, l + "attention.attention.query.weight", ws.dxn, M, 3 * H, H)
+                _lib.call("climb_layernorm_bwd", ws.dxn, H, adt, ws.x[i], H, ws.mean1[i], ws.rstd1[i], self.p(l + "layernorm_before.weight"),
+                          ws.dres, H, ws.dres, H, None if self.precision == "fp32" else ws.dres_c, H, ws.part, M, H, st)
+                self.bias_grad_from_part(ws.part.data_ptr(), 3 * H, nlnb, l + "layernorm_before.weight", H)
+                self.bias_grad_from_part(ws.part.data_ptr() + 4 * H, 3 * H, nlnb, l + "layernorm_before.bias", H)
+                if i > first_layer:
+                    self.bias_grad_from_part(ws.part.data_ptr() + 8 * H, 3 * H, nlnb, f"{ENC}encoder.layer.{i - 1}.output.dense.bias", H)
+            self._ready(*lay.layer_range[i])
+        if embeddings and first_layer == 0:
+            self.embedding_backward(ws, sv)
+            self._ready(*lay.embed_range)
+
+    def embedding_backward(self, ws: Workspace, sv):
+        cfg = self.cfg
+        B, T, H = ws.B, ws.T, cfg["hidden"]
+        st = _stream()
+        e = ENC + "embeddings."
+        rg = self.requires_grad
+        ntypes = self.layout.shapes[e + "token_type_embeddings.weight"][0]
+        _lib.call("climb_image_embed_bwd", ws.dres, ws.img_type, ws.dproj, self.adt,
+                  self.g(e + "position_embeddings") if rg[e + "position_embeddings"] else None,
+                  self.g(e + "cls_token") if rg[e + "cls_token"] else None, ws.part, B, T, ws.NP, ws.S_pad, H, ntypes, st)
+        self.bias_grad_from_part(ws.part.data_ptr(), ntypes * H, ws.NP + 1, e + "token_type_embeddings.weight", ntypes * H)
+        Kp = cfg["channels"] * cfg["patch"] ** 2
+        self.bias_grad(ws.dproj, self.adt, e + "patch_embeddings.projection.bias", B * ws.NP, H, ws)
+        self.linear_dw(ws.dproj, ws.a_patch, e + "patch_embeddings.projection.weight", B * ws.NP, H, Kp)
+        te = e + "text_embeddings."
+        _lib.call("climb_embed_text_bwd", sv["input_ids"], sv["token_type_ids"], self.p(te + "word_embeddings.weight"),
+                  self.p(te + "token_type_embeddings.weight"), self.p(te + "position_embeddings.weight"), self.p(te + "LayerNorm.weight"),
+                  ws.tmean, ws.trstd, ws.dres, B, T, ws.S_pad, H,
+                  self.g(te + "word_embeddings.weight") if rg[te + "word_embeddings.weight"] else None,
+                  self.g(te + "token_type_embeddings.weight") if rg[te + "token_type_embeddings.weight"] else None,
+                  self.g(te + "position_embeddings.weight") if rg[te + "position_embeddings.weight"] else None, ws.part, st)
+        nb = (B * T + 31) // 32
+        self.bias_grad_from_part(ws.part.data_ptr(), 3 * H, nb, te + "LayerNorm.weight", H)
+        self.bias_grad_from_part(ws.part.data_ptr() + 4 * H, 3 * H, nb, te + "LayerNorm.bias", H)
+        if rg[e + "token_type_embeddings.weight"]:   # row 0 of the modality table (text rows)
+            _lib.call("climb_colreduce", ws.part.data_ptr() + 8 * H, 3 * H, nb, self.g(e + "token_type_embeddings.weight"), H, 1.0, st)
+
+    # ------------------------------------------------------------------ task heads (fp32; REF/modeling/vilt.py:179-203)
+    def head_forward(self, task_key: str, pooled_in: torch.Tensor, training: bool, keep_mask: Optional[torch.Tensor] = None):
+        tc = self.task_cfgs[task_key]
+        H = self.cfg["hidden"]
+        st = _stream()
+        hs = HeadState()
+        hs.task, hs.x = task_key, pooled_in
+        h = f"task_layer.{task_key}."
+        dev = self.device
+        if tc["model_type"] == "classification":
+            Bh, Kin = pooled_in.shape
+            D, NL = 2 * H, tc["num_labels"]
+            hs.z = torch.empty((Bh, D), dtype=torch.float32, device=dev)
+            hs.zn = torch.empty_like(hs.z)
+            hs.gz = torch.empty_like(hs.z)
+            hs.mean = torch.empty((Bh,), dtype=torch.float32, device=dev)
+            hs.rstd = torch.empty_like(hs.mean)
+            hs.logits = torch.empty((Bh, NL), dtype=torch.float32, device=dev)
+            self._gemm_f32(pooled_in, Kin, 1, self.p(h + "0.weight"), Kin, 1, hs.z, D, Bh, D, Kin, self.p(h + "0.bias"))
+            _lib.call("climb_layernorm_fwd", hs.z, D, self.p(h + "1.weight"), self.p(h + "1.bias"), self.cfg["head_ln_eps"], hs.zn, D, F32,
+                      hs.mean, hs.rstd, Bh, D, st)
+            _lib.call("climb_elementwise", 0, hs.zn, None, hs.gz, Bh * D, 1.0, st)
+            self._gemm_f32(hs.gz, D, 1, self.p(h + "3.weight"), D, 1, hs.logits, NL, Bh, NL, D, self.p(h + "3.bias"))
+            return hs.logits, hs
+        # multi-choice: Dropout(0.1) -> Linear(768, 1) -> squeeze        pooled_in [b, nc, H]
+        b, nc, _ = pooled_in.shape
+        flat_in = pooled_in.reshape(b * nc, H)
+        hs.keep = None
+        if training:
+            if keep_mask is None:
+                keep_mask = (torch.rand((b * nc, H), device=dev) >= 0.1).to(torch.float32)
+            hs.keep = keep_mask.reshape(b * nc, H).contiguous()
+            hs.xd = torch.empty_like(flat_in)
+            _lib.call("climb_elementwise", 3, flat_in, hs.keep, hs.xd, b * nc * H, 1.0 / 0.9, st)
+        else:
+            hs.xd = flat_in
+        hs.logits = torch.empty((b, nc), dtype=torch.float32, device=dev)
+        self._gemm_f32(hs.xd, H, 1, self.p(h + "1.weight"), H, 1, hs.logits, 1, b * nc, 1, H, self.p(h + "1.bias"))
+        return hs.logits, hs
+
+    def head_backward(self, hs: HeadState, dlogits: torch.Tensor) -> torch.Tensor:
+        task_key = hs.task
+        tc = self.task_cfgs[task_key]
+        H = self.cfg["hidden"]
+        st = _stream()
+        h = f"task_layer.{task_key}."
+        rg = self.requires_grad
+        dev = self.device
+        ones = torch.ones((max(dlogits.shape[0] * (dlogits.shape[1] if tc["model_type"] != "classification" else 1), 8),),
+                          dtype=torch.float32, device=dev)
+        if tc["model_type"] == "classification":
+            Bh, Kin = hs.x.shape
+            D, NL = 2 * H, tc["num_labels"]
+            ldl = dlogits.stride(0)
+            if rg[h + "3.weight"]:
+                self._gemm_f32(dlogits, 1, ldl, hs.gz, 1, D, self.g(h + "3.weight"), D, NL, D, Bh, beta=1.0)
+            if rg[h + "3.bias"]:
+                self._gemm_f32(dlogits, 1, ldl, ones, 0, 1, self.g(h + "3.bias"), 1, NL, 1, Bh, beta=1.0)
+            dg = torch.empty((Bh, D), dtype=torch.float32, device=dev)
+            self._gemm_f32(dlogits, ldl, 1, self.p(h + "3.weight"), 1, D, dg, D, Bh, D, NL)
+            dzn = torch.empty_like(dg)
+            _lib.call("climb_elementwise", 1, dg, hs.zn, dzn, Bh * D, 1.0, st)
+            dz = torch.empty_like(dg)
+            lnb = _lib.query("climb_layernorm_bwd_rows_per_block")
+            nb = (Bh + lnb - 1) // lnb
+            part = torch.empty((nb * 3 * D,), dtype=torch.float32, device=dev)
+            _lib.call("climb_layernorm_bwd", dzn, D, F32, hs.z, D, hs.mean, hs.rstd, self.p(h + "1.weight"), None, 0, dz, D, None, 0, part, Bh, D, st)
+            self.bias_grad_from_part(part.data_ptr(), 3 * D, nb, h + "1.weight", D)
+            self.bias_grad_from_part(part.data_ptr() + 4 * D, 3 * D, nb, h + "1.bias", D)
+            if rg[h + "0.weight"]:
+                self._gemm_f32(dz, 1, D, hs.x, 1, Kin, self.g(h + "0.weight"), Kin, D, Kin, Bh, beta=1.0)
+            if rg[h + "0.bias"]:
+                self._gemm_f32(dz, 1, D, ones, 0, 1, self.g(h + "0.bias"), 1, D, 1, Bh, beta=1.0)
+            dx = torch.empty((Bh, Kin), dtype=torch.float32, device=dev)
+            self._gemm_f32(dz, D, 1, self.p(h + "0.weight"), 1, Kin, dx, Kin, Bh, Kin, D)
+            self._ready(*self.layout.head_range[task_key])
+            return dx
+        b, nc = dlogits.shape
+        n = b * nc
+        dl = dlogits.reshape(n, 1)
+        if rg[h + "1.weight"]:
+            self._gemm_f32(dl, 1, 1, hs.xd, 1, H, self.g(h + "1.weight"), H, 1, H, n, beta=1.0)
+        if rg[h + "1.bias"]:
+            self._gemm_f32(dl, 1, 1, ones, 0, 1, self.g(h + "1.bias"), 1, 1, 1, n, beta=1.0)
+        dx = torch.empty((n, H), dtype=torch.float32, device=dev)
+        self._gemm_f32(dl, 1, 1, self.p(h + "1.weight"), 1, H, dx, H, n, H, 1)
+        if hs.keep is not None:
+            _lib.call("climb_elementwise", 3, dx, hs.keep, dx, n * H, 1.0 / 0.9, st)
+        self._ready(*self.layout.head_range[task_key])
+        return dx.view(b, nc, H)
+
+    # ------------------------------------------------------------------ losses
+    def loss_and_grad(self, task_key: str, logits: torch.Tensor, target: torch.Tensor, gscale: float = 1.0):
+        """VQA: BCEWithLogits(mean)*num_labels (REF train_vqa.py:155-157); others: CrossEntropyLoss (train_nlvr2.py:80)."""
+        st = _stream()
+        loss = torch.empty((), dtype=torch.float32, device=self.device)
+        dlogits = torch.empty_like(logits)
+        Bh, NL = logits.shape
+        if task_key == "vqa":
+            _lib.call("climb_bce_logits", logits, logits.stride(0), target, target.stride(0), dlogits, dlogits.stride(0), loss, Bh, NL, gscale, st)
+        else:
+            _lib.call("climb_cross_entropy", logits, logits.stride(0), target, dlogits, dlogits.stride(0), loss, Bh, NL, gscale, st)
+        return loss, dlogits
+
+    # ------------------------------------------------------------------ EWC / Fisher on the contiguous encoder range
+    def ewc_penalty(self, star: torch.Tensor, fisher: torch.Tensor, lam: float, add_grad: bool, gscale: float = 1.0) -> torch.Tensor:
+        n = self.layout.encoder_end
+        if self._ewc_ws is None:
+            self._ewc_ws = torch.empty((_lib.query("climb_ewc_workspace_floats"),), dtype=torch.float32, device=self.device)
+        out = torch.empty((), dtype=torch.float32, device=self.device)
+        _lib.call("climb_ewc_penalty", self.flat, star, fisher, self.grad if add_grad else None, n, lam, gscale, self._ewc_ws, out, _stream())
+        return out
+
+    def fisher_accumulate(self, fisher: torch.Tensor):
+        _lib.call("climb_fisher_accum", fisher, self.grad, self.layout.encoder_end, _stream())

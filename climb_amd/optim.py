@@ -1,0 +1,92 @@
+"""Fused multi-tensor AdamW over the flat parameter buffer (one HIP launch per step).
+
+Semantics are `torch.optim.AdamW` exactly as REF/modeling/vilt.py:205-215 constructs it (decoupled weight decay, bias
+correction, per-parameter step counts, parameters whose `.grad` is None are skipped), so it is a drop-in for the
+reference's `optimizer.step(); scheduler.step(); optimizer.zero_grad()` sequence (REF train_vqa.py:168-172) and works
+with `transformers.get_polynomial_decay_schedule_with_warmup` (a LambdaLR over `param_groups`)."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+class FusedAdamW(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, host=None):
+        if host is None:
+            raise ValueError("FusedAdamW needs the engine host of the model whose parameters it updates (model.create_optimizer builds it)")
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self._host = host
+        self._eng = None
+        self._m = self._v = None
+        self._steps = {}            # parameter name -> number of updates so far
+        self._seg_group_host = None
+        self._seg_start = self._seg_group = None
+
+    def _prepare(self):
+        eng = self._host.engine()
+        if eng is not self._eng:
+            self._eng = eng
+            lay = eng.layout
+            self._m = torch.zeros(lay.total, dtype=torch.float32, device=eng.device)
+            self._v = torch.zeros(lay.total, dtype=torch.float32, device=eng.device)
+            segs = lay.segments()
+            self._seg_names = [s[0] for s in segs]
+            starts = np.array([s[1] for s in segs] + [lay.total], dtype=np.int64)
+            self._seg_start = torch.from_numpy(starts).to(eng.device)
+            self._seg_group = torch.full((len(segs),), -1, dtype=torch.int8, device=eng.device)
+            self._seg_group_host = None
+            by_id = {id(p): n for n, p in self._host._params.items()}
+            self._group_of = {}
+            for gi, g in enumerate(self.param_groups):
+                for p in g["params"]:
+                    n = by_id.get(id(p))
+                    if n is None:
+                        raise RuntimeError("FusedAdamW: parameter is not part of the bound model (was the model re-created?)")
+                    self._group_of[n] = gi
+        return eng
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        eng = self._prepare()
+        params = self._host._params
+        combos = {}             # (param group, step count) -> kernel group slot
+        seg_group = np.full((len(self._seg_names),), -1, dtype=np.int8)
+        for si, n in enumerate(self._seg_names):
+            gi = self._group_of.get(n)
+            if gi is None:
+                continue
+            p = params[n]
+            if not p.requires_grad or not eng.is_touched(n):      # torch skips parameters whose .grad is None
+                continue
+            t = self._steps.get(n, 0) + 1
+            self._steps[n] = t
+            key = (gi, t)
+            slot = combos.get(key)
+            if slot is None:
+                slot = combos[key] = len(combos)
+                if slot >= 8:
+                    raise RuntimeError("FusedAdamW: more than 8 distinct (group, step) combinations in one step")
+            seg_group[si] = slot
+        if not combos:
+            return loss
+        table = np.zeros((len(combos), 8), dtype=np.float32)
+        for (gi, t), slot in combos.items():
+            g = self.param_groups[gi]
+            b1, b2 = g["betas"]
+            table[slot] = (g["lr"], g["weight_decay"], b1, b2, g["eps"], 1.0 - b1 ** t, 1.0 - b2 ** t, 0.0)
+        if self._seg_group_host is None or not np.array_equal(seg_group, self._seg_group_host):
+            self._seg_group.copy_(torch.from_numpy(seg_group))
+            self._seg_group_host = seg_group
+        shadow = eng.shadow_ptr()
+        _lib.call("climb_adamw", eng.flat, eng.grad, self._m, self._v, shadow, eng.layout.total, self._seg_start, self._seg_group,
+                  len(self._seg_names), table.ctypes.data, len(combos), 1.0, torch.cuda.current_stream().cuda_stream)
+        eng.params_updated(shadow_fresh=shadow is not None)
+        return loss
+
+    def zero_grad(self, set_to_none: bool = True):
+        """One memset of the flat gradient buffer; every `.grad` becomes None (torch's set_to_none=True behaviour)."""
+        self._host.engine()
+        self._host.drop_grads()

@@ -1,0 +1,178 @@
+"""Task trainers with the surface the reference's CL plugins use (SURVEY.md §8(b) "Trainer surface"):
+`.hparams`, `.batch2inputs_converter`, `.get_train_dataloader()`, `.get_collate_fn()`, `.loss_criterion`, `.device`,
+`.train_step(model, batch, optimizer=None, scheduler=None, ewc=None) -> (loss, output, ewc_task, ewc_loss)`, `.train`,
+`.eval`, `.eval_forgetting`.
+
+Semantics follow REF/train/visionlanguage_tasks/train_vqa.py (:121-282) and its NLVR2 / SNLI-VE / VCR copies (identical
+but for names, dataloaders and the loss -- verified by diff).  `train_step` runs the fused HIP step
+(forward + loss + backward [+ EWC term], no autograd graph); the optimizer is the fused AdamW.
+
+Dataset construction is host I/O and out of scope for this round: dataloaders are injected."""
+from __future__ import annotations
+
+import copy
+import logging
+from typing import Dict, Optional, Tuple
+
+import torch
+from torch import nn
+
+from ..modeling.vilt import convert_batch_to_vilt_input_dict
+from ..utils import wandb_logger
+
+logger = logging.getLogger(__name__)
+
+
+def polynomial_decay_schedule_with_warmup(optimizer, num_warmup_steps: int, num_training_steps: int, lr_end: float = 0.0, power: float = 1.0):
+    """transformers.get_polynomial_decay_schedule_with_warmup as called at REF train_vqa.py:199-205 (restated so the
+    product path has no transformers dependency)."""
+    lr_init = optimizer.defaults["lr"]
+
+    def lr_lambda(current_step: int):
+        if current_step < num_warmup_steps:
+            return float(current_step) / float(max(1, num_warmup_steps))
+        if current_step > num_training_steps:
+            return lr_end / lr_init
+        lr_range = lr_init - lr_end
+        decay_steps = num_training_steps - num_warmup_steps
+        pct_remaining = 1 - (current_step - num_warmup_steps) / decay_steps
+        return (lr_range * pct_remaining ** power + lr_end) / lr_init
+    return torch.optim.lr_scheduler.LambdaLR(optimizer, lr_lambda)
+
+
+class TaskTrainer(nn.Module):
+    """REF/train/visionlanguage_tasks/task_trainer.py:5"""
+
+    def __init__(self):
+        super().__init__()
+
+
+class VLTaskTrainer(TaskTrainer):
+    task_key = None
+    target_field = "labels"
+
+    def __init__(self, args, task_configs: Dict, model_config: Dict, device: torch.device, train_dataloader=None, val_dataloader=None):
+        super().__init__()
+        self.args = args
+        self.device = device
+        self.task_config = task_configs[self.task_key]
+        self.visual_input_type = model_config.get("visual_input_type", "pil-image")
+        self.batch2inputs_converter = model_config.get("batch2inputs_converter", convert_batch_to_vilt_input_dict)
+        self.train_dataloader, self.val_dataloader = train_dataloader, val_dataloader
+        if train_dataloader is None:
+            raise RuntimeError(f"{type(self).__name__}: pass train_dataloader/val_dataloader -- dataset loading (PIL, annotation "
+                               "parsing) is host I/O kept outside this package (SURVEY.md row F1)")
+        self.num_epochs = self.task_config["num_epochs"]
+        self.lr = self.task_config["lr"]
+        self.adam_epsilon = self.task_config["adam_epsilon"]
+        self.weight_decay = self.task_config["weight_decay"]
+        self.hparams = {"lr": self.lr, "weight_decay": self.weight_decay, "adam_epsilon": self.adam_epsilon}
+        self.loss_criterion = nn.BCEWithLogitsLoss(reduction="mean") if self.task_key == "vqa" else nn.CrossEntropyLoss()
+        self.max_steps = len(self.train_dataloader) * self.num_epochs
+        self.warmup_ratio = 0.1       # hard-coded in the reference too (train_vqa.py:97)
+
+    def get_train_dataloader(self):
+        return self.train_dataloader
+
+    def get_collate_fn(self):
+        return self.train_dataloader.collate_fn
+
+    # ---- REF train_vqa.py:121-133
+    def forward_pass(self, model, batch: Dict, do_eval: bool = False) -> Tuple:
+        inputs = self.batch2inputs_converter(batch)
+        with torch.no_grad() if do_eval else torch.enable_grad():
+            return model(task_key=self.task_key, **inputs)
+
+    # ---- REF train_vqa.py:135-174
+    def train_step(self, model, batch: Dict, optimizer=None, scheduler=None, ewc=None):
+        inputs = self.batch2inputs_converter(batch)
+        target = batch[self.target_field]
+        loss, output, ewc_task, ewc_loss = model.fused_forward_backward(self.task_key, inputs["images"], inputs["texts"], target, ewc)
+        if optimizer is not None:
+            optimizer.step()
+            if scheduler is not None:
+                scheduler.step()
+            optimizer.zero_grad()
+        return loss, output, ewc_task, ewc_loss
+
+    # ---- REF train_vqa.py:176-244
+    def train(self, model, replay_memory=None, ewc=None):
+        model.to(self.device)
+        do_replay = do_ewc = False
+        if self.args.cl_algorithm == "experience_replay":
+            assert replay_memory is not None
+            do_replay = replay_memory.do_replay()
+        elif self.args.cl_algorithm == "ewc":
+            assert ewc is not None
+            do_ewc = ewc.do_ewc()
+        optimizer = model.create_optimizer(self.hparams)
+        scheduler = polynomial_decay_schedule_with_warmup(optimizer, int(self.max_steps * self.warmup_ratio), self.max_steps, 0.0, 1.0)
+        best_score = 0
+        best_model = {"epoch": 0, "model": copy.deepcopy(model), "optimizer_state": optimizer.state_dict()}
+        model.zero_grad()
+        for epoch in range(self.num_epochs):
+            model.train()
+            for step, batch in enumerate(self.train_dataloader):
+                loss, output, ewc_task, ewc_loss = self.train_step(model, batch, optimizer, scheduler, ewc)
+                if do_replay and (step + 1) % self.args.replay_frequency == 0:
+                    sampled_replay_task = replay_memory.sample_replay_task()
+                    replay_memory.run_replay_step(task_key=sampled_replay_task, model=model)
+                if (step + 1) % wandb_logger.get_log_freq() == 0:
+                    log_dict = {self.task_key: {"loss": loss.item()}}
+                    if ewc is not None and do_ewc:
+                        log_dict[ewc_task] = {"ewc_loss": ewc_loss.item()}
+                    wandb_logger.log(log_dict)
+            eval_score = self.eval(model)
+            logger.info("Evaluation after epoch {}: {:.2f}".format(epoch + 1, eval_score))
+            wandb_logger.log({self.task_key: {"val_score": eval_score}})
+            if eval_score > best_score:
+                best_score = eval_score
+                best_model["epoch"] = epoch
+                best_model["model"] = copy.deepcopy(model)
+        return best_score, best_model
+
+    # ---- REF train_nlvr2.py:225-244 (argmax accuracy); VQA overrides the per-batch score
+    def batch_score(self, logits: torch.Tensor, batch: Dict) -> torch.Tensor:
+        return (logits.argmax(-1) == batch["labels"].to(logits.device)).sum()
+
+    def eval(self, model) -> float:
+        model.eval()
+        score = torch.zeros((), dtype=torch.float64, device=self.device)
+        for step, batch in enumerate(self.val_dataloader):
+            output = self.forward_pass(model, batch, do_eval=True)
+            score += self.batch_score(output[1], batch).double()      # accumulated on device: one sync per eval, not per batch
+        model.train()
+        return float(score.item()) / len(self.val_dataloader.dataset) * 100.0
+
+    def eval_forgetting(self, model, model_path: str) -> float:
+        model.to(self.device)
+        model.load_state_dict(torch.load(model_path))
+        return self.eval(model)
+
+
+class VQATrainer(VLTaskTrainer):
+    task_key = "vqa"
+    target_field = "target_scores"
+
+    def compute_score_with_logits(self, logits: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
+        """REF train_vqa.py:99-113: VQA score of the argmax answer."""
+        idx = torch.max(logits, 1)[1]
+        one_hots = torch.zeros_like(labels)
+        one_hots.scatter_(1, idx.view(-1, 1), 1)
+        return one_hots * labels
+
+    def batch_score(self, logits, batch):
+        target = batch["target_scores"].to(logits.device)
+        return self.compute_score_with_logits(logits, target).sum()
+
+
+class NLVR2Trainer(VLTaskTrainer):
+    task_key = "nlvr2"
+
+
+class SNLIVETrainer(VLTaskTrainer):
+    task_key = "snli-ve"
+
+
+class VCRTrainer(VLTaskTrainer):
+    task_key = "vcr"

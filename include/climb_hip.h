@@ -1,0 +1,96 @@
+/* climb_hip.h -- C ABI of libclimb_hip.so: the MI355X (gfx950) device side of CLiMB's ViLT continual-fine-tuning step.
+ *
+ * The reference (GLAMOR-USC/CLiMB) is pure Python on eager PyTorch; it has no FFI of its own.  Each entry point below
+ * replaces the eager-op sequence the reference runs at the cited place (REF = CLiMB src/, HF = transformers
+ * models/vilt/modeling_vilt.py 5.15.0, the third-party module REF/modeling/vilt.py:17 imports).  INTEGRATION.md shows
+ * the ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain pointers + sizes, no torch types; all pointers are DEVICE pointers unless a comment says otherwise
+ *   - every launcher takes the hipStream_t to enqueue on as its last argument (`void* stream`), never synchronises,
+ *     never allocates, and is safe to capture into a hipGraph
+ *   - return value: 0 = ok, >0 = hipError_t, <0 = library code (-1 invalid argument, -2 unsupported shape);
+ *     climb_error_string() renders either.  Nothing throws across this boundary.
+ *   - dtype codes: 0 = fp32, 1 = bf16 (raw 16-bit).  ld* = leading dimension in ELEMENTS.
+ *   - token layout: activations are [B, S_pad, H] row-major with S_pad = roundup(T + 1 + NP, 32);
+ *     rows [0,T) text, T image [CLS], [T+1, T+1+NP) patches in raster order, the rest zero padding (masked as keys).
+ */
+#ifndef CLIMB_HIP_H
+#define CLIMB_HIP_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- library ---------------------------------------------------------------------------------------------------- */
+int climb_version(void);
+const char* climb_arch(void);
+const char* climb_error_string(int code);
+int climb_device_sync(void);
+
+/* ---- embeddings -------------------------------------------------------------------------------------------------- */
+/* HF:237-269 TextEmbeddings.forward + HF:208-210: x[b,t,:] = LN(word[ids]+type[tt]+pos[t])*gamma+beta + modality[0].
+ * ids/tts are int64 [B,T]; mean/rstd [B*T] are saved for the backward. */
+int climb_embed_text_fwd(const long* ids, const long* tts, const float* word, const float* type, const float* pos, const float* gamma, const float* beta, const float* mod0, float eps, float* x, int B, int T, int S_pad, int H, float* mean, float* rstd, void* stream);
+/* backward of the above: atomically scatter-adds into dword/dtype/dpos; part[ceil(B*T/32)][3][H] = {dgamma, dbeta, dmodality0} partials */
+int climb_embed_text_bwd(const long* ids, const long* tts, const float* word, const float* type, const float* pos, const float* gamma, const float* mean, const float* rstd, const float* dres, int B, int T, int S_pad, int H, float* dword, float* dtype_, float* dpos, float* part, void* stream);
+/* HF:292-300 Conv2d(3,768,k=32,s=32) as a GEMM: out[(b*NP + py*gw + px), c*P*P + ky*P + kx] = pixels[b,c,py*P+ky,px*P+kx] */
+int climb_im2col(const float* pixels, void* out, int out_dtype, int B, int C, int H, int W, int P, void* stream);
+/* HF:168-173, :211-216: image rows of the embedding = proj/cls + position + modality[img_type[b]]; padding rows zeroed */
+int climb_assemble_image(const float* proj, const float* cls, const float* pos, const float* mod, const int* img_type, float* x, int B, int T, int NP, int S_pad, int H, void* stream);
+/* backward of the image rows; part[(NP+1)][ntypes][H] modality partials (reduce with climb_colreduce, stride ntypes*H) */
+int climb_image_embed_bwd(const float* dres, const int* img_type, void* dproj, int dproj_dtype, float* dpos, float* dcls, float* part, int B, int T, int NP, int S_pad, int H, int ntypes, void* stream);
+/* HF:623-627 additive key mask as a [B,S_pad] vector: 0 keep, -3e38 masked text token or padding row */
+int climb_key_bias(const long* attn_mask, float* bias, int B, int T, int S, int S_pad, void* stream);
+
+/* ---- LayerNorm ------------------------------------------------------------------------------------------------- */
+/* nn.LayerNorm (HF:430-451 layernorm_before/after eps 1e-12; REF/modeling/vilt.py:192 head LN eps 1e-5); x fp32, y dtype */
+int climb_layernorm_fwd(const float* x, long ldx, const float* gamma, const float* beta, float eps, void* y, long ldy, int y_dtype, float* mean, float* rstd, int M, int C, void* stream);
+/* dxo = dres_in + LNbwd(dy); optional cast of dxo; part[ceil(M/32)][3][C] = {dgamma, dbeta, colsum(dxo)} partials */
+int climb_layernorm_bwd(const void* dy, long lddy, int dtype, const float* x, long ldx, const float* mean, const float* rstd, const float* gamma, const float* dres_in, long ldr, float* dxo, long ldo, void* dcast, long ldc, float* part, int M, int C, void* stream);
+int climb_layernorm_bwd_rows_per_block(void);
+/* out[c] = beta*out[c] + sum_b part[b*stride + c]  (deterministic second stage of every column reduction) */
+int climb_colreduce(const float* part, long stride, int nblk, float* out, int ncols, float beta, void* stream);
+/* bias gradients: part[ceil(M/64)][C] column sums of x (optionally also writes a bf16 cast of an fp32 x) */
+int climb_colsum(const void* x, long ldx, int in_dtype, void* cast_bf16, long ldc, float* part, int M, int C, void* stream);
+int climb_colsum_rows_per_block(void);
+
+/* ---- GEMM ------------------------------------------------------------------------------------------------------ */
+/* nn.Linear forward / input-grad / weight-grad (HF:325-327, :366-369, :397-400, :410-414; REF/modeling/vilt.py:190-195)
+ * on v_mfma_f32_32x32x2_f32 (exact fp32):  C[m,n] = epi(sum_k A[m*sam+k*sak] * B[n*sbn+k*sbk] + bias[n]) + beta*C[m,n]
+ * epi: 0 none, 1 GELU (aux_out = pre-activation), 2 + aux residual, 3 * gelu'(aux), 4 tanh */
+int climb_gemm_f32(const float* A, long sam, long sak, const float* B, long sbn, long sbk, float* C, long ldc, int M, int N, int K, const float* bias, int epi, const float* aux, long ldaux, float* aux_out, long ldauxo, float beta, void* stream);
+
+/* ---- attention ------------------------------------------------------------------------------------------------- */
+/* HF:322-351 ViltSelfAttention: softmax(Q K^T / sqrt(d) + key_bias) V per (batch, head); scores never leave the CU.
+ * qkv [B*S_pad, 3H] columns [q|k|v]; ctx [B*S_pad, H]; lse [B, heads, S_pad] saved for backward */
+int climb_attn_fwd_f32(const float* qkv, const float* key_bias, float* ctx, float* lse, int B, int S_pad, int heads, int head_dim, void* stream);
+/* delta[b,h,q] = sum_d dctx*ctx (softmax backward row term) */
+int climb_attn_delta(const void* dctx, const void* ctx, int dtype, float* delta, int B, int S_pad, int heads, void* stream);
+int climb_attn_bwd_f32(const float* qkv, const float* key_bias, const float* dctx, const float* lse, const float* delta, float* dqkv, int B, int S_pad, int heads, int head_dim, void* stream);
+
+/* ---- heads / losses -------------------------------------------------------------------------------------------- */
+/* op: 0 gelu(a) | 1 a*gelu'(b) | 2 a*(1-b^2) (tanh bwd) | 3 a*b*s (dropout) | 4 a*s | 5 a+b */
+int climb_elementwise(int op, const float* a, const float* b, float* out, long n, float s, void* stream);
+/* REF/train/visionlanguage_tasks/train_vqa.py:95,:157: loss = BCEWithLogits(mean)*N; dlogits = gscale*(sigmoid(x)-t)/B */
+int climb_bce_logits(const float* logits, long ldl, const float* target, long ldt, float* dlogits, long ldd, float* loss, int B, int N, float gscale, void* stream);
+/* REF/train/visionlanguage_tasks/train_nlvr2.py:80 nn.CrossEntropyLoss(); labels int64 */
+int climb_cross_entropy(const float* logits, long ldl, const long* labels, float* dlogits, long ldd, float* loss, int B, int N, float gscale, void* stream);
+
+/* ---- optimiser / continual-learning terms (flat parameter buffer) ------------------------------------------------ */
+/* torch.optim.AdamW as built by REF/modeling/vilt.py:205-215.  seg_start[nseg+1] (int64, device) tensor offsets,
+ * seg_group[nseg] (int8, device) group id or -1 = tensor skipped; groups = HOST array [ngroups][8] =
+ * {lr, wd, beta1, beta2, eps, 1-beta1^t, 1-beta2^t, 0}.  Optionally refreshes the bf16 weight shadow in the same pass. */
+int climb_adamw(float* p, const float* g, float* m, float* v, void* shadow_bf16, long n, const long* seg_start, const signed char* seg_group, int nseg, const float* groups, int ngroups, float gscale, void* stream);
+/* REF/cl_algorithms/ewc.py:75-87: loss_out = lam*sum F (theta-theta*)^2; grad += gscale*2*lam*F*(theta-theta*) if grad != NULL */
+int climb_ewc_penalty(const float* theta, const float* star, const float* fisher, float* grad, long n, float lam, float gscale, float* partials, float* loss_out, void* stream);
+int climb_ewc_workspace_floats(void);
+/* REF/cl_algorithms/ewc.py:62-64: fisher += grad^2 */
+int climb_fisher_accum(float* fisher, const float* grad, long n, void* stream);
+int climb_scale(float* x, long n, float s, void* stream);
+int climb_cast_bf16(const float* x, void* y, long n, void* stream);
+int climb_transpose_bf16(const void* in, void* out, int R, int C, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,227 @@
+"""Kernel-level parity on the MI355X: every C-ABI launcher against a plain PyTorch fp32 reference of the same op
+(run on the CPU in float64 where it matters).  Tolerances are written next to each check."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch.device("cuda:0")
+
+
+def _st():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def gelu(x):
+    return 0.5 * x * (1.0 + torch.erf(x / math.sqrt(2.0)))
+
+
+@pytest.mark.parametrize("M,N,K", [(64, 64, 16), (370, 768, 768), (130, 2304, 768), (64, 3129, 1536), (7, 2, 1536), (300, 96, 52)])
+def test_gemm_f32_forward_layout(M, N, K):
+    from climb_amd import _lib
+    dev = _dev()
+    g = torch.Generator().manual_seed(M * 7 + N)
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g)       # asymmetric operands: a transposed write would be caught
+    bias = torch.randn(N, generator=g)
+    ref = A.double() @ W.double().t() + bias.double()
+    Ad, Wd, bd = A.to(dev), W.to(dev), bias.to(dev)
+    C = torch.empty(M, N, device=dev)
+    _lib.call("climb_gemm_f32", Ad, K, 1, Wd, K, 1, C, N, M, N, K, bd, 0, None, 0, None, 0, 0.0, _st())
+    assert _rel(C, ref) < 2e-6
+
+
+def test_gemm_f32_strided_variants_and_epilogues():
+    from climb_amd import _lib
+    dev = _dev()
+    g = torch.Generator().manual_seed(3)
+    M, N, K = 200, 192, 136
+    dY = torch.randn(M, N, generator=g)
+    W = torch.randn(N, K, generator=g)
+    X = torch.randn(M, K, generator=g)
+    U = torch.randn(M, K, generator=g)
+    dYd, Wd, Xd, Ud = dY.to(dev), W.to(dev), X.to(dev), U.to(dev)
+    # input grad with GELU' epilogue: dX = (dY W) * gelu'(U)
+    dX = torch.empty(M, K, device=dev)
+    _lib.call("climb_gemm_f32", dYd, N, 1, Wd, 1, K, dX, K, M, K, N, None, 3, Ud, K, None, 0, 0.0, _st())
+    Ur = U.double().requires_grad_(True)
+    gelu(Ur).backward(dY.double() @ W.double())
+    assert _rel(dX, Ur.grad) < 5e-6
+    # weight grad, accumulating: dW += dY^T X
+    dW0 = torch.randn(N, K, generator=g)
+    dW = dW0.to(dev).clone()
+    _lib.call("climb_gemm_f32", dYd, 1, N, Xd, 1, K, dW, K, N, K, M, None, 0, None, 0, None, 0, 1.0, _st())
+    assert _rel(dW, dW0.double() + dY.double().t() @ X.double()) < 2e-6
+    # forward with GELU (pre-activation saved), residual and tanh epilogues
+    b = torch.randn(N, generator=g).to(dev)
+    Y = torch.empty(M, N, device=dev)
+    pre = torch.empty(M, N, device=dev)
+    _lib.call("climb_gemm_f32", Xd, K, 1, Wd, K, 1, Y, N, M, N, K, b, 1, None, 0, pre, N, 0.0, _st())
+    ref_pre = X.double() @ W.double().t() + b.cpu().double()
+    assert _rel(pre, ref_pre) < 2e-6 and _rel(Y, gelu(ref_pre)) < 5e-6
+    R = torch.randn(M, N, generator=g).to(dev)
+    _lib.call("climb_gemm_f32", Xd, K, 1, Wd, K, 1, Y, N, M, N, K, b, 2, R, N, None, 0, 0.0, _st())
+    assert _rel(Y, ref_pre + R.cpu().double()) < 2e-6
+    _lib.call("climb_gemm_f32", Xd, K, 1, Wd, K, 1, Y, N, M, N, K, b, 4, None, 0, None, 0, 0.0, _st())
+    assert _rel(Y, torch.tanh(ref_pre * 1.0)) < 5e-6
+
+
+@pytest.mark.parametrize("C,dt", [(768, "f32"), (1536, "f32"), (768, "bf16")])
+def test_layernorm_fwd_bwd(C, dt):
+    from climb_amd import _lib
+    dev = _dev()
+    M = 77
+    g = torch.Generator().manual_seed(C)
+    x = torch.randn(M, C, generator=g) * 2 + 0.5
+    gamma = 1 + 0.1 * torch.randn(C, generator=g)
+    beta = 0.1 * torch.randn(C, generator=g)
+    dy = torch.randn(M, C, generator=g)
+    dres = torch.randn(M, C, generator=g)
+    code = 0 if dt == "f32" else 1
+    tdt = torch.float32 if dt == "f32" else torch.bfloat16
+    tol = 2e-6 if dt == "f32" else 6e-3
+    xd = x.to(dev)
+    y = torch.empty(M, C, device=dev, dtype=tdt)
+    mean = torch.empty(M, device=dev)
+    rstd = torch.empty(M, device=dev)
+    _lib.call("climb_layernorm_fwd", xd, C, gamma.to(dev), beta.to(dev), 1e-12, y, C, code, mean, rstd, M, C, _st())
+    xr = x.double().requires_grad_(True)
+    gr = gamma.double().requires_grad_(True)
+    br = beta.double().requires_grad_(True)
+    yr = torch.nn.functional.layer_norm(xr, (C,), gr, br, 1e-12)
+    assert _rel(y.float(), yr.detach()) < tol
+    dy_used = dy.to(dev).to(tdt)
+    yr.backward(dy_used.float().cpu().double())
+    rows = _lib.query("climb_layernorm_bwd_rows_per_block")
+    nb = (M + rows - 1) // rows
+    part = torch.empty(nb * 3 * C, device=dev)
+    dxo = torch.empty(M, C, device=dev)
+    dcast = torch.empty(M, C, device=dev, dtype=tdt)
+    _lib.call("climb_layernorm_bwd", dy_used, C, code, xd, C, mean, rstd, gamma.to(dev), dres.to(dev), C, dxo, C, dcast, C, part, M, C, _st())
+    assert _rel(dxo, dres.double() + xr.grad) < 5e-6
+    assert _rel(dcast.float(), dres.double() + xr.grad) < tol
+    out = torch.zeros(3 * C, device=dev)
+    _lib.call("climb_colreduce", part, 3 * C, nb, out, 3 * C, 0.0, _st())
+    assert _rel(out[:C], gr.grad) < 5e-6
+    assert _rel(out[C:2 * C], br.grad) < 5e-6
+    assert _rel(out[2 * C:], (dres.double() + xr.grad).sum(0)) < 5e-6
+
+
+def _attn_ref(qkv, bias, heads):
+    B, S, H3 = qkv.shape
+    H = H3 // 3
+    d = H // heads
+    q, k, v = qkv.split(H, dim=-1)
+    q = q.view(B, S, heads, d).transpose(1, 2)
+    k = k.view(B, S, heads, d).transpose(1, 2)
+    v = v.view(B, S, heads, d).transpose(1, 2)
+    s = q @ k.transpose(-1, -2) / math.sqrt(d) + bias[:, None, None, :]
+    p = torch.softmax(s, dim=-1)
+    return (p @ v).transpose(1, 2).reshape(B, S, H)
+
+
+@pytest.mark.parametrize("S_pad,valid", [(64, 50), (192, 185), (224, 200), (288, 281)])
+def test_attention_f32_fwd_bwd(S_pad, valid):
+    from climb_amd import _lib
+    dev = _dev()
+    B, heads, d = 2, 3, 64
+    H = heads * d
+    g = torch.Generator().manual_seed(S_pad)
+    qkv = torch.randn(B, S_pad, 3 * H, generator=g)
+    qkv[..., :2 * H] *= 1.5                       # non-trivial softmax
+    bias = torch.zeros(B, S_pad)
+    bias[:, valid:] = -3.0e38
+    bias[1, 3:7] = -3.0e38                        # masked text tokens in the middle
+    dctx = torch.randn(B, S_pad, H, generator=g)
+    dctx[:, valid:] = 0
+    qr = qkv.double().requires_grad_(True)
+    ref = _attn_ref(qr, bias.double().clamp(min=-1e300), heads)
+    ref.backward(dctx.double())
+    qd, bd, dd = qkv.to(dev).view(B * S_pad, 3 * H), bias.to(dev), dctx.to(dev).view(B * S_pad, H)
+    ctx = torch.empty(B * S_pad, H, device=dev)
+    lse = torch.empty(B, heads, S_pad, device=dev)
+    _lib.call("climb_attn_fwd_f32", qd, bd, ctx, lse, B, S_pad, heads, d, _st())
+    assert _rel(ctx.view(B, S_pad, H)[:, :valid], ref.detach()[:, :valid]) < 5e-6
+    delta = torch.empty(B, heads, S_pad, device=dev)
+    dqkv = torch.full((B * S_pad, 3 * H), float("nan"), device=dev)
+    _lib.call("climb_attn_delta", dd, ctx, 0, delta, B, S_pad, heads, _st())
+    _lib.call("climb_attn_bwd_f32", qd, bd, dd, lse, delta, dqkv, B, S_pad, heads, d, _st())
+    assert not torch.isnan(dqkv).any()
+    assert _rel(dqkv.view(B, S_pad, 3 * H), qr.grad) < 1e-5
+
+
+def test_losses():
+    from climb_amd import _lib
+    dev = _dev()
+    g = torch.Generator().manual_seed(0)
+    B, N = 5, 3129
+    x = torch.randn(B, N, generator=g) * 3
+    t = (torch.rand(B, N, generator=g) > 0.999).float() * 0.6
+    xr = x.double().requires_grad_(True)
+    ref = torch.nn.functional.binary_cross_entropy_with_logits(xr, t.double(), reduction="mean") * N
+    ref.backward()
+    loss = torch.empty((), device=dev)
+    dl = torch.empty(B, N, device=dev)
+    _lib.call("climb_bce_logits", x.to(dev), N, t.to(dev), N, dl, N, loss, B, N, 1.0, _st())
+    assert abs(loss.item() - ref.item()) < 2e-6 * abs(ref.item())
+    assert _rel(dl, xr.grad) < 2e-6
+    for n in (2, 3, 4):
+        x = torch.randn(B, n, generator=g)
+        lab = torch.randint(0, n, (B,), generator=g)
+        xr = x.double().requires_grad_(True)
+        ref = torch.nn.functional.cross_entropy(xr, lab)
+        ref.backward()
+        dl = torch.empty(B, n, device=dev)
+        _lib.call("climb_cross_entropy", x.to(dev), n, lab.to(dev), dl, n, loss, B, n, 1.0, _st())
+        assert abs(loss.item() - ref.item()) < 2e-6 and _rel(dl, xr.grad) < 2e-6
+
+
+def test_adamw_ewc_fisher_flat_kernels():
+    from climb_amd import _lib
+    dev = _dev()
+    g = torch.Generator().manual_seed(1)
+    n = 64 * 40
+    p = torch.randn(n, generator=g)
+    gr = torch.randn(n, generator=g) * 0.1
+    starts = np.array([0, 640, 1280, n], dtype=np.int64)
+    groups = np.array([0, -1, 1], dtype=np.int8)
+    table = np.array([[1e-3, 1e-2, 0.9, 0.98, 1e-8, 1 - 0.9 ** 3, 1 - 0.98 ** 3, 0], [2e-3, 0.0, 0.9, 0.98, 1e-8, 1 - 0.9, 1 - 0.98, 0]], dtype=np.float32)
+    m0, v0 = torch.rand(n, generator=g) * 0.01, torch.rand(n, generator=g) * 0.001
+    pd, gd, md, vd = p.to(dev), gr.to(dev), m0.to(dev), v0.to(dev)
+    _lib.call("climb_adamw", pd, gd, md, vd, None, n, torch.from_numpy(starts).to(dev), torch.from_numpy(groups).to(dev), 3,
+              table.ctypes.data, 2, 1.0, _st())
+    ref = p.double().clone()
+    for (lo, hi, row) in ((0, 640, 0), (1280, n, 1)):
+        lr, wd, b1, b2, eps, bc1, bc2, _ = [float(x) for x in table[row]]
+        pp, gg = ref[lo:hi], gr[lo:hi].double()
+        mm = b1 * m0[lo:hi].double() + (1 - b1) * gg
+        vv = b2 * v0[lo:hi].double() + (1 - b2) * gg * gg
+        pp.mul_(1 - lr * wd)
+        pp.sub_((lr / bc1) * mm / (vv.sqrt() / math.sqrt(bc2) + eps))
+    assert _rel(pd, ref) < 2e-6
+    assert torch.equal(pd[640:1280].cpu(), p[640:1280])          # skipped tensor untouched
+    # EWC penalty + gradient, Fisher accumulate
+    star, fis = torch.randn(n, generator=g), torch.rand(n, generator=g)
+    grad = torch.randn(n, generator=g)
+    gd2 = grad.to(dev)
+    ws = torch.empty(_lib.query("climb_ewc_workspace_floats"), device=dev)
+    out = torch.empty((), device=dev)
+    _lib.call("climb_ewc_penalty", p.to(dev), star.to(dev), fis.to(dev), gd2, n, 100.0, 1.0, ws, out, _st())
+    ref_l = 100.0 * (fis.double() * (p.double() - star.double()) ** 2).sum()
+    assert abs(out.item() - ref_l.item()) < 2e-6 * ref_l.item()
+    assert _rel(gd2, grad.double() + 200.0 * fis.double() * (p.double() - star.double())) < 2e-6
+    f2 = fis.to(dev).clone()
+    _lib.call("climb_fisher_accum", f2, gd2, n, _st())
+    assert _rel(f2, fis.double() + gd2.cpu().double() ** 2) < 2e-6
