@@ -1,0 +1,171 @@
+#!/usr/bin/env python
+"""bench.py -- ViLT VQAv2 fine-tune step throughput on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5                      # BASELINE configs[1]: bf16, bs=64/GPU, 384x384, 40 tokens
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One "step" = forward + BCE loss + backward + (N>1: gradient all-reduce over RCCL) + fused AdamW with the reference's
+warm-up/decay schedule, on one synthetic batch already resident in HBM (SURVEY.md §8(d) input spec).  Rank 0 prints ONE
+JSON line; `value` is whole-job image-text pairs/s.  `roofline` is for the dominant kernel (the GEMM), timed live with HIP
+events on the launch stream; `cpu_baseline` is the CPU oracle (a port of the reference path) on this node's host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FLOP_PER_SAMPLE = 100.14e9          # forward 33.38 + backward 66.76 GFLOP at S=185, no padding counted
+PEAK = {"bf16": 2500.0, "fp32": 157.3}   # dense MFMA peak TFLOP/s for the operand dtype (MI355X_MICROARCH.md)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=64, help="sequences per GPU per step")
+    ap.add_argument("--precision", default=os.environ.get("CLIMB_AMD_PRECISION", "bf16"), choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=6)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("for --gpus N>1 launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
+                         "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from climb_amd.modeling import create_continual_learner_map
+    from climb_amd.configs.task_configs import task_configs
+    from climb_amd.configs.model_configs import model_configs
+    from climb_amd.train import polynomial_decay_schedule_with_warmup
+
+    B, T = args.batch, 40
+    tasks = ["vqa"]
+    model = create_continual_learner_map["vilt"](model_name_or_path="random-init:42", ordered_cl_tasks=tasks, model_config=model_configs["vilt"],
+                                                 task_configs=task_configs, device=dev, precision=args.precision)
+    model.train()
+    if world > 1:
+        from climb_amd.parallel import GradientAllReducer
+        GradientAllReducer(model)       # broadcasts rank 0's weights, hooks bucketed all-reduce into the backward
+    # synthetic batch, resident in HBM before the timed region (per-rank shard: different seed per rank)
+    g = torch.Generator().manual_seed(1 + rank)
+    texts = dict(input_ids=torch.randint(0, 30522, (B, T), generator=g).to(dev), token_type_ids=torch.zeros(B, T, dtype=torch.long, device=dev),
+                 attention_mask=torch.ones(B, T, dtype=torch.long, device=dev))
+    pixels = torch.randn(B, 3, 384, 384, generator=g).to(dev)
+    target = torch.zeros(B, 3129)
+    target[torch.arange(B), torch.randint(0, 3129, (B,), generator=g)] = 1.0
+    target = target.to(dev)
+
+    total_steps = args.steps + args.warmup
+    opt = model.create_optimizer({"lr": 1e-4, "weight_decay": 1e-2, "adam_epsilon": 1e-8})
+    sched = polynomial_decay_schedule_with_warmup(opt, max(1, int(0.1 * total_steps)), total_steps, 0.0, 1.0)
+    opt.zero_grad()
+
+    def step():
+        loss, _, _, _ = model.fused_forward_backward("vqa", pixels, texts, target)
+        opt.step()
+        sched.step()
+        opt.zero_grad()
+        return loss
+
+    for _ in range(args.warmup):
+        loss = step()
+    eng = model._host.engine()
+    dominant = "gemm_bf16_nt" if args.precision == "bf16" else "gemm_f32"
+    eng.prof = {"kernel": dominant, "events": []}
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    dt = time.perf_counter() - t0
+    final_loss = float(loss.item())
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    events = eng.prof["events"]
+    eng.prof = None
+
+    if rank == 0:
+        ws = eng.workspace(B, T)
+        ms = dt / args.steps * 1e3
+        value = world * B * args.steps / dt
+        # dominant kernel: average launch duration and algorithmic rate (padding rows S..S_pad not counted)
+        k_ms = [a.elapsed_time(b) for a, b, _ in events]
+        k_flops = sum(f for _, _, f in events) * (ws.S / ws.S_pad)
+        k_time = sum(k_ms) * 1e-3
+        achieved = k_flops / k_time / 1e12 if k_time > 0 else 0.0
+        roof = {"bound": "mfma", "kernel": dominant, "achieved": round(achieved, 2), "peak": PEAK[args.precision], "unit": "TFLOP/s",
+                "frac": round(achieved / PEAK[args.precision], 4), "traffic": None,
+                "launches_per_step": len(events) // max(1, args.steps), "avg_launch_us": round(1e3 * sum(k_ms) / max(1, len(k_ms)), 2),
+                "kernel_time_frac_of_step": round(k_time / dt, 4),
+                "whole_step_tflops": round(FLOP_PER_SAMPLE * B * args.steps / dt / 1e12, 2),
+                "whole_step_frac": round(FLOP_PER_SAMPLE * B * args.steps / dt / 1e12 / PEAK[args.precision], 4)}
+        out = {"metric": "image-text pairs/sec on ViLT VQAv2 fine-tune step", "value": round(value, 2), "unit": "samples/s", "n_gpus": world,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+               "config": {"workload": "BASELINE.json configs[1]: ViLT sequential-FT VQAv2 step (fwd+BCE+bwd+AdamW), 384x384 image + 40 tokens, "
+                                      "12-layer ViLT-B/32 random-init + VQA head", "batch_per_gpu": B, "global_batch": B * world, "seq_len": ws.S,
+                          "seq_len_padded": ws.S_pad, "parallelism": f"dp{world}", "final_loss": round(final_loss, 3)},
+               "roofline": roof}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_steps)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(steps: int):
+    """The CPU oracle (oracle/vilt_oracle.py: a plain-PyTorch fp32 port of the reference path, pinned to the reference by
+    tests/golden) timed on this node's host cores: B=2 (BASELINE.json configs[0]) training steps, 1 warm-up excluded."""
+    import torch
+    from oracle import vilt_oracle as vo
+    # torch's default intra-op thread count already honours the cgroup / affinity limits of this container
+    # (os.cpu_count() does not, and oversubscribing OpenMP threads makes the baseline meaningless)
+    cores = torch.get_num_threads()
+    B = 2
+    P = vo.init_params(["vqa"], 42)
+    state = {}
+    times = []
+    for s in range(steps + 1):
+        enc = vo.synthetic_encodings(B, seed=100 + s)
+        tgt = vo.synthetic_vqa_targets(B, seed=100 + s)
+        t0 = time.perf_counter()
+        vo.train_step(P, "vqa", enc, tgt, opt_state=state, lr=1e-4)
+        times.append(time.perf_counter() - t0)
+    times = sorted(times[1:])
+    med = times[len(times) // 2]
+    try:
+        model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+    except Exception:
+        model = "unknown"
+    return {"value": round(B / med, 3), "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{steps} fp32 training steps (fwd+BCE+bwd+AdamW) at batch {B}, 384x384 + 40 tokens, median step {med:.3f}s, 1 warm-up excluded",
+            "cpu": model}
+
+
+if __name__ == "__main__":
+    main()

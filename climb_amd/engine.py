@@ -111,6 +111,7 @@ class ViltEngine:
         self.grad_ready_hook: Optional[Callable[[int, int], None]] = None   # (lo, hi) flat range whose grads are final
         self.touched: List[tuple] = []                  # flat ranges that received gradients in the last backward
         self.saved = None
+        self.prof = None                                # bench.py: {"kernel": name, "events": [(start, end, flops)]}
 
     # ------------------------------------------------------------------ buffers
     def allocate(self):
@@ -173,6 +174,14 @@ class ViltEngine:
             raise NotImplementedError
 
     def _gemm_f32(self, A, sam, sak, Bm, sbn, sbk, C, ldc, M, N, K, bias=None, epi=EPI_NONE, aux=None, ldaux=0, aux_out=None, ldauxo=0, beta=0.0):
+        prof = self.prof
+        if prof is not None and prof["kernel"] == "gemm_f32":
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            _lib.call("climb_gemm_f32", A, sam, sak, Bm, sbn, sbk, C, ldc, M, N, K, bias, epi, aux, ldaux, aux_out, ldauxo, beta, _stream())
+            e1.record()
+            prof["events"].append((e0, e1, 2.0 * M * N * K))
+            return
         _lib.call("climb_gemm_f32", A, sam, sak, Bm, sbn, sbk, C, ldc, M, N, K, bias, epi, aux, ldaux, aux_out, ldauxo, beta, _stream())
 
     def linear_fwd(self, X, wname, bname, Y, M, N, K, epi=EPI_NONE, aux=None, aux_out=None):

@@ -107,6 +107,11 @@ def test_single_image_step_vs_oracle_and_golden(golden_dir, fname):
     _, _, _, oG = vo.train_step(P, task, enc, target)
     worst = 0.0
     for n in names:
+        if n.endswith("attention.key.bias"):
+            # d loss / d key.bias is identically zero (a per-query constant added to every score cancels in the softmax);
+            # both sides hold rounding noise only, so compare it against the query-bias gradient scale instead
+            assert float(G[n].abs().max()) <= 1e-3 * float(oG[n.replace("key.bias", "query.bias")].abs().max() + 1e-30), n
+            continue
         worst = max(worst, _close(G[n], oG[n], TOL, f"grad {n}"))
     print(f"{fname}: worst per-tensor gradient error vs oracle = {worst:.2e}")
 
