@@ -1,0 +1,311 @@
+// bf16 MFMA GEMMs for the ViLT encoder linears (throughput mode): v_mfma_f32_32x32x16_bf16, fp32 accumulate.
+//
+//   NT  C[M,N] = epi(A[M,K] . B[N,K]^T + bias)      forward (B = W) and input-gradient (B = W^T shadow) GEMMs
+//   TN  C[N,K] += A[M,N]^T . B[M,K]                 weight-gradient GEMM, reduction over the token dimension M
+//
+// Both: 256 threads = 4 waves (2x2), block tile 128x128, BK = 64, double-buffered LDS, global -> registers -> LDS
+// staging with the next tile's loads in flight under the current tile's MFMAs (one barrier per k-tile).
+// Operands are issued "swapped" (MFMA A = the weight-side tile, MFMA B = the token-side tile) so that in the 32x32
+// accumulator layout a lane owns ONE output row and 4 CONSECUTIVE output columns per register group: epilogues read
+// bias / residual / pre-activation and write C as 8- or 16-byte vectors.
+//
+// LDS images:
+//   NT: [128 rows][64 k] bf16, 128-B rows, 16-B chunks XOR-swizzled by swz(row) so that the ds_read_b128 fragment reads
+//       (16-lane groups = 16 different rows, same k-chunk) hit 16 distinct 4-bank groups: conflict-free.
+//   TN: [64 m][128 cols] bf16 with a 320-B row pitch; fragments are gathered with ds_read_b64_tr_b16 (the gfx950 LDS
+//       transpose read: a 16-lane group loads a [4 m][16 col] block and each lane receives one column = 4 consecutive
+//       reduction indices), two reads per 8-element operand.  Pitch 320 B puts 4 consecutive m-rows in 4 different
+//       bank quarters: conflict-free.
+#include "common.h"
+
+#define GB_BM 128
+#define GB_BN 128
+#define GB_BK 64
+
+__device__ __forceinline__ int swz(int row) {  // chunk XOR mask: rows (r, r+2) differ in bit 2, 16 rows of a group all distinct with parity
+  int y = (row >> 1) & 7;
+  return ((y & 1) << 2) | (y >> 1);
+}
+
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+__device__ __forceinline__ bf16x8 as_bf16x8(u32x4 v) {
+  union { u32x4 u; bf16x8 b; } c;
+  c.u = v;
+  return c.b;
+}
+
+// ---------------------------------------------------------------------------------------------------------------- NT
+// stage one [128][64] tile: thread t handles chunks (row = t/8 + 32p, c = t%8), p = 0..3
+__device__ __forceinline__ void nt_load(u32x4 (&r)[4], const bf16_t* __restrict__ P, long ld, int row0, int k0, int R, int K) {
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    int row = row0 + (t >> 3) + 32 * p;
+    row = row < R ? row : R - 1;                       // clamp: rows beyond R are never stored
+    const int k = k0 + (t & 7) * 8;
+    if (k < K) r[p] = *reinterpret_cast<const u32x4*>(P + (long)row * ld + k);
+    else r[p] = (u32x4){0u, 0u, 0u, 0u};
+  }
+}
+__device__ __forceinline__ void nt_store(const u32x4 (&r)[4], unsigned char* __restrict__ S) {
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int row = (t >> 3) + 32 * p, c = t & 7;
+    *reinterpret_cast<u32x4*>(S + row * 128 + ((c ^ swz(row)) << 4)) = r[p];
+  }
+}
+
+template <typename TO, int EPI>
+__global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ B, long ldb,
+                                                           TO* __restrict__ C, long ldc, int M, int N, int K, const float* __restrict__ bias,
+                                                           const void* __restrict__ aux, long ldaux, bf16_t* __restrict__ aux_out, long ldauxo) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * GB_BM * GB_BK * 2];   // [buf][A|B][128][64] bf16 = 64 KB
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int wm = wid >> 1, wn = wid & 1, half = lane >> 5, l31 = lane & 31;
+  // XCD-aware tile order: consecutive blocks of one XCD walk M-tiles under the same N-tile (B panel stays in that L2)
+  const int nbm = (M + GB_BM - 1) / GB_BM, nbn = (N + GB_BN - 1) / GB_BN;
+  int bid = blockIdx.x;
+  {
+    const int nwg = nbm * nbn, q = nwg / 8, rr = nwg % 8, xcd = bid % 8, idx = bid / 8;
+    bid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + idx;
+  }
+  const int m0 = (bid % nbm) * GB_BM, n0 = (bid / nbm) * GB_BN;
+  f32x16 acc[2][2];   // [n block][m block]
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  u32x4 ra[4], rb[4];
+  nt_load(ra, A, lda, m0, 0, M, K);
+  nt_load(rb, B, ldb, n0, 0, N, K);
+  nt_store(ra, smem);
+  nt_store(rb, smem + GB_BM * GB_BK * 2);
+  __syncthreads();
+  const int nk = (K + GB_BK - 1) / GB_BK;
+  for (int kt = 0; kt < nk; ++kt) {
+    unsigned char* As = smem + (kt & 1) * (2 * GB_BM * GB_BK * 2);
+    unsigned char* Bs = As + GB_BM * GB_BK * 2;
+    if (kt + 1 < nk) {
+      nt_load(ra, A, lda, m0, (kt + 1) * GB_BK, M, K);
+      nt_load(rb, B, ldb, n0, (kt + 1) * GB_BK, N, K);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      bf16x8 fa[2], fb[2];
+      const int c = 2 * ks + half;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int row = wm * 64 + j * 32 + l31;
+        fa[j] = as_bf16x8(*reinterpret_cast<const u32x4*>(As + row * 128 + ((c ^ swz(row)) << 4)));
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int row = wn * 64 + i * 32 + l31;
+        fb[i] = as_bf16x8(*reinterpret_cast<const u32x4*>(Bs + row * 128 + ((c ^ swz(row)) << 4)));
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[i], fa[j], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nk) {
+      unsigned char* An = smem + ((kt + 1) & 1) * (2 * GB_BM * GB_BK * 2);
+      nt_store(ra, An);
+      nt_store(rb, An + GB_BM * GB_BK * 2);
+    }
+    __syncthreads();
+  }
+  // epilogue: acc[i][j][4g..4g+3] = C[m][n..n+3], m = m0 + wm*64 + j*32 + l31, n = n0 + wn*64 + i*32 + 8g + 4*half
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int m = m0 + wm * 64 + j * 32 + l31;
+    if (m >= M) continue;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = n0 + wn * 64 + i * 32 + 8 * g + 4 * half;
+        if (n >= N) continue;
+        float4 v = make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+        if (bias) {
+          const float4 bv = ld4(bias + n);
+          v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+        }
+        if (EPI == EPI_GELU) {
+          st4(aux_out + (long)m * ldauxo + n, v);
+          v = make_float4(gelu_f(v.x), gelu_f(v.y), gelu_f(v.z), gelu_f(v.w));
+        } else if (EPI == EPI_RESID) {
+          const float4 rv = ld4(reinterpret_cast<const float*>(aux) + (long)m * ldaux + n);
+          v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+        } else if (EPI == EPI_DGELU) {
+          const float4 uv = ld4(reinterpret_cast<const bf16_t*>(aux) + (long)m * ldaux + n);
+          v.x *= dgelu_f(uv.x); v.y *= dgelu_f(uv.y); v.z *= dgelu_f(uv.z); v.w *= dgelu_f(uv.w);
+        }
+        st4(C + (long)m * ldc + n, v);
+      }
+  }
+}
+
+template <typename TO>
+static int nt_dispatch(const bf16_t* A, long lda, const bf16_t* B, long ldb, TO* C, long ldc, int M, int N, int K, const float* bias, int epi,
+                       const void* aux, long ldaux, bf16_t* aux_out, long ldauxo, hipStream_t st) {
+  const int nwg = ((M + GB_BM - 1) / GB_BM) * ((N + GB_BN - 1) / GB_BN);
+  dim3 grid(nwg), blk(256);
+#define NT_LAUNCH(E) hipLaunchKernelGGL((gemm_bf16_nt_kernel<TO, E>), grid, blk, 0, st, A, lda, B, ldb, C, ldc, M, N, K, bias, aux, ldaux, aux_out, ldauxo)
+  switch (epi) {
+    case EPI_NONE: NT_LAUNCH(EPI_NONE); break;
+    case EPI_GELU: NT_LAUNCH(EPI_GELU); break;
+    case EPI_RESID: NT_LAUNCH(EPI_RESID); break;
+    case EPI_DGELU: NT_LAUNCH(EPI_DGELU); break;
+    default: return CLIMB_EINVAL;
+  }
+#undef NT_LAUNCH
+  LAUNCH_CHECK();
+  return CLIMB_OK;
+}
+
+static inline bool al16p(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+// C (c_dtype: 0 fp32 / 1 bf16) [M,N] = epi(A[M,K] B[N,K]^T + bias).  A, B bf16 with K contiguous; K % 8 == 0, N % 4 == 0.
+// epi 1 (GELU): aux_out (bf16 [M,N]) receives the pre-activation.  epi 2: aux = fp32 residual [M,N].  epi 3: aux = bf16 pre-activation.
+extern "C" int climb_gemm_bf16_nt(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int c_dtype, int M, int N, int K,
+                                  const float* bias, int epi, const void* aux, long ldaux, void* aux_out, long ldauxo, void* stream) {
+  if (M <= 0 || N <= 0 || K <= 0 || (K % 8) || (N % 4) || (lda % 8) || (ldb % 8) || (ldc % 4) || !al16p(A) || !al16p(B) || !al16p(C)) return CLIMB_EINVAL;
+  if ((epi == EPI_RESID || epi == EPI_DGELU) && !aux) return CLIMB_EINVAL;
+  if (epi == EPI_GELU && !aux_out) return CLIMB_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if (c_dtype == CLIMB_DT_F32)
+    return nt_dispatch<float>((const bf16_t*)A, lda, (const bf16_t*)B, ldb, (float*)C, ldc, M, N, K, bias, epi, aux, ldaux, (bf16_t*)aux_out, ldauxo, st);
+  if (c_dtype == CLIMB_DT_BF16)
+    return nt_dispatch<bf16_t>((const bf16_t*)A, lda, (const bf16_t*)B, ldb, (bf16_t*)C, ldc, M, N, K, bias, epi, aux, ldaux, (bf16_t*)aux_out, ldauxo, st);
+  return CLIMB_EINVAL;
+}
+
+// ---------------------------------------------------------------------------------------------------------------- TN
+#define TN_BR 64            // reduction rows (tokens) per LDS tile
+#define TN_PITCH 320        // bytes per LDS row: 128 cols * 2 B + 64 B pad
+
+// stage one [64 m][128 cols] tile: thread t handles (row = t/16 + 16p, chunk = t%16), p = 0..3
+__device__ __forceinline__ void tn_load(u32x4 (&r)[4], const bf16_t* __restrict__ P, long ld, int m0, int c0, int m_end, int Ccols) {
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int m = m0 + (t >> 4) + 16 * p;
+    int c = c0 + (t & 15) * 8;
+    const bool ok = m < m_end && c < Ccols;              // rows past the end contribute zeros to the reduction
+    r[p] = ok ? *reinterpret_cast<const u32x4*>(P + (long)m * ld + c) : (u32x4){0u, 0u, 0u, 0u};
+  }
+}
+__device__ __forceinline__ void tn_store(const u32x4 (&r)[4], unsigned char* __restrict__ S) {
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) *reinterpret_cast<u32x4*>(S + ((t >> 4) + 16 * p) * TN_PITCH + ((t & 15) << 4)) = r[p];
+}
+// 8-element MFMA operand for output index (col0 + lane&31) and reduction rows mrow0 + (lane>>5)*8 + 0..7
+__device__ __forceinline__ bf16x8 tn_frag(const unsigned char* __restrict__ S, int mrow0, int col0, int lane) {
+  const int g16 = lane >> 4, i = lane & 15;
+  const int row = mrow0 + (g16 >> 1) * 8 + (i >> 2);
+  const int col = col0 + (g16 & 1) * 16 + 4 * (i & 3);
+  const unsigned char* p = S + row * TN_PITCH + col * 2;
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
+  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 4 * TN_PITCH));
+  union { s16x4 h[2]; bf16x8 b; } c;
+  c.h[0] = lo;
+  c.h[1] = hi;
+  return c.b;
+}
+
+// grid: (tiles, splits).  C[n][k] += sum_m A[m][n] * B[m][k]; ATOMIC = 1 when several splits accumulate into C.
+template <bool ATOMIC>
+__global__ __launch_bounds__(256) void gemm_bf16_tn_kernel(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ B, long ldb,
+                                                           float* __restrict__ C, long ldc, int M, int N, int K, int rows_per_split) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * TN_BR * TN_PITCH];   // [buf][A|B][64][320 B] = 80 KB
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int wn = wid >> 1, wk = wid & 1, half = lane >> 5, l31 = lane & 31;
+  const int nbn = (N + 127) / 128;
+  const int n0 = (blockIdx.x % nbn) * 128, k0 = (blockIdx.x / nbn) * 128;
+  const int mbeg = blockIdx.y * rows_per_split;
+  const int mend = min(M, mbeg + rows_per_split);
+  f32x16 acc[2][2];   // [n block][k block]
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  u32x4 ra[4], rb[4];
+  tn_load(ra, A, lda, mbeg, n0, mend, N);
+  tn_load(rb, B, ldb, mbeg, k0, mend, K);
+  tn_store(ra, smem);
+  tn_store(rb, smem + TN_BR * TN_PITCH);
+  __syncthreads();
+  const int nt = (mend - mbeg + TN_BR - 1) / TN_BR;
+  for (int t = 0; t < nt; ++t) {
+    const unsigned char* As = smem + (t & 1) * (2 * TN_BR * TN_PITCH);
+    const unsigned char* Bs = As + TN_BR * TN_PITCH;
+    if (t + 1 < nt) {
+      tn_load(ra, A, lda, mbeg + (t + 1) * TN_BR, n0, mend, N);
+      tn_load(rb, B, ldb, mbeg + (t + 1) * TN_BR, k0, mend, K);
+    }
+#pragma unroll
+    for (int ms = 0; ms < TN_BR / 16; ++ms) {
+      bf16x8 fa[2], fb[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) fa[i] = tn_frag(As, ms * 16, wn * 64 + i * 32, lane);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) fb[j] = tn_frag(Bs, ms * 16, wk * 64 + j * 32, lane);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+    if (t + 1 < nt) {
+      unsigned char* An = smem + ((t + 1) & 1) * (2 * TN_BR * TN_PITCH);
+      tn_store(ra, An);
+      tn_store(rb, An + TN_BR * TN_PITCH);
+    }
+    __syncthreads();
+  }
+  // D layout: col = lane&31 -> k, row = (r&3) + 8*(r>>2) + 4*half -> n ; a wave-instruction writes 2 rows x 32 consecutive floats
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int k = k0 + wk * 64 + j * 32 + l31;
+      if (k >= K) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = n0 + wn * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (n >= N) continue;
+        float* cp = C + (long)n * ldc + k;
+        if (ATOMIC) atomicAdd(cp, acc[i][j][r]);
+        else *cp += acc[i][j][r];
+      }
+    }
+}
+
+// C[N,K] (fp32, ldc) += A[M,N]^T B[M,K]; A, B bf16 row-major (lda, ldb).  N % 8 == 0, K % 8 == 0.
+extern "C" int climb_gemm_bf16_tn(const void* A, long lda, const void* B, long ldb, float* C, long ldc, int M, int N, int K, void* stream) {
+  if (M <= 0 || N <= 0 || K <= 0 || (N % 8) || (K % 8) || (lda % 8) || (ldb % 8) || !al16p(A) || !al16p(B)) return CLIMB_EINVAL;
+  const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
+  int splits = (512 + tiles - 1) / tiles;                         // aim at ~2 workgroups per CU
+  const int max_splits = (M + 4 * TN_BR - 1) / (4 * TN_BR);       // at least 4 LDS tiles of work per split
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  int rows = (M + splits - 1) / splits;
+  rows = (rows + TN_BR - 1) / TN_BR * TN_BR;
+  splits = (M + rows - 1) / rows;
+  dim3 grid(tiles, splits), blk(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (splits > 1)
+    hipLaunchKernelGGL((gemm_bf16_tn_kernel<true>), grid, blk, 0, st, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc, M, N, K, rows);
+  else
+    hipLaunchKernelGGL((gemm_bf16_tn_kernel<false>), grid, blk, 0, st, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc, M, N, K, rows);
+  LAUNCH_CHECK();
+  return CLIMB_OK;
+}

@@ -169,6 +169,36 @@ extern "C" int climb_transpose_bf16(const void* in, void* out, int R, int C, voi
   return CLIMB_OK;
 }
 
+// many [R,C] -> [C,R] transposes in one launch: table[i] = {src_off, dst_off, R, C} (elements), grid.y = matrix
+__global__ __launch_bounds__(256) void transpose_bf16_batched_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst,
+                                                                     const long* __restrict__ table) {
+  __shared__ bf16_t tile[64][66];
+  const long* t = table + 4 * blockIdx.y;
+  const int R = (int)t[2], C = (int)t[3];
+  const int tc = (C + 63) / 64, tr = (R + 63) / 64;
+  const bf16_t* in = src + t[0];
+  bf16_t* out = dst + t[1];
+  for (int tileid = blockIdx.x; tileid < tc * tr; tileid += gridDim.x) {
+    const int r0 = (tileid / tc) * 64, c0 = (tileid % tc) * 64;
+    __syncthreads();
+    for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+      int r = e >> 6, c = e & 63;
+      tile[r][c] = (r0 + r < R && c0 + c < C) ? in[(long)(r0 + r) * C + c0 + c] : (bf16_t)0;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+      int c = e >> 6, r = e & 63;
+      if (r0 + r < R && c0 + c < C) out[(long)(c0 + c) * R + r0 + r] = tile[r][c];
+    }
+  }
+}
+extern "C" int climb_transpose_bf16_batched(const void* src, void* dst, const long* table, int n, int tiles_per_matrix, void* stream) {
+  if (n <= 0 || tiles_per_matrix <= 0) return CLIMB_EINVAL;
+  hipLaunchKernelGGL(transpose_bf16_batched_kernel, dim3(tiles_per_matrix, n), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, (bf16_t*)dst, table);
+  LAUNCH_CHECK();
+  return CLIMB_OK;
+}
+
 extern "C" int climb_version() { return 100; }
 extern "C" const char* climb_arch() { return "gfx950"; }
 extern "C" const char* climb_error_string(int code) {

@@ -106,6 +106,7 @@ class ViltEngine:
         self._shadow = None                             # bf16 copies of the flat buffer (bf16 mode)
         self._shadow_t = None
         self._shadow_version = -1
+        self._shadow_stale = False
         self._ewc_ws = None
         self.requires_grad: Dict[str, bool] = {n: True for n in layout.shapes}
         self.grad_ready_hook: Optional[Callable[[int, int], None]] = None   # (lo, hi) flat range whose grads are final
@@ -145,13 +146,6 @@ class ViltEngine:
             if lo <= o < hi:
                 return True
         return False
-
-    def shadow_ptr(self):
-        """bf16 weight shadow the fused AdamW refreshes in the same pass (None in fp32 mode)."""
-        return None
-
-    def params_updated(self, shadow_fresh: bool = False):
-        pass
 
     def workspace(self, B: int, T: int) -> Workspace:
         key = (B, T)
@@ -218,14 +212,88 @@ class ViltEngine:
         _lib.call("climb_colsum", dY, C, dtype, None, 0, ws.part, M, C, _stream())
         _lib.call("climb_colreduce", ws.part, C, (M + csr - 1) // csr, self.g(bname), C, 1.0, _stream())
 
-    # bf16 paths are bound in engine_bf16.py (keeps this file readable)
-    def _bf16_fwd(self, *a, **k):
-        raise NotImplementedError("bf16 GEMM path not linked")
+    # ------------------------------------------------------------------ bf16 operand shadows + GEMM dispatch
+    def _linear_weight_names(self):
+        """2-D encoder weights that appear as the B operand of an input-gradient GEMM (need a [K,N] transposed shadow)."""
+        out = []
+        for i in range(self.cfg["layers"]):
+            l = f"{ENC}encoder.layer.{i}."
+            H, Fd = self.cfg["hidden"], self.cfg["ffn"]
+            out += [(l + "attention.attention.query.weight", 3 * H, H), (l + "attention.output.dense.weight", H, H),
+                    (l + "intermediate.dense.weight", Fd, H), (l + "output.dense.weight", H, Fd)]
+        return out
 
-    _bf16_dx = _bf16_dw = _bf16_fwd
+    def _build_shadow(self):
+        import numpy as np
+        dev = self.device
+        self._shadow = torch.empty(self.layout.total, dtype=torch.bfloat16, device=dev)
+        rows, off = [], 0
+        self._t_off = {}
+        for name, N, K in self._linear_weight_names():
+            self._t_off[name] = off
+            rows.append((self.layout.offset[name], off, N, K))
+            off += N * K
+        self._shadow_t = torch.empty(off, dtype=torch.bfloat16, device=dev)
+        self._t_table = torch.from_numpy(np.array(rows, dtype=np.int64)).to(dev)
+        self._t_n = len(rows)
 
-    def refresh_shadow(self):
-        pass
+    def refresh_shadow(self, cast: bool = True):
+        """bf16 copies of the weights for the MFMA operands: refreshed when the fp32 master changed (torch in-place ops
+        bump the version counter; our fused AdamW refreshes the straight shadow itself and calls params_updated)."""
+        if self.precision != "bf16":
+            return
+        if self._shadow is None:
+            self._build_shadow()
+            self._shadow_version = -1
+        ver = self.flat._version
+        if ver == self._shadow_version and not self._shadow_stale:
+            return
+        st = _stream()
+        if self._shadow_stale != "transpose-only":
+            _lib.call("climb_cast_bf16", self.flat, self._shadow, self.layout.total, st)
+        _lib.call("climb_transpose_bf16_batched", self._shadow, self._shadow_t, self._t_table, self._t_n, 96, st)
+        self._shadow_version = ver
+        self._shadow_stale = False
+
+    def shadow_ptr(self):
+        """bf16 weight shadow the fused AdamW refreshes in the same pass (None in fp32 mode)."""
+        if self.precision != "bf16":
+            return None
+        if self._shadow is None:
+            self.refresh_shadow()          # first use: full cast, so tensors the optimiser skips have valid shadows too
+        return self._shadow
+
+    def params_updated(self, shadow_fresh: bool = False):
+        self._shadow_stale = "transpose-only" if shadow_fresh else True
+
+    def sp(self, name: str) -> int:
+        return self._shadow.data_ptr() + 2 * self.layout.offset[name]
+
+    def spt(self, name: str) -> int:
+        return self._shadow_t.data_ptr() + 2 * self._t_off[name]
+
+    def _timed_call(self, kernel, flops, name, *args):
+        prof = self.prof
+        if prof is not None and prof["kernel"] == kernel:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            _lib.call(name, *args)
+            e1.record()
+            prof["events"].append((e0, e1, flops))
+        else:
+            _lib.call(name, *args)
+
+    def _bf16_fwd(self, X, wname, bname, Y, M, N, K, epi=EPI_NONE, aux=None, aux_out=None, out_f32=False):
+        self._timed_call("gemm_bf16_nt", 2.0 * M * N * K, "climb_gemm_bf16_nt", X, K, self.sp(wname), K, Y, N, F32 if out_f32 else BF16, M, N, K,
+                         self.p(bname) if bname else None, epi, aux, N, aux_out, N, _stream())
+
+    def _bf16_dx(self, dY, wname, dX, M, N, K, epi=EPI_NONE, aux=None):
+        # dX[M,K] = dY[M,N] W[N,K] = dY (W^T)^T : NT GEMM against the transposed shadow [K,N]
+        self._timed_call("gemm_bf16_nt", 2.0 * M * N * K, "climb_gemm_bf16_nt", dY, N, self.spt(wname), N, dX, K, BF16, M, K, N, None, epi, aux, K,
+                         None, 0, _stream())
+
+    def _bf16_dw(self, dY, X, wname, M, N, K):
+        self._timed_call("gemm_bf16_tn", 2.0 * M * N * K, "climb_gemm_bf16_tn", dY, N, X, K, self.g(wname), K, M, N, K, _stream())
 
     @property
     def adt(self):

@@ -89,6 +89,19 @@ int climb_fisher_accum(float* fisher, const float* grad, long n, void* stream);
 int climb_scale(float* x, long n, float s, void* stream);
 int climb_cast_bf16(const float* x, void* y, long n, void* stream);
 int climb_transpose_bf16(const void* in, void* out, int R, int C, void* stream);
+/* n transposes in one launch: table[i] = {src_off, dst_off, R, C} in elements (int64, device); grid = (tiles_per_matrix, n) */
+int climb_transpose_bf16_batched(const void* src, void* dst, const long* table, int n, int tiles_per_matrix, void* stream);
+
+/* ---- bf16 throughput path (v_mfma_f32_32x32x16_bf16, fp32 accumulate) --------------------------------------------------- */
+/* nn.Linear forward and input-gradient GEMMs (HF:325-327, :366-369, :397-400, :410-414):
+ * C[M,N] (c_dtype) = epi(A[M,K] B[N,K]^T + bias); A,B bf16, K contiguous.  epi 1: aux_out (bf16) = pre-activation;
+ * epi 2: aux = fp32 residual [M,N]; epi 3: aux = bf16 pre-activation (multiplies by gelu'). */
+int climb_gemm_bf16_nt(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int c_dtype, int M, int N, int K, const float* bias, int epi, const void* aux, long ldaux, void* aux_out, long ldauxo, void* stream);
+/* weight gradient: C[N,K] (fp32) += A[M,N]^T B[M,K]; reduction over tokens via LDS transpose reads, split over M with fp32 atomics */
+int climb_gemm_bf16_tn(const void* A, long lda, const void* B, long ldb, float* C, long ldc, int M, int N, int K, void* stream);
+/* HF:322-351 in bf16: same contract as the _f32 entry points, qkv/ctx/dctx/dqkv are bf16 */
+int climb_attn_fwd_bf16(const void* qkv, const float* key_bias, void* ctx, float* lse, int B, int S_pad, int heads, int head_dim, void* stream);
+int climb_attn_bwd_bf16(const void* qkv, const float* key_bias, const void* dctx, const float* lse, const float* delta, void* dqkv, int B, int S_pad, int heads, int head_dim, void* stream);
 
 #ifdef __cplusplus
 }

@@ -226,3 +226,98 @@ def test_adamw_ewc_fisher_flat_kernels():
     f2 = fis.to(dev).clone()
     _lib.call("climb_fisher_accum", f2, gd2, n, _st())
     assert _rel(f2, fis.double() + gd2.cpu().double() ** 2) < 2e-6
+
+
+# ------------------------------------------------------------------------------------------------ bf16 throughput path
+def _bf(x):
+    return x.to(torch.bfloat16)
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (384, 768, 768), (200, 2304, 768), (390, 48, 768), (384, 768, 3072)])
+def test_gemm_bf16_nt(M, N, K):
+    """bf16 operands, fp32 accumulate: compared with a float64 product of the SAME bf16-rounded operands, so the only
+    error left is accumulation order + the bf16 rounding of the output (<= 2^-8 relative)."""
+    from climb_amd import _lib
+    dev = _dev()
+    g = torch.Generator().manual_seed(M + N + K)
+    A, W = _bf(torch.randn(M, K, generator=g)), _bf(torch.randn(N, K, generator=g) * 0.05)
+    bias = torch.randn(N, generator=g)
+    ref = A.double() @ W.double().t() + bias.double()
+    Ad, Wd, bd = A.to(dev), W.to(dev), bias.to(dev)
+    C32 = torch.empty(M, N, device=dev)
+    _lib.call("climb_gemm_bf16_nt", Ad, K, Wd, K, C32, N, 0, M, N, K, bd, 0, None, 0, None, 0, _st())
+    assert _rel(C32, ref) < 1e-5
+    C16 = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    U = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    _lib.call("climb_gemm_bf16_nt", Ad, K, Wd, K, C16, N, 1, M, N, K, bd, 1, None, 0, U, N, _st())
+    assert _rel(U.float(), ref) < 5e-3 and _rel(C16.float(), gelu(ref)) < 5e-3
+    R = torch.randn(M, N, generator=g).to(dev)
+    _lib.call("climb_gemm_bf16_nt", Ad, K, Wd, K, C32, N, 0, M, N, K, bd, 2, R, N, None, 0, _st())
+    assert _rel(C32, ref + R.cpu().double()) < 1e-5
+    Uin = _bf(torch.randn(M, N, generator=g)).to(dev)
+    _lib.call("climb_gemm_bf16_nt", Ad, K, Wd, K, C16, N, 1, M, N, K, None, 3, Uin, N, None, 0, _st())
+    ur = Uin.cpu().double().requires_grad_(True)
+    gelu(ur).backward(A.double() @ W.double().t())
+    assert _rel(C16.float(), ur.grad) < 5e-3
+
+
+@pytest.mark.parametrize("M,N,K", [(64, 128, 128), (384, 768, 768), (1000, 2304, 768), (300, 768, 3072), (130, 48, 768)])
+def test_gemm_bf16_tn_weight_grad(M, N, K):
+    from climb_amd import _lib
+    dev = _dev()
+    g = torch.Generator().manual_seed(M + 3 * N + K)
+    dY, X = _bf(torch.randn(M, N, generator=g)), _bf(torch.randn(M, K, generator=g))
+    C0 = torch.randn(N, K, generator=g)
+    C = C0.to(dev).clone()
+    _lib.call("climb_gemm_bf16_tn", dY.to(dev), N, X.to(dev), K, C, K, M, N, K, _st())
+    ref = C0.double() + dY.double().t() @ X.double()
+    assert _rel(C, ref) < 1e-5
+
+
+@pytest.mark.parametrize("S_pad,valid", [(64, 50), (192, 185), (224, 200), (288, 281)])
+def test_attention_bf16_fwd_bwd(S_pad, valid):
+    from climb_amd import _lib
+    dev = _dev()
+    B, heads, d = 2, 3, 64
+    H = heads * d
+    g = torch.Generator().manual_seed(S_pad + 1)
+    qkv = _bf(torch.randn(B, S_pad, 3 * H, generator=g))
+    bias = torch.zeros(B, S_pad)
+    bias[:, valid:] = -3.0e38
+    bias[1, 3:7] = -3.0e38
+    dctx = _bf(torch.randn(B, S_pad, H, generator=g))
+    dctx[:, valid:] = 0
+    qr = qkv.double().requires_grad_(True)
+    ref = _attn_ref(qr, bias.double().clamp(min=-1e300), heads)
+    ref.backward(dctx.double())
+    qd, bd, dd = qkv.to(dev).view(B * S_pad, 3 * H), bias.to(dev), dctx.to(dev).view(B * S_pad, H)
+    ctx = torch.empty(B * S_pad, H, device=dev, dtype=torch.bfloat16)
+    lse = torch.empty(B, heads, S_pad, device=dev)
+    _lib.call("climb_attn_fwd_bf16", qd, bd, ctx, lse, B, S_pad, heads, d, _st())
+    e_fwd = _rel(ctx.float().view(B, S_pad, H)[:, :valid], ref.detach()[:, :valid])
+    delta = torch.empty(B, heads, S_pad, device=dev)
+    dqkv = torch.full((B * S_pad, 3 * H), float("nan"), device=dev, dtype=torch.bfloat16)
+    _lib.call("climb_attn_delta", dd, ctx, 1, delta, B, S_pad, heads, _st())
+    _lib.call("climb_attn_bwd_bf16", qd, bd, dd, lse, delta, dqkv, B, S_pad, heads, d, _st())
+    assert not torch.isnan(dqkv.float()).any()
+    e_bwd = _rel(dqkv.float().view(B, S_pad, 3 * H), qr.grad)
+    print(f"attention bf16 S_pad={S_pad}: fwd {e_fwd:.2e} bwd {e_bwd:.2e}")
+    # P and dS are rounded to bf16 before the second MFMA of each product: 2^-8 relative per element, averaged by the sums
+    assert e_fwd < 1e-2 and e_bwd < 2e-2
+
+
+def test_weight_shadow_cast_and_batched_transpose():
+    from climb_amd import _lib
+    dev = _dev()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2 * 96 * 160, generator=g)
+    xd = x.to(dev)
+    sh = torch.empty_like(xd, dtype=torch.bfloat16)
+    _lib.call("climb_cast_bf16", xd, sh, x.numel(), _st())
+    assert torch.equal(sh.cpu(), x.to(torch.bfloat16))
+    out = torch.empty_like(sh)
+    table = torch.tensor([[0, 0, 96, 160], [96 * 160, 96 * 160, 160, 96]], dtype=torch.int64, device=dev)
+    _lib.call("climb_transpose_bf16_batched", sh, out, table, 2, 4, _st())
+    a = sh[:96 * 160].view(96, 160).t().contiguous().view(-1)
+    b = sh[96 * 160:].view(160, 96).t().contiguous().view(-1)
+    assert torch.equal(out.cpu(), torch.cat([a, b]).cpu())

@@ -336,3 +336,39 @@ def test_freeze_bottom_k_skips_frozen_gradients():
     _, _, _, oG = vo.train_step(P, "vqa", enc, target, trainable=trainable)
     for n in (vo.ENC + "encoder.layer.9.attention.attention.query.weight", vo.ENC + "encoder.layer.11.output.dense.bias", "task_layer.vqa.0.weight"):
         _close(G[n], oG[n], TOL, n)
+
+
+# ------------------------------------------------------------------------------------------------ bf16 throughput mode
+BF16_TOL = 3e-2     # bf16 operands (2^-8 relative rounding per GEMM input) through 12 layers; fp32 accumulate/statistics
+
+
+def test_bf16_mode_step_vs_oracle(golden_dir):
+    """BASELINE.json configs[1] arithmetic (bf16 MFMA operands) on the config-0 inputs: same step as the fp32 test,
+    looser tolerance.  The 1e-3 / argmax-exact bar of north_star is the fp32 mode's; this documents what bf16 costs."""
+    z = np.load(os.path.join(golden_dir, "vqa_b2.npz"))
+    m = _meta(z)
+    B = int(m["B"])
+    model, P = make_model(m["tasks"].split(","), int(m["wseed"]), precision="bf16")
+    enc = vo.synthetic_encodings(B, seed=int(m["dseed"]))
+    target = vo.synthetic_vqa_targets(B, seed=int(m["dseed"]))
+    images, texts = enc_to_inputs(enc)
+    model.train()
+    loss, (pooled, logits), _, _ = model.fused_forward_backward("vqa", images, texts, target)
+    e = dict(pooled=_close(pooled, z["pooled"], BF16_TOL, "pooled"), logits=_close(logits, z["logits"], BF16_TOL, "logits"),
+             loss=_close(loss, z["loss"], BF16_TOL, "loss"))
+    G = grads_of(model)
+    names = [str(n) for n in z["grad_names"]]
+    norms, _ = _summary(G, names)
+    big = z["grad_norms"] > 1e-3 * z["grad_norms"].max()
+    rel = np.abs(norms - z["grad_norms"])[big] / z["grad_norms"][big]
+    print("bf16 mode errors:", {k: f"{v:.2e}" for k, v in e.items()}, f"grad-norm rel err: median {np.median(rel):.2e} max {rel.max():.2e}")
+    assert rel.max() < 6e-2
+    # a second step after the fused AdamW must see refreshed bf16 shadows (straight and transposed)
+    opt = model.create_optimizer({"lr": 1e-3, "weight_decay": 1e-2, "adam_epsilon": 1e-8})
+    opt.step()
+    opt.zero_grad()
+    loss2, _, _, _ = model.fused_forward_backward("vqa", images, texts, target)
+    P2 = {n: p.detach().cpu().clone() for n, p in model.named_parameters()}
+    o_loss2, _, _, _ = vo.train_step(P2, "vqa", enc, target)
+    _close(loss2, o_loss2, BF16_TOL, "loss after one AdamW step")
+    assert abs(float(loss2) - float(loss)) > 1e-3 * abs(float(loss)), "the update must change the loss"
