@@ -27,7 +27,15 @@ __device__ __forceinline__ void tile_load(TileRegs<BR>& t, const float* __restri
     for (int p = 0; p < NE / 4; ++p) {
       int row = tid / 4 + 64 * p, kq = (tid & 3) * 4;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (r0 + row < R && k0 + kq < K) v = ld4(P + (long)(r0 + row) * s_r + (k0 + kq));
+      if (r0 + row < R) {
+        const float* q = P + (long)(r0 + row) * s_r + (k0 + kq);
+        if (k0 + kq + 3 < K) v = ld4(q);
+        else {                                   // ragged K tail: element-wise, zero-filled
+          if (k0 + kq < K) v.x = q[0];
+          if (k0 + kq + 1 < K) v.y = q[1];
+          if (k0 + kq + 2 < K) v.z = q[2];
+        }
+      }
       t.v[p * 4 + 0] = v.x; t.v[p * 4 + 1] = v.y; t.v[p * 4 + 2] = v.z; t.v[p * 4 + 3] = v.w;
     }
   } else if (mode == 2) {
@@ -37,7 +45,15 @@ __device__ __forceinline__ void tile_load(TileRegs<BR>& t, const float* __restri
     for (int p = 0; p < NE / 4; ++p) {
       int k = tid / TPK + KPP * p, r4 = (tid % TPK) * 4;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (k0 + k < K && r0 + r4 < R) v = ld4(P + (long)(k0 + k) * s_k + (r0 + r4));
+      if (k0 + k < K) {
+        const float* q = P + (long)(k0 + k) * s_k + (r0 + r4);
+        if (r0 + r4 + 3 < R) v = ld4(q);
+        else {                                   // ragged row tail (e.g. 3129 VQA labels)
+          if (r0 + r4 < R) v.x = q[0];
+          if (r0 + r4 + 1 < R) v.y = q[1];
+          if (r0 + r4 + 2 < R) v.z = q[2];
+        }
+      }
       t.v[p * 4 + 0] = v.x; t.v[p * 4 + 1] = v.y; t.v[p * 4 + 2] = v.z; t.v[p * 4 + 3] = v.w;
     }
   } else {
@@ -161,8 +177,8 @@ extern "C" int climb_gemm_f32(const float* A, long sam, long sak, const float* B
   if ((epi == EPI_RESID || epi == EPI_DGELU) && !aux) return CLIMB_EINVAL;
   if (epi == EPI_GELU && !aux_out) return CLIMB_EINVAL;
   auto pick = [](const float* P, long s_r, long s_k, int R, int K_) -> int {
-    if (s_k == 1 && (s_r % 4) == 0 && (K_ % 4) == 0 && al16(P)) return 1;
-    if (s_r == 1 && (s_k % 4) == 0 && (R % 4) == 0 && al16(P)) return 2;
+    if (s_k == 1 && (s_r % 4) == 0 && al16(P)) return 1;
+    if (s_r == 1 && (s_k % 4) == 0 && al16(P)) return 2;
     return 0;
   };
   const int modeA = pick(A, sam, sak, M, K), modeB = pick(B, sbn, sbk, N, K);

@@ -77,7 +77,7 @@ extern "C" int climb_layernorm_fwd(const float* x, long ldx, const float* gamma,
 //   dxo = dres_in + rstd * (g - mean_c(g) - xhat * mean_c(g * xhat)),  g = dy * gamma, xhat = (x - mean) * rstd
 // Writes dxo (fp32, may alias dres_in), an optional cast of it (next GEMM operand), and per-block partial column
 // sums  part[blk][0]=dgamma, [1]=dbeta, [2]=colsum(dxo)  (reduced deterministically by climb_colreduce).
-#define LNB_ROWS 32  // rows per block (4 waves x 8 rows)
+#define LNB_ROWS 16  // rows per block (4 waves x 4 rows)
 template <typename TI, typename TO, int NV>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TI* __restrict__ dy, long lddy, const float* __restrict__ x, long ldx,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -174,24 +174,49 @@ extern "C" int climb_layernorm_bwd(const void* dy, long lddy, int dtype, const f
 extern "C" int climb_layernorm_bwd_rows_per_block() { return LNB_ROWS; }
 
 // out[c] = beta*out[c] + sum_b part[b*stride + c]     (deterministic second stage of every column reduction)
-__global__ void colreduce_kernel(const float* __restrict__ part, long stride, int nblk, float* __restrict__ out, int ncols, float beta) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= ncols) return;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  int b = 0;
-  for (; b + 3 < nblk; b += 4) {
-    s0 += part[(long)b * stride + c];
-    s1 += part[(long)(b + 1) * stride + c];
-    s2 += part[(long)(b + 2) * stride + c];
-    s3 += part[(long)(b + 3) * stride + c];
+// block = 32 columns x 8 row-groups: each thread sums nblk/8 partial rows (independent loads), LDS tree over the groups.
+// grid.y selects one of up to 3 (column offset -> output) pairs so the {dgamma, dbeta, colsum} triple is ONE launch.
+struct ColOut { float* out[3]; long col_off[3]; };
+__global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict__ part, long stride, int nblk, ColOut o, int ncols, float beta) {
+  __shared__ float red[8][33];
+  const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cx;
+  float* out = o.out[blockIdx.y];
+  if (!out) return;
+  const float* src = part + o.col_off[blockIdx.y];
+  float s0 = 0.f, s1 = 0.f;
+  if (c < ncols) {
+    int b = ry;
+    for (; b + 8 < nblk; b += 16) {
+      s0 += src[(long)b * stride + c];
+      s1 += src[(long)(b + 8) * stride + c];
+    }
+    if (b < nblk) s0 += src[(long)b * stride + c];
   }
-  for (; b < nblk; ++b) s0 += part[(long)b * stride + c];
-  float s = (s0 + s1) + (s2 + s3);
-  out[c] = (beta != 0.f ? beta * out[c] : 0.f) + s;
+  red[ry][cx] = s0 + s1;
+  __syncthreads();
+  if (ry == 0 && c < ncols) {
+    float s = ((red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx])) + ((red[4][cx] + red[5][cx]) + (red[6][cx] + red[7][cx]));
+    out[c] = (beta != 0.f ? beta * out[c] : 0.f) + s;
+  }
 }
 extern "C" int climb_colreduce(const float* part, long stride, int nblk, float* out, int ncols, float beta, void* stream) {
   if (ncols <= 0 || nblk <= 0) return CLIMB_EINVAL;
-  hipLaunchKernelGGL(colreduce_kernel, dim3((ncols + 127) / 128), dim3(128), 0, (hipStream_t)stream, part, stride, nblk, out, ncols, beta);
+  ColOut o;
+  o.out[0] = out; o.out[1] = o.out[2] = nullptr;
+  o.col_off[0] = o.col_off[1] = o.col_off[2] = 0;
+  hipLaunchKernelGGL(colreduce_kernel, dim3((ncols + 31) / 32, 1), dim3(256), 0, (hipStream_t)stream, part, stride, nblk, o, ncols, beta);
+  LAUNCH_CHECK();
+  return CLIMB_OK;
+}
+// three reductions over the same partial buffer: out_k[c] = beta*out_k[c] + sum_b part[b*stride + k*ncols + c]; NULL outputs are skipped
+extern "C" int climb_colreduce3(const float* part, long stride, int nblk, float* out0, float* out1, float* out2, int ncols, float beta, void* stream) {
+  if (ncols <= 0 || nblk <= 0) return CLIMB_EINVAL;
+  if (!out0 && !out1 && !out2) return CLIMB_OK;
+  ColOut o;
+  o.out[0] = out0; o.out[1] = out1; o.out[2] = out2;
+  o.col_off[0] = 0; o.col_off[1] = ncols; o.col_off[2] = 2L * ncols;
+  hipLaunchKernelGGL(colreduce_kernel, dim3((ncols + 31) / 32, 3), dim3(256), 0, (hipStream_t)stream, part, stride, nblk, o, ncols, beta);
   LAUNCH_CHECK();
   return CLIMB_OK;
 }
@@ -288,14 +313,15 @@ extern "C" int climb_embed_text_fwd(const long* ids, const long* tts, const floa
   return CLIMB_OK;
 }
 
-// Backward of the above.  dres rows [b, t, :] hold d(x).  Scatter-adds (atomics) into the word/type/pos tables;
-// per-block partials part[blk][0]=dgamma, [1]=dbeta, [2]=dmodality0 (colreduce'd by the caller).
+// Backward of the above.  dres rows [b, t, :] hold d(x).  Writes the pre-LayerNorm gradient dpre [B*T, H] (summed into the
+// position / token-type tables by embed_text_bwd_tables_kernel: every row hits the same few table rows, so atomics there
+// would serialise), scatter-adds into the word table, and per-block partials part[blk][0]=dgamma, [1]=dbeta, [2]=dmodality0.
 __global__ __launch_bounds__(256) void embed_text_bwd_kernel(const long* __restrict__ ids, const long* __restrict__ tts,
                                                              const float* __restrict__ word, const float* __restrict__ type,
                                                              const float* __restrict__ pos, const float* __restrict__ gamma,
                                                              const float* __restrict__ mean, const float* __restrict__ rstd,
                                                              const float* __restrict__ dres, int B, int T, int S_pad, int H,
-                                                             float* dword, float* dtype_, float* dpos, float* __restrict__ part) {
+                                                             float* dword, float* __restrict__ dpre, float* __restrict__ part) {
   __shared__ __attribute__((aligned(16))) float red[3][4][768];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   float4 ag[3], ab[3], am[3], gm[3];
@@ -333,12 +359,10 @@ __global__ __launch_bounds__(256) void embed_text_bwd_kernel(const long* __restr
       if (c < H) {
         float o[4] = {rs * (g[i].x - m1 - xh[i].x * m2), rs * (g[i].y - m1 - xh[i].y * m2), rs * (g[i].z - m1 - xh[i].z * m2),
                       rs * (g[i].w - m1 - xh[i].w * m2)};
+        if (dpre) st4(dpre + (long)row * H + c, make_float4(o[0], o[1], o[2], o[3]));
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          if (dword) atomicAdd(dword + id * H + c + j, o[j]);
-          if (dtype_) atomicAdd(dtype_ + tt * H + c + j, o[j]);
-          if (dpos) atomicAdd(dpos + (long)t * H + c + j, o[j]);
-        }
+        for (int j = 0; j < 4; ++j)
+          if (dword) atomicAdd(dword + id * H + c + j, o[j]);          // random vocabulary rows: low contention
         ag[i].x += d[i].x * xh[i].x; ag[i].y += d[i].y * xh[i].y; ag[i].z += d[i].z * xh[i].z; ag[i].w += d[i].w * xh[i].w;
         ab[i].x += d[i].x; ab[i].y += d[i].y; ab[i].z += d[i].z; ab[i].w += d[i].w;
         am[i].x += d[i].x; am[i].y += d[i].y; am[i].z += d[i].z; am[i].w += d[i].w;
@@ -358,14 +382,40 @@ __global__ __launch_bounds__(256) void embed_text_bwd_kernel(const long* __restr
     part[((long)blockIdx.x * 3 + k) * H + c] = red[k][0][c] + red[k][1][c] + red[k][2][c] + red[k][3][c];
   }
 }
-// part: ceil(B*T/32)*3*H floats
+// dpos[t,:] += sum_b dpre[b,t,:];  dtype[k,:] += sum_{(b,t): tt==k} dpre[b,t,:]  (k < 2).  One thread per (t, 4 columns).
+__global__ void embed_text_bwd_tables_kernel(const float* __restrict__ dpre, const long* __restrict__ tts, float* dpos, float* dtype_, int B, int T,
+                                             int H, float* __restrict__ part) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int per_row = H / 4;
+  if (i >= T * per_row) return;
+  const int t = i / per_row, c = (i - t * per_row) * 4;
+  float4 tot = make_float4(0.f, 0.f, 0.f, 0.f), t1 = tot;
+  for (int b = 0; b < B; ++b) {
+    float4 v = ld4(dpre + ((long)b * T + t) * H + c);
+    tot.x += v.x; tot.y += v.y; tot.z += v.z; tot.w += v.w;
+    if (tts[b * T + t] != 0) { t1.x += v.x; t1.y += v.y; t1.z += v.z; t1.w += v.w; }
+  }
+  if (dpos) {
+    float4 o = ld4(dpos + (long)t * H + c);
+    st4(dpos + (long)t * H + c, make_float4(o.x + tot.x, o.y + tot.y, o.z + tot.z, o.w + tot.w));
+  }
+  // per-t partials of the two token-type rows: part[t][0][:] (type 0), part[t][1][:] (type 1)
+  st4(part + ((long)t * 2 + 0) * H + c, make_float4(tot.x - t1.x, tot.y - t1.y, tot.z - t1.z, tot.w - t1.w));
+  st4(part + ((long)t * 2 + 1) * H + c, t1);
+}
+// part: ceil(B*T/32)*3*H floats; dpre: B*T*H floats; part2: T*2*H floats (token-type partials, reduce with stride 2H over T)
 extern "C" int climb_embed_text_bwd(const long* ids, const long* tts, const float* word, const float* type, const float* pos,
                                     const float* gamma, const float* mean, const float* rstd, const float* dres, int B, int T, int S_pad, int H,
-                                    float* dword, float* dtype_, float* dpos, float* part, void* stream) {
+                                    float* dword, float* dpos, float* dpre, float* part, float* part2, void* stream) {
   if (H != 768) return CLIMB_EUNSUPPORTED;
   hipLaunchKernelGGL(embed_text_bwd_kernel, dim3((B * T + 31) / 32), dim3(256), 0, (hipStream_t)stream, ids, tts, word, type, pos, gamma, mean,
-                     rstd, dres, B, T, S_pad, H, dword, dtype_, dpos, part);
+                     rstd, dres, B, T, S_pad, H, dword, dpre, part);
   LAUNCH_CHECK();
+  if (dpre) {
+    int n = T * (H / 4);
+    hipLaunchKernelGGL(embed_text_bwd_tables_kernel, dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, dpre, tts, dpos, (float*)nullptr, B, T, H, part2);
+    LAUNCH_CHECK();
+  }
   return CLIMB_OK;
 }
 
@@ -506,14 +556,14 @@ extern "C" int climb_elementwise(int op, const float* a, const float* b, float* 
 // ------------------------------------------------------------------------------------------------
 // Losses, fused with their gradient.
 // VQA (REF/train/visionlanguage_tasks/train_vqa.py:95,:157): BCEWithLogits(mean) * N  ==  sum_{b,n} bce / B.
-//   dlogits = gscale * (sigmoid(x) - t) / B.   Single block => deterministic reduction.
-__global__ __launch_bounds__(1024) void bce_logits_kernel(const float* __restrict__ logits, long ldl, const float* __restrict__ target, long ldt,
-                                                          float* __restrict__ dlogits, long ldd, float* __restrict__ loss, int B, int N,
-                                                          float gscale) {
-  __shared__ float red[16];
+//   dlogits = gscale * (sigmoid(x) - t) / B.
+#define BCE_BLOCKS 128
+__global__ __launch_bounds__(256) void bce_logits_kernel(const float* __restrict__ logits, long ldl, const float* __restrict__ target, long ldt,
+                                                         float* __restrict__ dlogits, long ldd, float* __restrict__ partials, int B, int N, float gscale) {
+  __shared__ float red[4];
   float acc = 0.f;
   const float invB = 1.f / (float)B;
-  for (long i = threadIdx.x; i < (long)B * N; i += 1024) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < (long)B * N; i += (long)gridDim.x * 256) {
     int b = (int)(i / N), n = (int)(i - (long)b * N);
     float x = logits[b * ldl + n], t = target[b * ldt + n];
     acc += fmaxf(x, 0.f) - x * t + log1pf(__expf(-fabsf(x)));
@@ -522,15 +572,24 @@ __global__ __launch_bounds__(1024) void bce_logits_kernel(const float* __restric
   acc = wave_sum(acc);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    float s = 0.f;
-    for (int i = 0; i < 16; ++i) s += red[i];
-    *loss = s * invB;
-  }
+  if (threadIdx.x == 0) partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
-extern "C" int climb_bce_logits(const float* logits, long ldl, const float* target, long ldt, float* dlogits, long ldd, float* loss, int B, int N,
-                                float gscale, void* stream) {
-  hipLaunchKernelGGL(bce_logits_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, logits, ldl, target, ldt, dlogits, ldd, loss, B, N, gscale);
+__global__ __launch_bounds__(128) void bce_finish_kernel(const float* __restrict__ partials, int n, float scale, float* __restrict__ loss) {
+  __shared__ float red[2];
+  float acc = threadIdx.x < n ? partials[threadIdx.x] : 0.f;
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) *loss = (red[0] + red[1]) * scale;
+}
+extern "C" int climb_bce_workspace_floats() { return BCE_BLOCKS; }
+// partials: BCE_BLOCKS floats of scratch (fixed block count + fixed summation order => deterministic)
+extern "C" int climb_bce_logits(const float* logits, long ldl, const float* target, long ldt, float* dlogits, long ldd, float* loss, float* partials,
+                                int B, int N, float gscale, void* stream) {
+  if (B <= 0 || N <= 0 || !partials) return CLIMB_EINVAL;
+  hipLaunchKernelGGL(bce_logits_kernel, dim3(BCE_BLOCKS), dim3(256), 0, (hipStream_t)stream, logits, ldl, target, ldt, dlogits, ldd, partials, B, N, gscale);
+  LAUNCH_CHECK();
+  hipLaunchKernelGGL(bce_finish_kernel, dim3(1), dim3(128), 0, (hipStream_t)stream, partials, BCE_BLOCKS, 1.f / (float)B, loss);
   LAUNCH_CHECK();
   return CLIMB_OK;
 }

@@ -84,6 +84,8 @@ class Workspace:
         npart = max(((M + lnb - 1) // lnb) * 3 * H, ((M + csr - 1) // csr) * max(Fd, 3 * H),
                     (self.NP + 1) * 3 * H, ((B * T + 31) // 32) * 3 * H)
         self.part = buf((npart,))
+        self.dpre = buf((B * T, H))
+        self.part2 = buf((T * 2 * H,))
         self.ones = torch.ones((max(B, 8),), dtype=f32, device=dev)
 
 
@@ -108,6 +110,7 @@ class ViltEngine:
         self._shadow_version = -1
         self._shadow_stale = False
         self._ewc_ws = None
+        self._bce_ws = None
         self.requires_grad: Dict[str, bool] = {n: True for n in layout.shapes}
         self.grad_ready_hook: Optional[Callable[[int, int], None]] = None   # (lo, hi) flat range whose grads are final
         self.touched: List[tuple] = []                  # flat ranges that received gradients in the last backward
@@ -199,6 +202,12 @@ class ViltEngine:
             self._gemm_f32(dY, 1, N, X, 1, K, self.g(wname), K, N, K, M, beta=1.0)
         else:
             self._bf16_dw(dY, X, wname, M, N, K)
+
+    def reduce3(self, part, nblk, ncols, n0, n1, n2):
+        """{dgamma, dbeta, colsum} partials -> three parameter gradients, one launch (names may be None / frozen)."""
+        rg = self.requires_grad
+        ptrs = [self.g(n) if (n is not None and rg[n]) else None for n in (n0, n1, n2)]
+        _lib.call("climb_colreduce3", part, 3 * ncols, nblk, ptrs[0], ptrs[1], ptrs[2], ncols, 1.0, _stream())
 
     def bias_grad_from_part(self, part_ptr, stride, nblk, bname, ncols):
         if bname is not None and self.requires_grad[bname]:
@@ -411,9 +420,7 @@ class ViltEngine:
         xL = ws.x[cfg["layers"]]
         _lib.call("climb_layernorm_bwd", ws.dclsn, H, F32, xL, ws.S_pad * H, ws.fmean, ws.frstd, self.p(ENC + "layernorm.weight"), None, 0,
                   ws.dres, ws.S_pad * H, None, 0, ws.part, B, H, st)
-        nb = (B + lnb - 1) // lnb
-        self.bias_grad_from_part(ws.part.data_ptr(), 3 * H, nb, ENC + "layernorm.weight", H)
-        self.bias_grad_from_part(ws.part.data_ptr() + 4 * H, 3 * H, nb, ENC + "layernorm.bias", H)
+        self.reduce3(ws.part, (B + lnb - 1) // lnb, H, ENC + "layernorm.weight", ENC + "layernorm.bias", None)
         self._ready(*lay.top_range)
         # d(x_L): cast for the GEMMs (bf16 mode) + column sums for the last layer's output bias
         csr = _lib.query("climb_colsum_rows_per_block")
@@ -431,9 +438,7 @@ class ViltEngine:
             self.linear_dx(ws.du, l + "intermediate.dense.weight", ws.dhn, M, Fd, H)
             _lib.call("climb_layernorm_bwd", ws.dhn, H, adt, ws.h1[i], H, ws.mean2[i], ws.rstd2[i], self.p(l + "layernorm_after.weight"),
                       ws.dres, H, ws.dres, H, None if self.precision == "fp32" else ws.dres_c, H, ws.part, M, H, st)
-            self.bias_grad_from_part(ws.part.data_ptr(), 3 * H, nlnb, l + "layernorm_after.weight", H)
-            self.bias_grad_from_part(ws.part.data_ptr() + 4 * H, 3 * H, nlnb, l + "layernorm_after.bias", H)
-            self.bias_grad_from_part(ws.part.data_ptr() + 8 * H, 3 * H, nlnb, l + "attention.output.dense.bias", H)
+            self.reduce3(ws.part, nlnb, H, l + "layernorm_after.weight", l + "layernorm_after.bias", l + "attention.output.dense.bias")
             # attention: h1 = x + Wo ctx + bo
             self.linear_dw(ws.dres_c, ws.ctx[i], l + "attention.output.dense.weight", M, H, H)
             self.linear_dx(ws.dres_c, l + "attention.output.dense.weight", ws.dctx, M, H, H)
@@ -447,10 +452,8 @@ class ViltEngine:
                 self.linear_dx(ws.dqkv, l + "attention.attention.query.weight", ws.dxn, M, 3 * H, H)
                 _lib.call("climb_layernorm_bwd", ws.dxn, H, adt, ws.x[i], H, ws.mean1[i], ws.rstd1[i], self.p(l + "layernorm_before.weight"),
                           ws.dres, H, ws.dres, H, None if self.precision == "fp32" else ws.dres_c, H, ws.part, M, H, st)
-                self.bias_grad_from_part(ws.part.data_ptr(), 3 * H, nlnb, l + "layernorm_before.weight", H)
-                self.bias_grad_from_part(ws.part.data_ptr() + 4 * H, 3 * H, nlnb, l + "layernorm_before.bias", H)
-                if i > first_layer:
-                    self.bias_grad_from_part(ws.part.data_ptr() + 8 * H, 3 * H, nlnb, f"{ENC}encoder.layer.{i - 1}.output.dense.bias", H)
+                self.reduce3(ws.part, nlnb, H, l + "layernorm_before.weight", l + "layernorm_before.bias",
+                             f"{ENC}encoder.layer.{i - 1}.output.dense.bias" if i > first_layer else None)
             self._ready(*lay.layer_range[i])
         if embeddings and first_layer == 0:
             self.embedding_backward(ws, sv)
@@ -475,13 +478,13 @@ class ViltEngine:
                   self.p(te + "token_type_embeddings.weight"), self.p(te + "position_embeddings.weight"), self.p(te + "LayerNorm.weight"),
                   ws.tmean, ws.trstd, ws.dres, B, T, ws.S_pad, H,
                   self.g(te + "word_embeddings.weight") if rg[te + "word_embeddings.weight"] else None,
-                  self.g(te + "token_type_embeddings.weight") if rg[te + "token_type_embeddings.weight"] else None,
-                  self.g(te + "position_embeddings.weight") if rg[te + "position_embeddings.weight"] else None, ws.part, st)
+                  self.g(te + "position_embeddings.weight") if rg[te + "position_embeddings.weight"] else None,
+                  ws.dpre, ws.part, ws.part2, st)
         nb = (B * T + 31) // 32
-        self.bias_grad_from_part(ws.part.data_ptr(), 3 * H, nb, te + "LayerNorm.weight", H)
-        self.bias_grad_from_part(ws.part.data_ptr() + 4 * H, 3 * H, nb, te + "LayerNorm.bias", H)
-        if rg[e + "token_type_embeddings.weight"]:   # row 0 of the modality table (text rows)
-            _lib.call("climb_colreduce", ws.part.data_ptr() + 8 * H, 3 * H, nb, self.g(e + "token_type_embeddings.weight"), H, 1.0, st)
+        # [dgamma | dbeta | dmodality row 0 (text rows)] in one launch; the modality table starts with row 0
+        self.reduce3(ws.part, nb, H, te + "LayerNorm.weight", te + "LayerNorm.bias", e + "token_type_embeddings.weight")
+        if rg[te + "token_type_embeddings.weight"]:
+            _lib.call("climb_colreduce", ws.part2, 2 * H, T, self.g(te + "token_type_embeddings.weight"), 2 * H, 1.0, st)
 
     # ------------------------------------------------------------------ task heads (fp32; REF/modeling/vilt.py:179-203)
     def head_forward(self, task_key: str, pooled_in: torch.Tensor, training: bool, keep_mask: Optional[torch.Tensor] = None):
@@ -500,12 +503,13 @@ class ViltEngine:
             hs.gz = torch.empty_like(hs.z)
             hs.mean = torch.empty((Bh,), dtype=torch.float32, device=dev)
             hs.rstd = torch.empty_like(hs.mean)
-            hs.logits = torch.empty((Bh, NL), dtype=torch.float32, device=dev)
+            ldl = _round_up(NL, 4)          # 16-byte aligned rows so the head GEMMs take the vector load paths (3129 -> 3132)
+            hs.logits = torch.zeros((Bh, ldl), dtype=torch.float32, device=dev)[:, :NL]
             self._gemm_f32(pooled_in, Kin, 1, self.p(h + "0.weight"), Kin, 1, hs.z, D, Bh, D, Kin, self.p(h + "0.bias"))
             _lib.call("climb_layernorm_fwd", hs.z, D, self.p(h + "1.weight"), self.p(h + "1.bias"), self.cfg["head_ln_eps"], hs.zn, D, F32,
                       hs.mean, hs.rstd, Bh, D, st)
             _lib.call("climb_elementwise", 0, hs.zn, None, hs.gz, Bh * D, 1.0, st)
-            self._gemm_f32(hs.gz, D, 1, self.p(h + "3.weight"), D, 1, hs.logits, NL, Bh, NL, D, self.p(h + "3.bias"))
+            self._gemm_f32(hs.gz, D, 1, self.p(h + "3.weight"), D, 1, hs.logits, ldl, Bh, NL, D, self.p(h + "3.bias"))
             return hs.logits, hs
         # multi-choice: Dropout(0.1) -> Linear(768, 1) -> squeeze        pooled_in [b, nc, H]
         b, nc, _ = pooled_in.shape
@@ -579,10 +583,13 @@ class ViltEngine:
         """VQA: BCEWithLogits(mean)*num_labels (REF train_vqa.py:155-157); others: CrossEntropyLoss (train_nlvr2.py:80)."""
         st = _stream()
         loss = torch.empty((), dtype=torch.float32, device=self.device)
-        dlogits = torch.empty_like(logits)
         Bh, NL = logits.shape
+        dlogits = torch.zeros((Bh, logits.stride(0)), dtype=torch.float32, device=self.device)[:, :NL]      # same padded rows as logits
         if task_key == "vqa":
-            _lib.call("climb_bce_logits", logits, logits.stride(0), target, target.stride(0), dlogits, dlogits.stride(0), loss, Bh, NL, gscale, st)
+            if self._bce_ws is None:
+                self._bce_ws = torch.empty((_lib.query("climb_bce_workspace_floats"),), dtype=torch.float32, device=self.device)
+            _lib.call("climb_bce_logits", logits, logits.stride(0), target, target.stride(0), dlogits, dlogits.stride(0), loss, self._bce_ws, Bh, NL,
+                      gscale, st)
         else:
             _lib.call("climb_cross_entropy", logits, logits.stride(0), target, dlogits, dlogits.stride(0), loss, Bh, NL, gscale, st)
         return loss, dlogits

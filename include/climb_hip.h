@@ -31,8 +31,9 @@ int climb_device_sync(void);
 /* HF:237-269 TextEmbeddings.forward + HF:208-210: x[b,t,:] = LN(word[ids]+type[tt]+pos[t])*gamma+beta + modality[0].
  * ids/tts are int64 [B,T]; mean/rstd [B*T] are saved for the backward. */
 int climb_embed_text_fwd(const long* ids, const long* tts, const float* word, const float* type, const float* pos, const float* gamma, const float* beta, const float* mod0, float eps, float* x, int B, int T, int S_pad, int H, float* mean, float* rstd, void* stream);
-/* backward of the above: atomically scatter-adds into dword/dtype/dpos; part[ceil(B*T/32)][3][H] = {dgamma, dbeta, dmodality0} partials */
-int climb_embed_text_bwd(const long* ids, const long* tts, const float* word, const float* type, const float* pos, const float* gamma, const float* mean, const float* rstd, const float* dres, int B, int T, int S_pad, int H, float* dword, float* dtype_, float* dpos, float* part, void* stream);
+/* backward of the above: scatter-adds into dword (atomics), dpos += sum over the batch; part[ceil(B*T/32)][3][H] = {dgamma, dbeta,
+ * dmodality0} partials; part2[T][2][H] = token-type partials (reduce over T with stride 2H); dpre [B*T,H] scratch */
+int climb_embed_text_bwd(const long* ids, const long* tts, const float* word, const float* type, const float* pos, const float* gamma, const float* mean, const float* rstd, const float* dres, int B, int T, int S_pad, int H, float* dword, float* dpos, float* dpre, float* part, float* part2, void* stream);
 /* HF:292-300 Conv2d(3,768,k=32,s=32) as a GEMM: out[(b*NP + py*gw + px), c*P*P + ky*P + kx] = pixels[b,c,py*P+ky,px*P+kx] */
 int climb_im2col(const float* pixels, void* out, int out_dtype, int B, int C, int H, int W, int P, void* stream);
 /* HF:168-173, :211-216: image rows of the embedding = proj/cls + position + modality[img_type[b]]; padding rows zeroed */
@@ -50,6 +51,8 @@ int climb_layernorm_bwd(const void* dy, long lddy, int dtype, const float* x, lo
 int climb_layernorm_bwd_rows_per_block(void);
 /* out[c] = beta*out[c] + sum_b part[b*stride + c]  (deterministic second stage of every column reduction) */
 int climb_colreduce(const float* part, long stride, int nblk, float* out, int ncols, float beta, void* stream);
+/* the {dgamma, dbeta, colsum} triple in ONE launch: out_k[c] = beta*out_k[c] + sum_b part[b*stride + k*ncols + c]; NULL outputs skipped */
+int climb_colreduce3(const float* part, long stride, int nblk, float* out0, float* out1, float* out2, int ncols, float beta, void* stream);
 /* bias gradients: part[ceil(M/64)][C] column sums of x (optionally also writes a bf16 cast of an fp32 x) */
 int climb_colsum(const void* x, long ldx, int in_dtype, void* cast_bf16, long ldc, float* part, int M, int C, void* stream);
 int climb_colsum_rows_per_block(void);
@@ -72,7 +75,8 @@ int climb_attn_bwd_f32(const float* qkv, const float* key_bias, const float* dct
 /* op: 0 gelu(a) | 1 a*gelu'(b) | 2 a*(1-b^2) (tanh bwd) | 3 a*b*s (dropout) | 4 a*s | 5 a+b */
 int climb_elementwise(int op, const float* a, const float* b, float* out, long n, float s, void* stream);
 /* REF/train/visionlanguage_tasks/train_vqa.py:95,:157: loss = BCEWithLogits(mean)*N; dlogits = gscale*(sigmoid(x)-t)/B */
-int climb_bce_logits(const float* logits, long ldl, const float* target, long ldt, float* dlogits, long ldd, float* loss, int B, int N, float gscale, void* stream);
+int climb_bce_logits(const float* logits, long ldl, const float* target, long ldt, float* dlogits, long ldd, float* loss, float* partials, int B, int N, float gscale, void* stream);
+int climb_bce_workspace_floats(void);
 /* REF/train/visionlanguage_tasks/train_nlvr2.py:80 nn.CrossEntropyLoss(); labels int64 */
 int climb_cross_entropy(const float* logits, long ldl, const long* labels, float* dlogits, long ldd, float* loss, int B, int N, float gscale, void* stream);
 

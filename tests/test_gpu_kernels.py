@@ -118,6 +118,9 @@ def test_layernorm_fwd_bwd(C, dt):
     assert _rel(out[:C], gr.grad) < 5e-6
     assert _rel(out[C:2 * C], br.grad) < 5e-6
     assert _rel(out[2 * C:], (dres.double() + xr.grad).sum(0)) < 5e-6
+    o0, o2 = torch.ones(C, device=dev), torch.ones(C, device=dev)           # fused triple, accumulating, middle output skipped
+    _lib.call("climb_colreduce3", part, 3 * C, nb, o0, None, o2, C, 1.0, _st())
+    assert _rel(o0, 1 + gr.grad) < 5e-6 and _rel(o2, 1 + (dres.double() + xr.grad).sum(0)) < 5e-6
 
 
 def _attn_ref(qkv, bias, heads):
@@ -175,7 +178,8 @@ def test_losses():
     ref.backward()
     loss = torch.empty((), device=dev)
     dl = torch.empty(B, N, device=dev)
-    _lib.call("climb_bce_logits", x.to(dev), N, t.to(dev), N, dl, N, loss, B, N, 1.0, _st())
+    ws = torch.empty(_lib.query("climb_bce_workspace_floats"), device=dev)
+    _lib.call("climb_bce_logits", x.to(dev), N, t.to(dev), N, dl, N, loss, ws, B, N, 1.0, _st())
     assert abs(loss.item() - ref.item()) < 2e-6 * abs(ref.item())
     assert _rel(dl, xr.grad) < 2e-6
     for n in (2, 3, 4):

@@ -1,0 +1,187 @@
+"""CPU tests of the host side: C-ABI library loads and exports every symbol of include/climb_hip.h, flat layout
+invariants, reference-compatible names/grouping, and the plugin / trainer host logic (no device compute)."""
+import ctypes
+import os
+import random
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import vilt_oracle as vo
+
+
+def test_abi_library_exports_every_header_symbol():
+    from climb_amd import _lib
+    from climb_amd.build import build_library
+    lib = build_library(verbose=False)
+    so = ctypes.CDLL(lib)
+    protos = _lib.parse_header()
+    assert len(protos) >= 30
+    missing = [n for n in protos if not hasattr(so, n)]
+    assert not missing, missing
+    _lib.load()
+    assert _lib.query("climb_version") >= 100
+    assert _lib.load().climb_arch() == b"gfx950"
+    assert _lib.error_string(-1).startswith("climb")
+    # exported but undeclared entry points would be an undocumented ABI
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", lib], capture_output=True, text=True).stdout
+    exported = {l.split()[-1] for l in out.splitlines() if " T climb_" in l}
+    assert exported == set(protos), exported ^ set(protos)
+
+
+def test_engine_refuses_cpu():
+    from climb_amd.engine import ViltEngine
+    from climb_amd.layout import FlatLayout, TASK_ARITH
+    eng = ViltEngine(FlatLayout(["vqa"], TASK_ARITH), torch.device("cpu"), "fp32")
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        eng.allocate()
+
+
+def test_flat_layout_invariants():
+    from climb_amd.layout import FlatLayout, TASK_ARITH, ENC, ALIGN
+    lay = FlatLayout(["vqa", "nlvr2"], TASK_ARITH)
+    assert list(lay.shapes.keys()) == list(vo.param_shapes(["vqa", "nlvr2"]).keys())
+    assert all(tuple(lay.shapes[n]) == tuple(s) for n, s in vo.param_shapes(["vqa", "nlvr2"]).items())
+    assert all(o % ALIGN == 0 for o in lay.offset.values())
+    segs = lay.segments()
+    assert all(a[1] + a[2] == b[1] for a, b in zip(segs, segs[1:])) and segs[-1][1] + segs[-1][2] == lay.total
+    assert all(lay.numel(n) <= ln for n, _, ln in segs)
+    H = 768
+    for i in range(12):
+        l = f"{ENC}encoder.layer.{i}.attention.attention."
+        assert lay.offset[l + "key.weight"] == lay.offset[l + "query.weight"] + H * H      # fused [2304,768] QKV is a view
+        assert lay.offset[l + "value.weight"] == lay.offset[l + "key.weight"] + H * H
+        assert lay.offset[l + "key.bias"] == lay.offset[l + "query.bias"] + H
+        lo, hi = lay.layer_range[i]
+        assert all(lo <= lay.offset[n] < hi for n in lay.shapes if f".layer.{i}." in n)
+    enc_names = [n for n in lay.shapes if n.startswith(ENC)]
+    assert max(lay.offset[n] for n in enc_names) < lay.encoder_end <= min(lay.offset[n] for n in lay.shapes if not n.startswith(ENC))
+    assert lay.embed_range[1] == lay.layer_range[0][0] and lay.layer_range[-1][1] == lay.top_range[0]
+    assert FlatLayout(["vqa"], TASK_ARITH).shapes[ENC + "embeddings.token_type_embeddings.weight"] == (2, H)
+    assert lay.shapes[ENC + "embeddings.token_type_embeddings.weight"] == (3, H)
+
+
+def test_decay_grouping_matches_reference_quirk():
+    from climb_amd.layout import no_decay
+    for n in vo.param_shapes(["vqa", "nlvr2", "snli-ve", "vcr"]):
+        assert no_decay(n) == vo.no_decay(n)
+
+
+def test_schedule_matches_transformers():
+    from transformers import get_polynomial_decay_schedule_with_warmup
+    from climb_amd.train import polynomial_decay_schedule_with_warmup
+    p1, p2 = torch.nn.Parameter(torch.zeros(1)), torch.nn.Parameter(torch.zeros(1))
+    o1, o2 = torch.optim.AdamW([p1], lr=1e-4), torch.optim.AdamW([p2], lr=1e-4)
+    s1 = get_polynomial_decay_schedule_with_warmup(o1, num_warmup_steps=3, num_training_steps=30, lr_end=0, power=1)
+    s2 = polynomial_decay_schedule_with_warmup(o2, 3, 30, 0.0, 1.0)
+    for _ in range(33):
+        assert abs(o1.param_groups[0]["lr"] - o2.param_groups[0]["lr"]) < 1e-15
+        o1.step(); o2.step(); s1.step(); s2.step()
+
+
+def _cpu_model(tasks):
+    from climb_amd.modeling import create_continual_learner_map
+    from climb_amd.configs.task_configs import task_configs
+    from climb_amd.configs.model_configs import model_configs
+    return create_continual_learner_map["vilt"](model_name_or_path="random-init:0", ordered_cl_tasks=tasks, model_config=model_configs["vilt"],
+                                                task_configs=task_configs, device=torch.device("cpu"), precision="fp32")
+
+
+def test_model_surface_on_cpu_and_loud_failure():
+    model = _cpu_model(["vqa", "nlvr2"])
+    P = vo.init_params(["vqa", "nlvr2"], 42)
+    assert [n for n, _ in model.named_parameters()] == list(P.keys())
+    model.load_state_dict(P)
+    assert list(model.get_encoder().state_dict().keys()) == [k[len("vilt_encoder."):] for k in P if k.startswith(vo.ENC)]
+    assert model.get_encoder().vilt.embeddings.token_type_embeddings.weight.shape[0] == 3      # nlvr2 => third modality row
+    opt_groups = [
+        {n for n, p in model.named_parameters() if not vo.no_decay(n)},
+        {n for n, p in model.named_parameters() if vo.no_decay(n)},
+    ]
+    assert len(opt_groups[0]) + len(opt_groups[1]) == len(P)
+    enc = vo.synthetic_encodings(2, seed=1)
+    texts = dict(input_ids=enc["input_ids"], token_type_ids=enc["token_type_ids"], attention_mask=enc["attention_mask"])
+    with pytest.raises(RuntimeError, match="no CPU path"):          # the product path never silently falls back to CPU
+        model(task_key="vqa", images=enc["pixel_values"], texts=texts)
+    model.get_encoder().freeze_bottom_k_layers(9)
+    assert model._host.frozen_prefix() == (9, False)
+    model.get_encoder().freeze_all_weights()
+    assert model._host.any_encoder_grad() is None
+
+
+def test_multi_image_and_multi_choice_batching():
+    """One encoder call of b*n sequences: row order and image_token_type_idx must reproduce the reference's per-pass loop
+    (REF/modeling/vilt.py:281-304 and :331-347)."""
+    model = _cpu_model(["nlvr2", "vcr"])
+    b = 3
+    e = vo.synthetic_encodings(2 * b, seed=3)
+    enc = dict(input_ids=e["input_ids"][:b], token_type_ids=e["token_type_ids"][:b], attention_mask=e["attention_mask"][:b],
+               pixel_values=e["pixel_values"], pixel_mask=e["pixel_mask"])
+    out, kind = model._expand("nlvr2", enc)
+    assert kind == ("images", 2)
+    assert out["input_ids"].shape[0] == 2 * b and torch.equal(out["input_ids"][0], out["input_ids"][1]) and torch.equal(out["input_ids"][2], enc["input_ids"][1])
+    assert out["image_token_type_idx"].tolist() == [1, 2, 1, 2, 1, 2]
+    pooled = torch.arange(2 * b * 4, dtype=torch.float32).view(2 * b, 4)
+    shaped = model._shape_pooled(pooled, kind)
+    assert torch.equal(shaped, torch.cat([pooled[0::2], pooled[1::2]], dim=-1))
+    e = vo.synthetic_encodings(4 * b, seed=4)
+    enc = dict(input_ids=e["input_ids"], token_type_ids=e["token_type_ids"], attention_mask=e["attention_mask"],
+               pixel_values=e["pixel_values"][:b], pixel_mask=e["pixel_mask"][:b])
+    out, kind = model._expand("vcr", enc)
+    assert kind == ("choice", 4) and out["pixel_values"].shape[0] == 4 * b
+    assert torch.equal(out["pixel_values"][5], enc["pixel_values"][1])
+    shaped = model._shape_pooled(torch.arange(4 * b * 2, dtype=torch.float32).view(4 * b, 2), kind)
+    assert shaped.shape == (b, 4, 2) and shaped[1, 2, 0] == (4 * 1 + 2) * 2
+
+
+def test_replay_memory_host_logic():
+    from climb_amd.cl_algorithms import ExperienceReplayMemory
+    from climb_amd.configs.task_configs import task_configs
+    calls = {}
+
+    class FakeTrainer:
+        hparams = {"lr": 1e-4, "weight_decay": 1e-2, "adam_epsilon": 1e-8}
+
+        def __init__(self):
+            self.loader = types.SimpleNamespace(dataset=list(range(1000)), collate_fn=lambda items: {"items": items})
+
+        def get_train_dataloader(self):
+            return self.loader
+
+        def get_collate_fn(self):
+            return self.loader.collate_fn
+
+        def train_step(self, model, batch, optimizer=None, scheduler=None, ewc=None):
+            calls["batch"], calls["opt"], calls["sched"] = batch, optimizer, scheduler
+            return torch.tensor(1.5), None, None, None
+
+    class FakeModel:
+        def create_optimizer(self, hp):
+            calls["hp"] = hp
+            return "fresh-optimizer"
+    random.seed(0)
+    mem = ExperienceReplayMemory()
+    assert not mem.do_replay()
+    for key, bs in (("vqa", 64), ("nlvr2", 32), ("vcr", 16)):
+        mem.add_task_memory_buffer(args=types.SimpleNamespace(batch_size=64), task_key=key, task_config=task_configs[key], task_trainer=FakeTrainer(),
+                                   memory_percentage=0.01, sampling_strategy="random")
+        assert len(mem.memory_buffers[key]) == 10 and mem.memory_buffers[key].batch_size == bs      # REF experience_replay.py:93-98
+    assert mem.do_replay() and mem.sample_replay_task() in ("vqa", "nlvr2", "vcr")
+    mem.memory_buffers["vqa"].batch_size = 4
+    loss = mem.run_replay_step("vqa", FakeModel())
+    assert float(loss) == 1.5 and calls["opt"] == "fresh-optimizer" and calls["sched"] is None and calls["hp"]["lr"] == 1e-4
+    assert len(calls["batch"]["items"]) == 4 and set(calls["batch"]["items"]) <= set(mem.memory_buffers["vqa"].memory_idxs)
+    with pytest.raises(AssertionError):
+        mem.add_task_memory_buffer(args=types.SimpleNamespace(batch_size=64), task_key="snli-ve", task_config=task_configs["snli-ve"],
+                                   task_trainer=FakeTrainer(), memory_percentage=0.01, sampling_strategy="random-balanced")
+
+
+def test_task_configs_carry_reference_hyperparameters():
+    from climb_amd.configs.task_configs import task_configs
+    for k, lr, ep in (("vqa", 1e-4, 10), ("nlvr2", 1e-4, 10), ("snli-ve", 5e-5, 5), ("vcr", 1e-4, 10)):
+        c = task_configs[k]
+        assert (c["lr"], c["num_epochs"], c["weight_decay"], c["adam_epsilon"]) == (lr, ep, 1e-2, 1e-8)
+        assert c["num_labels"] == vo.TASKS[k]["num_labels"] and c["model_type"] == vo.TASKS[k]["model_type"]
