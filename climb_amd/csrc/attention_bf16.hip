@@ -58,8 +58,7 @@ __device__ __forceinline__ bf16x8 col_frag(const unsigned char* __restrict__ S, 
 __device__ __forceinline__ bf16x8 pack8(const f32x16& v, int s) {
   union { unsigned int u[4]; bf16x8 b; } c;
 #pragma unroll
-  for (int j = 0; j < 4; ++j)
-    c.u[j] = (unsigned int)f32_to_bf16(v[8 * s + 2 * j]) | ((unsigned int)f32_to_bf16(v[8 * s + 2 * j + 1]) << 16);
+  for (int j = 0; j < 4; ++j) c.u[j] = pack_bf16x2(v[8 * s + 2 * j], v[8 * s + 2 * j + 1]);
   return c.b;
 }
 // this lane's B operand for a 32-row register block: row (row0 + lane&31) of a global [.,64] bf16 matrix, 4 k-steps

@@ -24,11 +24,17 @@ typedef __attribute__((ext_vector_type(8))) short s16x8;
   } while (0)
 
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
-__device__ __forceinline__ bf16_t f32_to_bf16(float f) {  // round-to-nearest-even, NaN preserved
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
+// fp32 -> bf16, round-to-nearest-even: the casts lower to the gfx950 hardware converter v_cvt_pk_bf16_f32
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+  __bf16 h = (__bf16)f;
+  return __builtin_bit_cast(bf16_t, h);
+}
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  f32x2_t v = {lo, hi};
+  bf16x2_t h = __builtin_convertvector(v, bf16x2_t);
+  return __builtin_bit_cast(uint32_t, h);
 }
 
 template <typename T> struct Act;
@@ -51,8 +57,8 @@ __device__ __forceinline__ float4 ld4(const bf16_t* p) {
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 __device__ __forceinline__ void st4(bf16_t* p, float4 v) {
   uint2 r;
-  r.x = (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16);
-  r.y = (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16);
+  r.x = pack_bf16x2(v.x, v.y);
+  r.y = pack_bf16x2(v.z, v.w);
   *reinterpret_cast<uint2*>(p) = r;
 }
 
@@ -74,6 +80,20 @@ __device__ __forceinline__ float dgelu_f(float x) {
   float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
   return cdf + x * pdf;
 }
+
+// Fast GELU pair for the bf16 epilogues: erf by Abramowitz-Stegun 7.1.26 (|error| < 1.5e-7, far below bf16 resolution),
+// ONE v_exp shared between erf(x/sqrt2) and the Gaussian of gelu'.  The fp32 path keeps erff().
+__device__ __forceinline__ void gelu_parts(float x, float& cdf, float& pdf) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __frcp_rn(1.0f + 0.3275911f * z);
+  const float e = __expf(-z * z);                                    // = exp(-x^2/2)
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float erf_abs = 1.0f - poly * e;
+  cdf = 0.5f * (1.0f + copysignf(erf_abs, x));
+  pdf = 0.39894228040143267794f * e;
+}
+__device__ __forceinline__ float gelu_fast(float x) { float c, p; gelu_parts(x, c, p); return x * c; }
+__device__ __forceinline__ float dgelu_fast(float x) { float c, p; gelu_parts(x, c, p); return c + x * p; }
 
 // epilogue codes shared by the f32 and bf16 GEMMs
 #define EPI_NONE 0    // C = acc + bias

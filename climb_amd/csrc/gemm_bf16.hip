@@ -12,10 +12,12 @@
 // LDS images:
 //   NT: [128 rows][64 k] bf16, 128-B rows, 16-B chunks XOR-swizzled by swz(row) so that the ds_read_b128 fragment reads
 //       (16-lane groups = 16 different rows, same k-chunk) hit 16 distinct 4-bank groups: conflict-free.
-//   TN: [64 m][128 cols] bf16 with a 320-B row pitch; fragments are gathered with ds_read_b64_tr_b16 (the gfx950 LDS
-//       transpose read: a 16-lane group loads a [4 m][16 col] block and each lane receives one column = 4 consecutive
-//       reduction indices), two reads per 8-element operand.  Pitch 320 B puts 4 consecutive m-rows in 4 different
-//       bank quarters: conflict-free.
+//   TN: [64 m][128 cols] bf16, 256-B rows, 16-B chunks XOR-swizzled by (row & 3) << 2; fragments are gathered with
+//       ds_read_b64_tr_b16 (the gfx950 LDS transpose read: a 16-lane group loads a [4 m][16 col] block and each lane
+//       receives one column = 4 consecutive reduction indices), two reads per 8-element operand.  The swizzle puts 4
+//       consecutive m-rows in 4 different bank quarters: conflict-free.
+// Staging is LDS-DMA (global_load_lds_dwordx4, swizzle applied to the per-lane SOURCE address) whenever the shape allows;
+// a register-staged variant of each kernel handles ragged K / ragged reduction tails.
 #include "common.h"
 
 #define GB_BM 128
@@ -57,21 +59,49 @@ __device__ __forceinline__ void nt_store(const u32x4 (&r)[4], unsigned char* __r
   }
 }
 
-template <typename TO, int EPI>
+// LDS-DMA staging (global_load_lds_dwordx4): no VGPR round trip and no ds_write pass -- the register-staged path spends
+// more LDS cycles on its 13-cycle ds_write_b128s than on the fragment reads.  The DMA writes LDS linearly
+// (wave-uniform base + lane*16), so the swizzle is applied on the SOURCE side: the lane that owns LDS slot (row, cpos)
+// fetches logical chunk cpos ^ swz(row) of that row.  Wave w issues instructions 4w..4w+3 of the 16 per tile.
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void gbl_void_t;
+__device__ __forceinline__ void nt_glds(const bf16_t* __restrict__ P, long ld, int row0, int k0, int R, unsigned char* __restrict__ S) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int j = wave * 4 + i;
+    const int slot = j * 64 + lane, row = slot >> 3, c = (slot & 7) ^ swz(row);
+    int grow = row0 + row;
+    grow = grow < R ? grow : R - 1;
+    __builtin_amdgcn_global_load_lds((gbl_void_t*)(P + (long)grow * ld + k0 + c * 8), (lds_void_t*)(S + j * 1024), 16, 0, 0);
+  }
+}
+
+template <typename TO, int EPI, bool GLDS>
 __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ B, long ldb,
                                                            TO* __restrict__ C, long ldc, int M, int N, int K, const float* __restrict__ bias,
                                                            const void* __restrict__ aux, long ldaux, bf16_t* __restrict__ aux_out, long ldauxo) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * GB_BM * GB_BK * 2];   // [buf][A|B][128][64] bf16 = 64 KB
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int wm = wid >> 1, wn = wid & 1, half = lane >> 5, l31 = lane & 31;
-  // XCD-aware tile order: consecutive blocks of one XCD walk M-tiles under the same N-tile (B panel stays in that L2)
+  // XCD-aware tile order.  Blocks are dealt round-robin to the 8 XCDs (private 4 MB L2 each); remap so that every XCD
+  // owns a CONTIGUOUS chunk of a supertile order: groups of 8 M-tiles, inside a group N-tile-major.  The ~64 workgroups an
+  // XCD runs concurrently then cover ~8 A panels x ~8 B panels (~3 MB at K = 768) instead of 64 A panels x 1 B panel, so
+  // both operands are re-read from that L2, not from HBM / Infinity Cache.
   const int nbm = (M + GB_BM - 1) / GB_BM, nbn = (N + GB_BN - 1) / GB_BN;
   int bid = blockIdx.x;
   {
     const int nwg = nbm * nbn, q = nwg / 8, rr = nwg % 8, xcd = bid % 8, idx = bid / 8;
-    bid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + idx;
+    bid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + idx;      // bijective for any nwg
   }
-  const int m0 = (bid % nbm) * GB_BM, n0 = (bid / nbm) * GB_BN;
+  int tm, tn;
+  {
+    const int per_group = 8 * nbn, grp = bid / per_group, in = bid - grp * per_group;
+    const int rows = min(8, nbm - grp * 8);          // last group may hold fewer than 8 M-tiles
+    tn = in / rows;
+    tm = grp * 8 + (in - tn * rows);
+  }
+  const int m0 = tm * GB_BM, n0 = tn * GB_BN;
   f32x16 acc[2][2];   // [n block][m block]
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -80,18 +110,29 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(const bf16_t* __restr
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   u32x4 ra[4], rb[4];
-  nt_load(ra, A, lda, m0, 0, M, K);
-  nt_load(rb, B, ldb, n0, 0, N, K);
-  nt_store(ra, smem);
-  nt_store(rb, smem + GB_BM * GB_BK * 2);
+  if (GLDS) {
+    nt_glds(A, lda, m0, 0, M, smem);
+    nt_glds(B, ldb, n0, 0, N, smem + GB_BM * GB_BK * 2);
+  } else {
+    nt_load(ra, A, lda, m0, 0, M, K);
+    nt_load(rb, B, ldb, n0, 0, N, K);
+    nt_store(ra, smem);
+    nt_store(rb, smem + GB_BM * GB_BK * 2);
+  }
   __syncthreads();
   const int nk = (K + GB_BK - 1) / GB_BK;
   for (int kt = 0; kt < nk; ++kt) {
     unsigned char* As = smem + (kt & 1) * (2 * GB_BM * GB_BK * 2);
     unsigned char* Bs = As + GB_BM * GB_BK * 2;
     if (kt + 1 < nk) {
-      nt_load(ra, A, lda, m0, (kt + 1) * GB_BK, M, K);
-      nt_load(rb, B, ldb, n0, (kt + 1) * GB_BK, N, K);
+      if (GLDS) {
+        unsigned char* An = smem + ((kt + 1) & 1) * (2 * GB_BM * GB_BK * 2);
+        nt_glds(A, lda, m0, (kt + 1) * GB_BK, M, An);
+        nt_glds(B, ldb, n0, (kt + 1) * GB_BK, N, An + GB_BM * GB_BK * 2);
+      } else {
+        nt_load(ra, A, lda, m0, (kt + 1) * GB_BK, M, K);
+        nt_load(rb, B, ldb, n0, (kt + 1) * GB_BK, N, K);
+      }
     }
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
@@ -112,14 +153,23 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(const bf16_t* __restr
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[i], fa[j], acc[i][j], 0, 0, 0);
     }
-    if (kt + 1 < nk) {
+    if (!GLDS && kt + 1 < nk) {
       unsigned char* An = smem + ((kt + 1) & 1) * (2 * GB_BM * GB_BK * 2);
       nt_store(ra, An);
       nt_store(rb, An + GB_BM * GB_BK * 2);
     }
-    __syncthreads();
+    __syncthreads();    // with LDS-DMA in flight the compiler drains vmcnt(0) here: tile kt+1 has landed for every wave
   }
   // epilogue: acc[i][j][4g..4g+3] = C[m][n..n+3], m = m0 + wm*64 + j*32 + l31, n = n0 + wn*64 + i*32 + 8g + 4*half
+  // bias for all 8 column groups of this lane is fetched up front so its latency overlaps the first stores
+  float4 bv[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int n = n0 + wn * 64 + i * 32 + 8 * g + 4 * half;
+      bv[i][g] = (bias && n < N) ? ld4(bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int m = m0 + wm * 64 + j * 32 + l31;
@@ -130,20 +180,17 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(const bf16_t* __restr
       for (int g = 0; g < 4; ++g) {
         const int n = n0 + wn * 64 + i * 32 + 8 * g + 4 * half;
         if (n >= N) continue;
-        float4 v = make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
-        if (bias) {
-          const float4 bv = ld4(bias + n);
-          v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
-        }
+        float4 v = make_float4(acc[i][j][4 * g] + bv[i][g].x, acc[i][j][4 * g + 1] + bv[i][g].y, acc[i][j][4 * g + 2] + bv[i][g].z,
+                               acc[i][j][4 * g + 3] + bv[i][g].w);
         if (EPI == EPI_GELU) {
           st4(aux_out + (long)m * ldauxo + n, v);
-          v = make_float4(gelu_f(v.x), gelu_f(v.y), gelu_f(v.z), gelu_f(v.w));
+          v = make_float4(gelu_fast(v.x), gelu_fast(v.y), gelu_fast(v.z), gelu_fast(v.w));
         } else if (EPI == EPI_RESID) {
           const float4 rv = ld4(reinterpret_cast<const float*>(aux) + (long)m * ldaux + n);
           v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
         } else if (EPI == EPI_DGELU) {
           const float4 uv = ld4(reinterpret_cast<const bf16_t*>(aux) + (long)m * ldaux + n);
-          v.x *= dgelu_f(uv.x); v.y *= dgelu_f(uv.y); v.z *= dgelu_f(uv.z); v.w *= dgelu_f(uv.w);
+          v.x *= dgelu_fast(uv.x); v.y *= dgelu_fast(uv.y); v.z *= dgelu_fast(uv.z); v.w *= dgelu_fast(uv.w);
         }
         st4(C + (long)m * ldc + n, v);
       }
@@ -155,7 +202,12 @@ static int nt_dispatch(const bf16_t* A, long lda, const bf16_t* B, long ldb, TO*
                        const void* aux, long ldaux, bf16_t* aux_out, long ldauxo, hipStream_t st) {
   const int nwg = ((M + GB_BM - 1) / GB_BM) * ((N + GB_BN - 1) / GB_BN);
   dim3 grid(nwg), blk(256);
-#define NT_LAUNCH(E) hipLaunchKernelGGL((gemm_bf16_nt_kernel<TO, E>), grid, blk, 0, st, A, lda, B, ldb, C, ldc, M, N, K, bias, aux, ldaux, aux_out, ldauxo)
+  const bool glds = (K % GB_BK) == 0;      // the DMA path cannot zero-fill a ragged K tail
+#define NT_LAUNCH(E)                                                                                                                      \
+  do {                                                                                                                                    \
+    if (glds) hipLaunchKernelGGL((gemm_bf16_nt_kernel<TO, E, true>), grid, blk, 0, st, A, lda, B, ldb, C, ldc, M, N, K, bias, aux, ldaux, aux_out, ldauxo); \
+    else hipLaunchKernelGGL((gemm_bf16_nt_kernel<TO, E, false>), grid, blk, 0, st, A, lda, B, ldb, C, ldc, M, N, K, bias, aux, ldaux, aux_out, ldauxo);    \
+  } while (0)
   switch (epi) {
     case EPI_NONE: NT_LAUNCH(EPI_NONE); break;
     case EPI_GELU: NT_LAUNCH(EPI_GELU); break;
@@ -187,7 +239,8 @@ extern "C" int climb_gemm_bf16_nt(const void* A, long lda, const void* B, long l
 
 // ---------------------------------------------------------------------------------------------------------------- TN
 #define TN_BR 64            // reduction rows (tokens) per LDS tile
-#define TN_PITCH 320        // bytes per LDS row: 128 cols * 2 B + 64 B pad
+#define TN_PITCH 256        // bytes per LDS row: 128 cols * 2 B, 16-B chunks XOR-swizzled by tswz(row)
+__device__ __forceinline__ int tswz(int row) { return (row & 3) << 2; }   // 4 consecutive m-rows -> 4 different bank quarters
 
 // stage one [64 m][128 cols] tile: thread t handles (row = t/16 + 16p, chunk = t%16), p = 0..3
 __device__ __forceinline__ void tn_load(u32x4 (&r)[4], const bf16_t* __restrict__ P, long ld, int m0, int c0, int m_end, int Ccols) {
@@ -203,14 +256,30 @@ __device__ __forceinline__ void tn_load(u32x4 (&r)[4], const bf16_t* __restrict_
 __device__ __forceinline__ void tn_store(const u32x4 (&r)[4], unsigned char* __restrict__ S) {
   const int t = threadIdx.x;
 #pragma unroll
-  for (int p = 0; p < 4; ++p) *reinterpret_cast<u32x4*>(S + ((t >> 4) + 16 * p) * TN_PITCH + ((t & 15) << 4)) = r[p];
+  for (int p = 0; p < 4; ++p) {
+    const int row = (t >> 4) + 16 * p;
+    *reinterpret_cast<u32x4*>(S + row * TN_PITCH + (((t & 15) ^ tswz(row)) << 4)) = r[p];
+  }
+}
+// LDS-DMA staging of a FULL [64][128] tile (rows must all be inside the reduction range; columns are clamped)
+__device__ __forceinline__ void tn_glds(const bf16_t* __restrict__ P, long ld, int m0, int c0, int Ccols, unsigned char* __restrict__ S) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int j = wave * 4 + i;
+    const int slot = j * 64 + lane, row = slot >> 4, c = (slot & 15) ^ tswz(row);
+    int col = c0 + c * 8;
+    col = col < Ccols ? col : Ccols - 8;
+    __builtin_amdgcn_global_load_lds((gbl_void_t*)(P + (long)(m0 + row) * ld + col), (lds_void_t*)(S + j * 1024), 16, 0, 0);
+  }
 }
 // 8-element MFMA operand for output index (col0 + lane&31) and reduction rows mrow0 + (lane>>5)*8 + 0..7
 __device__ __forceinline__ bf16x8 tn_frag(const unsigned char* __restrict__ S, int mrow0, int col0, int lane) {
   const int g16 = lane >> 4, i = lane & 15;
   const int row = mrow0 + (g16 >> 1) * 8 + (i >> 2);
   const int col = col0 + (g16 & 1) * 16 + 4 * (i & 3);
-  const unsigned char* p = S + row * TN_PITCH + col * 2;
+  // rows `row` and `row + 4` share (row & 3), hence the same swizzle
+  const unsigned char* p = S + row * TN_PITCH + ((((col >> 3) ^ tswz(row))) << 4) + (col & 7) * 2;
   typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
   s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
   s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 4 * TN_PITCH));
@@ -220,16 +289,24 @@ __device__ __forceinline__ bf16x8 tn_frag(const unsigned char* __restrict__ S, i
   return c.b;
 }
 
-// grid: (tiles, splits).  C[n][k] += sum_m A[m][n] * B[m][k]; ATOMIC = 1 when several splits accumulate into C.
-template <bool ATOMIC>
+// grid: tiles * splits.  C[n][k] += sum_m A[m][n] * B[m][k]; ATOMIC = 1 when several splits accumulate into C.
+template <bool ATOMIC, bool GLDS>
 __global__ __launch_bounds__(256) void gemm_bf16_tn_kernel(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ B, long ldb,
                                                            float* __restrict__ C, long ldc, int M, int N, int K, int rows_per_split) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * TN_BR * TN_PITCH];   // [buf][A|B][64][320 B] = 80 KB
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * TN_BR * TN_PITCH];   // [buf][A|B][64][256 B] = 64 KB
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int wn = wid >> 1, wk = wid & 1, half = lane >> 5, l31 = lane & 31;
-  const int nbn = (N + 127) / 128;
-  const int n0 = (blockIdx.x % nbn) * 128, k0 = (blockIdx.x / nbn) * 128;
-  const int mbeg = blockIdx.y * rows_per_split;
+  // 1-D grid, XCD-contiguous chunks: the workgroups one XCD runs together belong to the same token range (split), so its
+  // L2 holds each dY / X panel once while all (n, k) tiles of that split consume them
+  const int nbn = (N + 127) / 128, tiles = nbn * ((K + 127) / 128);
+  int bid = blockIdx.x;
+  {
+    const int nwg = gridDim.x, q = nwg / 8, rr = nwg % 8, xcd = bid % 8, idx = bid / 8;
+    bid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + idx;
+  }
+  const int split = bid / tiles, tile = bid - split * tiles;
+  const int n0 = (tile % nbn) * 128, k0 = (tile / nbn) * 128;
+  const int mbeg = split * rows_per_split;
   const int mend = min(M, mbeg + rows_per_split);
   f32x16 acc[2][2];   // [n block][k block]
 #pragma unroll
@@ -239,18 +316,29 @@ __global__ __launch_bounds__(256) void gemm_bf16_tn_kernel(const bf16_t* __restr
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   u32x4 ra[4], rb[4];
-  tn_load(ra, A, lda, mbeg, n0, mend, N);
-  tn_load(rb, B, ldb, mbeg, k0, mend, K);
-  tn_store(ra, smem);
-  tn_store(rb, smem + TN_BR * TN_PITCH);
+  if (GLDS) {
+    tn_glds(A, lda, mbeg, n0, N, smem);
+    tn_glds(B, ldb, mbeg, k0, K, smem + TN_BR * TN_PITCH);
+  } else {
+    tn_load(ra, A, lda, mbeg, n0, mend, N);
+    tn_load(rb, B, ldb, mbeg, k0, mend, K);
+    tn_store(ra, smem);
+    tn_store(rb, smem + TN_BR * TN_PITCH);
+  }
   __syncthreads();
   const int nt = (mend - mbeg + TN_BR - 1) / TN_BR;
   for (int t = 0; t < nt; ++t) {
     const unsigned char* As = smem + (t & 1) * (2 * TN_BR * TN_PITCH);
     const unsigned char* Bs = As + TN_BR * TN_PITCH;
     if (t + 1 < nt) {
-      tn_load(ra, A, lda, mbeg + (t + 1) * TN_BR, n0, mend, N);
-      tn_load(rb, B, ldb, mbeg + (t + 1) * TN_BR, k0, mend, K);
+      if (GLDS) {
+        unsigned char* An = smem + ((t + 1) & 1) * (2 * TN_BR * TN_PITCH);
+        tn_glds(A, lda, mbeg + (t + 1) * TN_BR, n0, N, An);
+        tn_glds(B, ldb, mbeg + (t + 1) * TN_BR, k0, K, An + TN_BR * TN_PITCH);
+      } else {
+        tn_load(ra, A, lda, mbeg + (t + 1) * TN_BR, n0, mend, N);
+        tn_load(rb, B, ldb, mbeg + (t + 1) * TN_BR, k0, mend, K);
+      }
     }
 #pragma unroll
     for (int ms = 0; ms < TN_BR / 16; ++ms) {
@@ -264,7 +352,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_tn_kernel(const bf16_t* __restr
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
     }
-    if (t + 1 < nt) {
+    if (!GLDS && t + 1 < nt) {
       unsigned char* An = smem + ((t + 1) & 1) * (2 * TN_BR * TN_PITCH);
       tn_store(ra, An);
       tn_store(rb, An + TN_BR * TN_PITCH);
@@ -300,12 +388,13 @@ extern "C" int climb_gemm_bf16_tn(const void* A, long lda, const void* B, long l
   int rows = (M + splits - 1) / splits;
   rows = (rows + TN_BR - 1) / TN_BR * TN_BR;
   splits = (M + rows - 1) / rows;
-  dim3 grid(tiles, splits), blk(256);
+  dim3 grid(tiles * splits), blk(256);
   hipStream_t st = (hipStream_t)stream;
-  if (splits > 1)
-    hipLaunchKernelGGL((gemm_bf16_tn_kernel<true>), grid, blk, 0, st, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc, M, N, K, rows);
-  else
-    hipLaunchKernelGGL((gemm_bf16_tn_kernel<false>), grid, blk, 0, st, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc, M, N, K, rows);
+  const bool glds = (M % TN_BR) == 0 && N >= 8 && K >= 8;      // the DMA path cannot zero-fill a ragged reduction tail
+#define TN_LAUNCH(AT, GL) hipLaunchKernelGGL((gemm_bf16_tn_kernel<AT, GL>), grid, blk, 0, st, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc, M, N, K, rows)
+  if (splits > 1) { if (glds) TN_LAUNCH(true, true); else TN_LAUNCH(true, false); }
+  else { if (glds) TN_LAUNCH(false, true); else TN_LAUNCH(false, false); }
+#undef TN_LAUNCH
   LAUNCH_CHECK();
   return CLIMB_OK;
 }
