@@ -292,7 +292,8 @@ __device__ __forceinline__ bf16x8 tn_frag(const unsigned char* __restrict__ S, i
 // grid: tiles * splits.  C[n][k] += sum_m A[m][n] * B[m][k]; ATOMIC = 1 when several splits accumulate into C.
 template <bool ATOMIC, bool GLDS>
 __global__ __launch_bounds__(256) void gemm_bf16_tn_kernel(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ B, long ldb,
-                                                           float* __restrict__ C, long ldc, int M, int N, int K, int rows_per_split) {
+                                                           float* __restrict__ C, long ldc, int M, int N, int K, int rows_per_split,
+                                                           float* __restrict__ dbias) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * TN_BR * TN_PITCH];   // [buf][A|B][64][256 B] = 64 KB
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int wn = wid >> 1, wk = wid & 1, half = lane >> 5, l31 = lane & 31;
@@ -315,6 +316,20 @@ __global__ __launch_bounds__(256) void gemm_bf16_tn_kernel(const bf16_t* __restr
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  // bias gradient db[n] = sum_m dY[m][n] rides along as dY^T . 1: the k-tile-0 workgroups issue one extra MFMA per dY
+  // fragment against an all-ones operand (every column of the result holds the column sum)
+  const bool do_bias = dbias != nullptr && k0 == 0 && wk == 0;
+  f32x16 accb[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accb[i][r] = 0.f;
+  bf16x8 ones;
+  {
+    union { unsigned int u[4]; bf16x8 b; } c;
+    c.u[0] = c.u[1] = c.u[2] = c.u[3] = 0x3F803F80u;
+    ones = c.b;
+  }
   u32x4 ra[4], rb[4];
   if (GLDS) {
     tn_glds(A, lda, mbeg, n0, N, smem);
@@ -351,6 +366,10 @@ __global__ __launch_bounds__(256) void gemm_bf16_tn_kernel(const bf16_t* __restr
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+      if (do_bias) {
+        accb[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], ones, accb[0], 0, 0, 0);
+        accb[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1], ones, accb[1], 0, 0, 0);
+      }
     }
     if (!GLDS && t + 1 < nt) {
       unsigned char* An = smem + ((t + 1) & 1) * (2 * TN_BR * TN_PITCH);
@@ -375,10 +394,24 @@ __global__ __launch_bounds__(256) void gemm_bf16_tn_kernel(const bf16_t* __restr
         else *cp += acc[i][j][r];
       }
     }
+  if (do_bias && l31 == 0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = n0 + wn * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (n < N) {
+          if (ATOMIC) atomicAdd(dbias + n, accb[i][r]);
+          else dbias[n] += accb[i][r];
+        }
+      }
+  }
 }
 
 // C[N,K] (fp32, ldc) += A[M,N]^T B[M,K]; A, B bf16 row-major (lda, ldb).  N % 8 == 0, K % 8 == 0.
-extern "C" int climb_gemm_bf16_tn(const void* A, long lda, const void* B, long ldb, float* C, long ldc, int M, int N, int K, void* stream) {
+// dbias (optional, fp32 [N]) += column sums of A  (the bias gradient of the same linear layer, fused)
+extern "C" int climb_gemm_bf16_tn(const void* A, long lda, const void* B, long ldb, float* C, long ldc, int M, int N, int K, float* dbias,
+                                  void* stream) {
   if (M <= 0 || N <= 0 || K <= 0 || (N % 8) || (K % 8) || (lda % 8) || (ldb % 8) || !al16p(A) || !al16p(B)) return CLIMB_EINVAL;
   const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
   int splits = (512 + tiles - 1) / tiles;                         // aim at ~2 workgroups per CU
@@ -391,7 +424,7 @@ extern "C" int climb_gemm_bf16_tn(const void* A, long lda, const void* B, long l
   dim3 grid(tiles * splits), blk(256);
   hipStream_t st = (hipStream_t)stream;
   const bool glds = (M % TN_BR) == 0 && N >= 8 && K >= 8;      // the DMA path cannot zero-fill a ragged reduction tail
-#define TN_LAUNCH(AT, GL) hipLaunchKernelGGL((gemm_bf16_tn_kernel<AT, GL>), grid, blk, 0, st, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc, M, N, K, rows)
+#define TN_LAUNCH(AT, GL) hipLaunchKernelGGL((gemm_bf16_tn_kernel<AT, GL>), grid, blk, 0, st, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc, M, N, K, rows, dbias)
   if (splits > 1) { if (glds) TN_LAUNCH(true, true); else TN_LAUNCH(true, false); }
   else { if (glds) TN_LAUNCH(false, true); else TN_LAUNCH(false, false); }
 #undef TN_LAUNCH

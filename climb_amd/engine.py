@@ -11,6 +11,7 @@ Two arithmetic modes share all of this code:
 from __future__ import annotations
 
 import math
+import os
 from typing import Callable, Dict, List, Optional
 
 import torch
@@ -116,6 +117,10 @@ class ViltEngine:
         self.touched: List[tuple] = []                  # flat ranges that received gradients in the last backward
         self.saved = None
         self.prof = None                                # bench.py: {"kernel": name, "events": [(start, end, flops)]}
+        # weight-gradient GEMMs run on a second HIP stream, concurrently with the input-gradient chain they do not feed
+        self.overlap_dw = os.environ.get("CLIMB_AMD_OVERLAP_DW", "1") != "0"
+        self._side = None
+        self._side_pending = None
 
     # ------------------------------------------------------------------ buffers
     def allocate(self):
@@ -194,20 +199,49 @@ class ViltEngine:
         else:
             self._bf16_dx(dY, wname, dX, M, N, K, epi, aux)
 
-    def linear_dw(self, dY, X, wname, M, N, K):
-        """dW[N,K] += dY[M,N]^T @ X[M,K]"""
+    def linear_dw(self, dY, X, wname, M, N, K, bname=None, ws=None):
+        """dW[N,K] += dY[M,N]^T @ X[M,K];  db[N] += colsum(dY) when `bname` is given (fused into the bf16 dW kernel)."""
+        want_b = bname is not None and self.requires_grad[bname]
         if not self.requires_grad[wname]:
+            if want_b:
+                self.bias_grad(dY, self.adt, bname, M, N, ws)
             return
         if self.precision == "fp32":
+            if want_b:
+                self.bias_grad(dY, F32, bname, M, N, ws)
             self._gemm_f32(dY, 1, N, X, 1, K, self.g(wname), K, N, K, M, beta=1.0)
         else:
-            self._bf16_dw(dY, X, wname, M, N, K)
+            self._bf16_dw(dY, X, wname, M, N, K, self.g(bname) if want_b else None)
 
     def reduce3(self, part, nblk, ncols, n0, n1, n2):
         """{dgamma, dbeta, colsum} partials -> three parameter gradients, one launch (names may be None / frozen)."""
         rg = self.requires_grad
         ptrs = [self.g(n) if (n is not None and rg[n]) else None for n in (n0, n1, n2)]
         _lib.call("climb_colreduce3", part, 3 * ncols, nblk, ptrs[0], ptrs[1], ptrs[2], ncols, 1.0, _stream())
+
+    def dw_async(self, *args, **kw):
+        """linear_dw on the side stream: dW needs dY and the saved input, and nothing on the dX chain needs dW, so the two
+        GEMM families of a layer overlap (this also fills the tail waves the 768-wide GEMMs leave on 256 CUs)."""
+        if not self.overlap_dw:
+            return self.linear_dw(*args, **kw)
+        main = torch.cuda.current_stream()
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        ev = torch.cuda.Event()
+        ev.record(main)
+        self._side.wait_event(ev)
+        with torch.cuda.stream(self._side):
+            self.linear_dw(*args, **kw)
+            done = torch.cuda.Event()
+            done.record(self._side)
+        self._side_pending = done
+
+    def join_side(self):
+        """Main stream waits for every outstanding weight-gradient GEMM (called before a buffer they read is overwritten
+        and before a layer's gradients are reported final)."""
+        if self._side_pending is not None:
+            torch.cuda.current_stream().wait_event(self._side_pending)
+            self._side_pending = None
 
     def bias_grad_from_part(self, part_ptr, stride, nblk, bname, ncols):
         if bname is not None and self.requires_grad[bname]:
@@ -301,8 +335,8 @@ class ViltEngine:
         self._timed_call("gemm_bf16_nt", 2.0 * M * N * K, "climb_gemm_bf16_nt", dY, N, self.spt(wname), N, dX, K, BF16, M, K, N, None, epi, aux, K,
                          None, 0, _stream())
 
-    def _bf16_dw(self, dY, X, wname, M, N, K):
-        self._timed_call("gemm_bf16_tn", 2.0 * M * N * K, "climb_gemm_bf16_tn", dY, N, X, K, self.g(wname), K, M, N, K, _stream())
+    def _bf16_dw(self, dY, X, wname, M, N, K, dbias=None):
+        self._timed_call("gemm_bf16_tn", 2.0 * M * N * K, "climb_gemm_bf16_tn", dY, N, X, K, self.g(wname), K, M, N, K, dbias, _stream())
 
     @property
     def adt(self):
@@ -432,28 +466,28 @@ class ViltEngine:
             l = f"{ENC}encoder.layer.{i}."
             # MLP: x_{i+1} = h1 + W2 gelu(u) + b2,  u = W1 hn + b1
             self.linear_dx(ws.dres_c, l + "output.dense.weight", ws.du, M, H, Fd, EPI_DGELU, ws.u[i])
-            self.linear_dw(ws.dres_c, ws.a[i], l + "output.dense.weight", M, H, Fd)
-            self.bias_grad(ws.du, adt, l + "intermediate.dense.bias", M, Fd, ws)
-            self.linear_dw(ws.du, ws.hn[i], l + "intermediate.dense.weight", M, Fd, H)
+            self.dw_async(ws.dres_c, ws.a[i], l + "output.dense.weight", M, H, Fd)
+            self.dw_async(ws.du, ws.hn[i], l + "intermediate.dense.weight", M, Fd, H, l + "intermediate.dense.bias", ws)
             self.linear_dx(ws.du, l + "intermediate.dense.weight", ws.dhn, M, Fd, H)
+            self.join_side()          # LN backward overwrites d(residual) that dW2 is reading
             _lib.call("climb_layernorm_bwd", ws.dhn, H, adt, ws.h1[i], H, ws.mean2[i], ws.rstd2[i], self.p(l + "layernorm_after.weight"),
                       ws.dres, H, ws.dres, H, None if self.precision == "fp32" else ws.dres_c, H, ws.part, M, H, st)
             self.reduce3(ws.part, nlnb, H, l + "layernorm_after.weight", l + "layernorm_after.bias", l + "attention.output.dense.bias")
             # attention: h1 = x + Wo ctx + bo
-            self.linear_dw(ws.dres_c, ws.ctx[i], l + "attention.output.dense.weight", M, H, H)
+            self.dw_async(ws.dres_c, ws.ctx[i], l + "attention.output.dense.weight", M, H, H)
             self.linear_dx(ws.dres_c, l + "attention.output.dense.weight", ws.dctx, M, H, H)
             self.attn_bwd(ws.qkv[i], ws.key_bias, ws.dctx, ws.ctx[i], ws.lse[i], ws.delta, ws.dqkv, B, ws.S_pad)
-            qb = l + "attention.attention.query.bias"
-            if rg[qb]:
-                self.bias_grad(ws.dqkv, adt, qb, M, 3 * H, ws)      # q/k/v biases are adjacent: one [2304] reduction
-            self.linear_dw(ws.dqkv, ws.xn[i], l + "attention.attention.query.weight", M, 3 * H, H)
+            # q/k/v weights and biases are adjacent: one [2304,768] weight-gradient GEMM + one [2304] bias reduction
+            self.dw_async(ws.dqkv, ws.xn[i], l + "attention.attention.query.weight", M, 3 * H, H, l + "attention.attention.query.bias", ws)
             need_dx = i > first_layer or embeddings
             if need_dx:
                 self.linear_dx(ws.dqkv, l + "attention.attention.query.weight", ws.dxn, M, 3 * H, H)
+                self.join_side()      # LN backward overwrites d(residual) (read by dWo); next layer overwrites du / dqkv
                 _lib.call("climb_layernorm_bwd", ws.dxn, H, adt, ws.x[i], H, ws.mean1[i], ws.rstd1[i], self.p(l + "layernorm_before.weight"),
                           ws.dres, H, ws.dres, H, None if self.precision == "fp32" else ws.dres_c, H, ws.part, M, H, st)
                 self.reduce3(ws.part, nlnb, H, l + "layernorm_before.weight", l + "layernorm_before.bias",
                              f"{ENC}encoder.layer.{i - 1}.output.dense.bias" if i > first_layer else None)
+            self.join_side()
             self._ready(*lay.layer_range[i])
         if embeddings and first_layer == 0:
             self.embedding_backward(ws, sv)
@@ -471,8 +505,7 @@ class ViltEngine:
                   self.g(e + "cls_token") if rg[e + "cls_token"] else None, ws.part, B, T, ws.NP, ws.S_pad, H, ntypes, st)
         self.bias_grad_from_part(ws.part.data_ptr(), ntypes * H, ws.NP + 1, e + "token_type_embeddings.weight", ntypes * H)
         Kp = cfg["channels"] * cfg["patch"] ** 2
-        self.bias_grad(ws.dproj, self.adt, e + "patch_embeddings.projection.bias", B * ws.NP, H, ws)
-        self.linear_dw(ws.dproj, ws.a_patch, e + "patch_embeddings.projection.weight", B * ws.NP, H, Kp)
+        self.linear_dw(ws.dproj, ws.a_patch, e + "patch_embeddings.projection.weight", B * ws.NP, H, Kp, e + "patch_embeddings.projection.bias", ws)
         te = e + "text_embeddings."
         _lib.call("climb_embed_text_bwd", sv["input_ids"], sv["token_type_ids"], self.p(te + "word_embeddings.weight"),
                   self.p(te + "token_type_embeddings.weight"), self.p(te + "position_embeddings.weight"), self.p(te + "LayerNorm.weight"),

@@ -101,8 +101,9 @@ int climb_transpose_bf16_batched(const void* src, void* dst, const long* table, 
  * C[M,N] (c_dtype) = epi(A[M,K] B[N,K]^T + bias); A,B bf16, K contiguous.  epi 1: aux_out (bf16) = pre-activation;
  * epi 2: aux = fp32 residual [M,N]; epi 3: aux = bf16 pre-activation (multiplies by gelu'). */
 int climb_gemm_bf16_nt(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int c_dtype, int M, int N, int K, const float* bias, int epi, const void* aux, long ldaux, void* aux_out, long ldauxo, void* stream);
-/* weight gradient: C[N,K] (fp32) += A[M,N]^T B[M,K]; reduction over tokens via LDS transpose reads, split over M with fp32 atomics */
-int climb_gemm_bf16_tn(const void* A, long lda, const void* B, long ldb, float* C, long ldc, int M, int N, int K, void* stream);
+/* weight gradient: C[N,K] (fp32) += A[M,N]^T B[M,K]; reduction over tokens via LDS transpose reads, split over M with fp32 atomics;
+ * dbias (optional, fp32 [N]) += column sums of A = the bias gradient of the same layer (one extra MFMA against an all-ones operand) */
+int climb_gemm_bf16_tn(const void* A, long lda, const void* B, long ldb, float* C, long ldc, int M, int N, int K, float* dbias, void* stream);
 /* HF:322-351 in bf16: same contract as the _f32 entry points, qkv/ctx/dctx/dqkv are bf16 */
 int climb_attn_fwd_bf16(const void* qkv, const float* key_bias, void* ctx, float* lse, int B, int S_pad, int heads, int head_dim, void* stream);
 int climb_attn_bwd_bf16(const void* qkv, const float* key_bias, const void* dctx, const float* lse, const float* delta, void* dqkv, int B, int S_pad, int heads, int head_dim, void* stream);

@@ -273,9 +273,12 @@ def test_gemm_bf16_tn_weight_grad(M, N, K):
     dY, X = _bf(torch.randn(M, N, generator=g)), _bf(torch.randn(M, K, generator=g))
     C0 = torch.randn(N, K, generator=g)
     C = C0.to(dev).clone()
-    _lib.call("climb_gemm_bf16_tn", dY.to(dev), N, X.to(dev), K, C, K, M, N, K, _st())
+    db0 = torch.randn(N, generator=g)
+    db = db0.to(dev).clone()
+    _lib.call("climb_gemm_bf16_tn", dY.to(dev), N, X.to(dev), K, C, K, M, N, K, db, _st())
     ref = C0.double() + dY.double().t() @ X.double()
     assert _rel(C, ref) < 1e-5
+    assert _rel(db, db0.double() + dY.double().sum(0)) < 1e-5          # fused bias gradient (dY^T . 1)
 
 
 @pytest.mark.parametrize("S_pad,valid", [(64, 50), (192, 185), (224, 200), (288, 281)])

@@ -42,7 +42,7 @@ for name, N, K in [("dW2", 768, 3072), ("dW1", 3072, 768), ("dWo", 768, 768), ("
     dY = torch.randn(M, N, device=dev).bfloat16()
     X = torch.randn(M, K, device=dev).bfloat16()
     C = torch.zeros(N, K, device=dev)
-    t = timeit(lambda: _lib.call("climb_gemm_bf16_tn", dY, N, X, K, C, K, M, N, K, st()))
+    t = timeit(lambda: _lib.call("climb_gemm_bf16_tn", dY, N, X, K, C, K, M, N, K, None, st()))
     f = 2.0 * M * N * K
     tt += t; tf += f
     print(f"TN {name:14s} N={N:5d} K={K:5d}: {t*1e6:8.1f} us  {f/t/1e12:7.1f} TF")
