@@ -101,3 +101,12 @@ __device__ __forceinline__ float dgelu_fast(float x) { float c, p; gelu_parts(x,
 #define EPI_RESID 2   // C = acc + bias + aux      (aux is f32 [M,N], leading dim ldaux)
 #define EPI_DGELU 3   // C = acc * gelu'(aux)      (aux has C's dtype)
 #define EPI_TANH 4    // C = tanh(acc + bias)
+#define EPI_SILU 5    // aux_out = acc + bias ; C = silu(aux_out)                  (adapter down-projection)
+#define EPI_DSILU 6   // C = acc * silu'(aux)       (aux has C's dtype)             (adapter backward)
+#define EPI_RESID2 7  // C = acc + bias + aux (f32) + aux2 (C's operand dtype)     (adapter up-projection + both residuals)
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float dsilu_f(float x) {
+  const float sg = 1.0f / (1.0f + __expf(-x));
+  return sg * (1.0f + x * (1.0f - sg));
+}

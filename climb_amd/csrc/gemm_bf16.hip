@@ -80,7 +80,8 @@ __device__ __forceinline__ void nt_glds(const bf16_t* __restrict__ P, long ld, i
 template <typename TO, int EPI, bool GLDS>
 __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ B, long ldb,
                                                            TO* __restrict__ C, long ldc, int M, int N, int K, const float* __restrict__ bias,
-                                                           const void* __restrict__ aux, long ldaux, bf16_t* __restrict__ aux_out, long ldauxo) {
+                                                           const void* __restrict__ aux, long ldaux, bf16_t* __restrict__ aux_out, long ldauxo,
+                                                           const bf16_t* __restrict__ aux2, long ldaux2) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * GB_BM * GB_BK * 2];   // [buf][A|B][128][64] bf16 = 64 KB
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int wm = wid >> 1, wn = wid & 1, half = lane >> 5, l31 = lane & 31;
@@ -191,6 +192,16 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(const bf16_t* __restr
         } else if (EPI == EPI_DGELU) {
           const float4 uv = ld4(reinterpret_cast<const bf16_t*>(aux) + (long)m * ldaux + n);
           v.x *= dgelu_fast(uv.x); v.y *= dgelu_fast(uv.y); v.z *= dgelu_fast(uv.z); v.w *= dgelu_fast(uv.w);
+        } else if (EPI == EPI_SILU) {
+          st4(aux_out + (long)m * ldauxo + n, v);
+          v = make_float4(silu_f(v.x), silu_f(v.y), silu_f(v.z), silu_f(v.w));
+        } else if (EPI == EPI_DSILU) {
+          const float4 uv = ld4(reinterpret_cast<const bf16_t*>(aux) + (long)m * ldaux + n);
+          v.x *= dsilu_f(uv.x); v.y *= dsilu_f(uv.y); v.z *= dsilu_f(uv.z); v.w *= dsilu_f(uv.w);
+        } else if (EPI == EPI_RESID2) {
+          const float4 rv = ld4(reinterpret_cast<const float*>(aux) + (long)m * ldaux + n);
+          const float4 yv = ld4(aux2 + (long)m * ldaux2 + n);
+          v.x += rv.x + yv.x; v.y += rv.y + yv.y; v.z += rv.z + yv.z; v.w += rv.w + yv.w;
         }
         st4(C + (long)m * ldc + n, v);
       }
@@ -199,20 +210,23 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(const bf16_t* __restr
 
 template <typename TO>
 static int nt_dispatch(const bf16_t* A, long lda, const bf16_t* B, long ldb, TO* C, long ldc, int M, int N, int K, const float* bias, int epi,
-                       const void* aux, long ldaux, bf16_t* aux_out, long ldauxo, hipStream_t st) {
+                       const void* aux, long ldaux, bf16_t* aux_out, long ldauxo, const bf16_t* aux2, long ldaux2, hipStream_t st) {
   const int nwg = ((M + GB_BM - 1) / GB_BM) * ((N + GB_BN - 1) / GB_BN);
   dim3 grid(nwg), blk(256);
   const bool glds = (K % GB_BK) == 0;      // the DMA path cannot zero-fill a ragged K tail
 #define NT_LAUNCH(E)                                                                                                                      \
   do {                                                                                                                                    \
-    if (glds) hipLaunchKernelGGL((gemm_bf16_nt_kernel<TO, E, true>), grid, blk, 0, st, A, lda, B, ldb, C, ldc, M, N, K, bias, aux, ldaux, aux_out, ldauxo); \
-    else hipLaunchKernelGGL((gemm_bf16_nt_kernel<TO, E, false>), grid, blk, 0, st, A, lda, B, ldb, C, ldc, M, N, K, bias, aux, ldaux, aux_out, ldauxo);    \
+    if (glds) hipLaunchKernelGGL((gemm_bf16_nt_kernel<TO, E, true>), grid, blk, 0, st, A, lda, B, ldb, C, ldc, M, N, K, bias, aux, ldaux, aux_out, ldauxo, aux2, ldaux2); \
+    else hipLaunchKernelGGL((gemm_bf16_nt_kernel<TO, E, false>), grid, blk, 0, st, A, lda, B, ldb, C, ldc, M, N, K, bias, aux, ldaux, aux_out, ldauxo, aux2, ldaux2);    \
   } while (0)
   switch (epi) {
     case EPI_NONE: NT_LAUNCH(EPI_NONE); break;
     case EPI_GELU: NT_LAUNCH(EPI_GELU); break;
     case EPI_RESID: NT_LAUNCH(EPI_RESID); break;
     case EPI_DGELU: NT_LAUNCH(EPI_DGELU); break;
+    case EPI_SILU: NT_LAUNCH(EPI_SILU); break;
+    case EPI_DSILU: NT_LAUNCH(EPI_DSILU); break;
+    case EPI_RESID2: NT_LAUNCH(EPI_RESID2); break;
     default: return CLIMB_EINVAL;
   }
 #undef NT_LAUNCH
@@ -223,17 +237,20 @@ static int nt_dispatch(const bf16_t* A, long lda, const bf16_t* B, long ldb, TO*
 static inline bool al16p(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 // C (c_dtype: 0 fp32 / 1 bf16) [M,N] = epi(A[M,K] B[N,K]^T + bias).  A, B bf16 with K contiguous; K % 8 == 0, N % 4 == 0.
-// epi 1 (GELU): aux_out (bf16 [M,N]) receives the pre-activation.  epi 2: aux = fp32 residual [M,N].  epi 3: aux = bf16 pre-activation.
+// epi 1/5 (GELU/SiLU): aux_out (bf16 [M,N]) receives the pre-activation.  epi 2: aux = fp32 residual [M,N].  epi 3/6: aux = bf16
+// pre-activation (x gelu'/silu').  epi 7: aux = fp32 residual and aux2 = bf16 second residual.
 extern "C" int climb_gemm_bf16_nt(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int c_dtype, int M, int N, int K,
-                                  const float* bias, int epi, const void* aux, long ldaux, void* aux_out, long ldauxo, void* stream) {
+                                  const float* bias, int epi, const void* aux, long ldaux, void* aux_out, long ldauxo, const void* aux2, long ldaux2,
+                                  void* stream) {
   if (M <= 0 || N <= 0 || K <= 0 || (K % 8) || (N % 4) || (lda % 8) || (ldb % 8) || (ldc % 4) || !al16p(A) || !al16p(B) || !al16p(C)) return CLIMB_EINVAL;
-  if ((epi == EPI_RESID || epi == EPI_DGELU) && !aux) return CLIMB_EINVAL;
-  if (epi == EPI_GELU && !aux_out) return CLIMB_EINVAL;
+  if ((epi == EPI_RESID || epi == EPI_DGELU || epi == EPI_DSILU || epi == EPI_RESID2) && !aux) return CLIMB_EINVAL;
+  if ((epi == EPI_GELU || epi == EPI_SILU) && !aux_out) return CLIMB_EINVAL;
+  if (epi == EPI_RESID2 && !aux2) return CLIMB_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   if (c_dtype == CLIMB_DT_F32)
-    return nt_dispatch<float>((const bf16_t*)A, lda, (const bf16_t*)B, ldb, (float*)C, ldc, M, N, K, bias, epi, aux, ldaux, (bf16_t*)aux_out, ldauxo, st);
+    return nt_dispatch<float>((const bf16_t*)A, lda, (const bf16_t*)B, ldb, (float*)C, ldc, M, N, K, bias, epi, aux, ldaux, (bf16_t*)aux_out, ldauxo, (const bf16_t*)aux2, ldaux2, st);
   if (c_dtype == CLIMB_DT_BF16)
-    return nt_dispatch<bf16_t>((const bf16_t*)A, lda, (const bf16_t*)B, ldb, (bf16_t*)C, ldc, M, N, K, bias, epi, aux, ldaux, (bf16_t*)aux_out, ldauxo, st);
+    return nt_dispatch<bf16_t>((const bf16_t*)A, lda, (const bf16_t*)B, ldb, (bf16_t*)C, ldc, M, N, K, bias, epi, aux, ldaux, (bf16_t*)aux_out, ldauxo, (const bf16_t*)aux2, ldaux2, st);
   return CLIMB_EINVAL;
 }
 

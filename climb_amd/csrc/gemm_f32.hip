@@ -101,7 +101,7 @@ template <int BM, int BN>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, long sam, long sak, int modeA, const float* __restrict__ B,
                                                        long sbn, long sbk, int modeB, float* C, long ldc, int M, int N, int K,
                                                        const float* __restrict__ bias, int epi, const float* aux, long ldaux, float* aux_out,
-                                                       long ldauxo, float beta) {
+                                                       long ldauxo, float beta, const float* aux2, long ldaux2) {
   constexpr int WM = BM / 2, WN = BN / 2;   // per-wave tile
   constexpr int TM = WM / 32, TN = WN / 32; // 32x32 MFMA blocks per wave
   __shared__ __attribute__((aligned(16))) float As[GF_BK * (BM + GF_PAD)];
@@ -161,6 +161,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
         else if (epi == EPI_RESID) v += aux[(long)m * ldaux + n];
         else if (epi == EPI_DGELU) v *= dgelu_f(aux[(long)m * ldaux + n]);
         else if (epi == EPI_TANH) v = tanhf(v);
+        else if (epi == EPI_SILU) { aux_out[(long)m * ldauxo + n] = v; v = silu_f(v); }
+        else if (epi == EPI_DSILU) v *= dsilu_f(aux[(long)m * ldaux + n]);
+        else if (epi == EPI_RESID2) v += aux[(long)m * ldaux + n] + aux2[(long)m * ldaux2 + n];
         float* cp = C + (long)m * ldc + n;
         if (beta != 0.f) v += beta * (*cp);
         *cp = v;
@@ -172,10 +175,12 @@ static inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 // C[m,n] (ldc) = epi(sum_k A[m*sam + k*sak] * B[n*sbn + k*sbk] + bias[n]) + beta*C
 extern "C" int climb_gemm_f32(const float* A, long sam, long sak, const float* B, long sbn, long sbk, float* C, long ldc, int M, int N, int K,
-                              const float* bias, int epi, const float* aux, long ldaux, float* aux_out, long ldauxo, float beta, void* stream) {
+                              const float* bias, int epi, const float* aux, long ldaux, float* aux_out, long ldauxo, float beta, const float* aux2,
+                              long ldaux2, void* stream) {
   if (M <= 0 || N <= 0 || K <= 0) return CLIMB_EINVAL;
-  if ((epi == EPI_RESID || epi == EPI_DGELU) && !aux) return CLIMB_EINVAL;
-  if (epi == EPI_GELU && !aux_out) return CLIMB_EINVAL;
+  if ((epi == EPI_RESID || epi == EPI_DGELU || epi == EPI_DSILU || epi == EPI_RESID2) && !aux) return CLIMB_EINVAL;
+  if ((epi == EPI_GELU || epi == EPI_SILU) && !aux_out) return CLIMB_EINVAL;
+  if (epi == EPI_RESID2 && !aux2) return CLIMB_EINVAL;
   auto pick = [](const float* P, long s_r, long s_k, int R, int K_) -> int {
     if (s_k == 1 && (s_r % 4) == 0 && al16(P)) return 1;
     if (s_r == 1 && (s_k % 4) == 0 && al16(P)) return 2;
@@ -187,11 +192,11 @@ extern "C" int climb_gemm_f32(const float* A, long sam, long sak, const float* B
   if (tiles128 >= 192) {
     dim3 grid((N + 127) / 128, (M + 127) / 128);
     hipLaunchKernelGGL((gemm_f32_kernel<128, 128>), grid, dim3(256), 0, st, A, sam, sak, modeA, B, sbn, sbk, modeB, C, ldc, M, N, K, bias, epi, aux,
-                       ldaux, aux_out, ldauxo, beta);
+                       ldaux, aux_out, ldauxo, beta, aux2, ldaux2);
   } else {
     dim3 grid((N + 63) / 64, (M + 63) / 64);
     hipLaunchKernelGGL((gemm_f32_kernel<64, 64>), grid, dim3(256), 0, st, A, sam, sak, modeA, B, sbn, sbk, modeB, C, ldc, M, N, K, bias, epi, aux,
-                       ldaux, aux_out, ldauxo, beta);
+                       ldaux, aux_out, ldauxo, beta, aux2, ldaux2);
   }
   LAUNCH_CHECK();
   return CLIMB_OK;

@@ -20,7 +20,7 @@ from . import _lib
 from .layout import ENC, FlatLayout, VILT_CFG, TASK_ARITH
 
 F32, BF16 = 0, 1
-EPI_NONE, EPI_GELU, EPI_RESID, EPI_DGELU, EPI_TANH = 0, 1, 2, 3, 4
+EPI_NONE, EPI_GELU, EPI_RESID, EPI_DGELU, EPI_TANH, EPI_SILU, EPI_DSILU, EPI_RESID2 = 0, 1, 2, 3, 4, 5, 6, 7
 
 
 def _stream():
@@ -87,6 +87,19 @@ class Workspace:
         self.part = buf((npart,))
         self.dpre = buf((B * T, H))
         self.part2 = buf((T * 2 * H,))
+        # Houlsby adapters (two per layer): sub-layer output y, bottleneck pre-activation z and s = silu(z)
+        self.has_adapters = bool(eng.layout.adapters)
+        if self.has_adapters:
+            r = max(eng.layout.adapters.values())
+            self.r = r
+            self.ya = [buf((M, H), adt) for _ in range(L)]
+            self.yo = [buf((M, H), adt) for _ in range(L)]
+            self.za = [buf((M, r), adt) for _ in range(L)]
+            self.sa = [buf((M, r), adt) for _ in range(L)]
+            self.zo = [buf((M, r), adt) for _ in range(L)]
+            self.so = [buf((M, r), adt) for _ in range(L)]
+            self.dz = buf((M, r), adt)
+            self.dy = buf((M, H), adt)
         self.ones = torch.ones((max(B, 8),), dtype=f32, device=dev)
 
 
@@ -116,9 +129,10 @@ class ViltEngine:
         self.grad_ready_hook: Optional[Callable[[int, int], None]] = None   # (lo, hi) flat range whose grads are final
         self.touched: List[tuple] = []                  # flat ranges that received gradients in the last backward
         self.saved = None
+        self.active_adapter: Optional[str] = None       # name of the adapter applied in forward/backward (None = plain ViLT)
         self.prof = None                                # bench.py: {"kernel": name, "events": [(start, end, flops)]}
         # weight-gradient GEMMs run on a second HIP stream, concurrently with the input-gradient chain they do not feed
-        self.overlap_dw = os.environ.get("CLIMB_AMD_OVERLAP_DW", "1") != "0"
+        self.overlap_dw = os.environ.get("CLIMB_AMD_OVERLAP_DW", "0") != "0"   # measured slower on MI355X (r01): off
         self._side = None
         self._side_pending = None
 
@@ -166,31 +180,16 @@ class ViltEngine:
 
     # ------------------------------------------------------------------ GEMM dispatch
     # forward:  Y[M,N] = X[M,K] W[N,K]^T ; input grad: dX[M,K] = dY[M,N] W[N,K] ; weight grad: dW[N,K] += dY^T X
-    def _fwd(self, X, W_name_or_ptr, bias_ptr, Y, M, N, K, epi=EPI_NONE, aux=None, aux_out=None, ldx=None, ldy=None):
-        st = _stream()
-        ldx = ldx or K
-        ldy = ldy or N
-        if self.precision == "fp32" or not isinstance(X, torch.Tensor) or X.dtype == torch.float32:
-            _lib.call("climb_gemm_f32", X, ldx, 1, W_name_or_ptr, K, 1, Y, ldy, M, N, K, bias_ptr, epi, aux, N, aux_out, N, 0.0, st)
-        else:
-            raise NotImplementedError
+    def _gemm_f32(self, A, sam, sak, Bm, sbn, sbk, C, ldc, M, N, K, bias=None, epi=EPI_NONE, aux=None, ldaux=0, aux_out=None, ldauxo=0, beta=0.0,
+                  aux2=None, ldaux2=0):
+        self._timed_call("gemm_f32", 2.0 * M * N * K, "climb_gemm_f32", A, sam, sak, Bm, sbn, sbk, C, ldc, M, N, K, bias, epi, aux, ldaux, aux_out,
+                         ldauxo, beta, aux2, ldaux2, _stream())
 
-    def _gemm_f32(self, A, sam, sak, Bm, sbn, sbk, C, ldc, M, N, K, bias=None, epi=EPI_NONE, aux=None, ldaux=0, aux_out=None, ldauxo=0, beta=0.0):
-        prof = self.prof
-        if prof is not None and prof["kernel"] == "gemm_f32":
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            _lib.call("climb_gemm_f32", A, sam, sak, Bm, sbn, sbk, C, ldc, M, N, K, bias, epi, aux, ldaux, aux_out, ldauxo, beta, _stream())
-            e1.record()
-            prof["events"].append((e0, e1, 2.0 * M * N * K))
-            return
-        _lib.call("climb_gemm_f32", A, sam, sak, Bm, sbn, sbk, C, ldc, M, N, K, bias, epi, aux, ldaux, aux_out, ldauxo, beta, _stream())
-
-    def linear_fwd(self, X, wname, bname, Y, M, N, K, epi=EPI_NONE, aux=None, aux_out=None):
+    def linear_fwd(self, X, wname, bname, Y, M, N, K, epi=EPI_NONE, aux=None, aux_out=None, aux2=None, out_f32=False):
         if self.precision == "fp32":
-            self._gemm_f32(X, K, 1, self.p(wname), K, 1, Y, N, M, N, K, self.p(bname) if bname else None, epi, aux, N, aux_out, N)
+            self._gemm_f32(X, K, 1, self.p(wname), K, 1, Y, N, M, N, K, self.p(bname) if bname else None, epi, aux, N, aux_out, N, 0.0, aux2, N)
         else:
-            self._bf16_fwd(X, wname, bname, Y, M, N, K, epi, aux, aux_out)
+            self._bf16_fwd(X, wname, bname, Y, M, N, K, epi, aux, aux_out, out_f32=out_f32, aux2=aux2)
 
     def linear_dx(self, dY, wname, dX, M, N, K, epi=EPI_NONE, aux=None):
         """dX[M,K] = dY[M,N] @ W[N,K]   (epi DGELU multiplies by gelu'(aux[M,K]))"""
@@ -264,6 +263,10 @@ class ViltEngine:
             H, Fd = self.cfg["hidden"], self.cfg["ffn"]
             out += [(l + "attention.attention.query.weight", 3 * H, H), (l + "attention.output.dense.weight", H, H),
                     (l + "intermediate.dense.weight", Fd, H), (l + "output.dense.weight", H, Fd)]
+            for t, r in self.layout.adapters.items():
+                for site in ("attention.output", "output"):
+                    a = f"{l}{site}.adapters.{t}."
+                    out += [(a + "adapter_down.0.weight", r, H), (a + "adapter_up.weight", H, r)]
         return out
 
     def _build_shadow(self):
@@ -326,14 +329,14 @@ class ViltEngine:
         else:
             _lib.call(name, *args)
 
-    def _bf16_fwd(self, X, wname, bname, Y, M, N, K, epi=EPI_NONE, aux=None, aux_out=None, out_f32=False):
+    def _bf16_fwd(self, X, wname, bname, Y, M, N, K, epi=EPI_NONE, aux=None, aux_out=None, out_f32=False, aux2=None):
         self._timed_call("gemm_bf16_nt", 2.0 * M * N * K, "climb_gemm_bf16_nt", X, K, self.sp(wname), K, Y, N, F32 if out_f32 else BF16, M, N, K,
-                         self.p(bname) if bname else None, epi, aux, N, aux_out, N, _stream())
+                         self.p(bname) if bname else None, epi, aux, N, aux_out, N, aux2, N, _stream())
 
     def _bf16_dx(self, dY, wname, dX, M, N, K, epi=EPI_NONE, aux=None):
         # dX[M,K] = dY[M,N] W[N,K] = dY (W^T)^T : NT GEMM against the transposed shadow [K,N]
         self._timed_call("gemm_bf16_nt", 2.0 * M * N * K, "climb_gemm_bf16_nt", dY, N, self.spt(wname), N, dX, K, BF16, M, K, N, None, epi, aux, K,
-                         None, 0, _stream())
+                         None, 0, None, 0, _stream())
 
     def _bf16_dw(self, dY, X, wname, M, N, K, dbias=None):
         self._timed_call("gemm_bf16_tn", 2.0 * M * N * K, "climb_gemm_bf16_tn", dY, N, X, K, self.g(wname), K, M, N, K, dbias, _stream())
@@ -371,6 +374,8 @@ class ViltEngine:
         _lib.call("climb_assemble_image", ws.proj, self.p(e + "cls_token"), self.p(e + "position_embeddings"),
                   self.p(e + "token_type_embeddings.weight"), ws.img_type, x0, B, T, ws.NP, ws.S_pad, H, st)
         M = ws.M
+        ad = self.active_adapter
+        r = self.layout.adapters[ad] if ad is not None else 0
         for i in range(cfg["layers"]):
             l = f"{ENC}encoder.layer.{i}."
             x = ws.x[i]
@@ -379,11 +384,24 @@ class ViltEngine:
             # fused QKV projection: q/k/v weights are adjacent in the flat buffer (HF:325-327 as one [2304,768] GEMM)
             self.linear_fwd(ws.xn[i], l + "attention.attention.query.weight", l + "attention.attention.query.bias", ws.qkv[i], M, 3 * H, H)
             self.attn_fwd(ws.qkv[i], ws.key_bias, ws.ctx[i], ws.lse[i], B, ws.S_pad)
-            self.linear_fwd_resid(ws.ctx[i], l + "attention.output.dense.weight", l + "attention.output.dense.bias", ws.h1[i], M, H, H, x)
+            if ad is None:
+                self.linear_fwd_resid(ws.ctx[i], l + "attention.output.dense.weight", l + "attention.output.dense.bias", ws.h1[i], M, H, H, x)
+            else:   # h1 = x + y + up(silu(down(y))),  y = Wo ctx + bo
+                a_ = f"{l}attention.output.adapters.{ad}."
+                self.linear_fwd(ws.ctx[i], l + "attention.output.dense.weight", l + "attention.output.dense.bias", ws.ya[i], M, H, H)
+                self.linear_fwd(ws.ya[i], a_ + "adapter_down.0.weight", a_ + "adapter_down.0.bias", ws.sa[i], M, r, H, EPI_SILU, None, ws.za[i])
+                self.linear_fwd(ws.sa[i], a_ + "adapter_up.weight", a_ + "adapter_up.bias", ws.h1[i], M, H, r, EPI_RESID2, x, None, ws.ya[i], out_f32=True)
             _lib.call("climb_layernorm_fwd", ws.h1[i], H, self.p(l + "layernorm_after.weight"), self.p(l + "layernorm_after.bias"), cfg["ln_eps"],
                       ws.hn[i], H, adt, ws.mean2[i], ws.rstd2[i], M, H, st)
             self.linear_fwd(ws.hn[i], l + "intermediate.dense.weight", l + "intermediate.dense.bias", ws.a[i], M, Fd, H, EPI_GELU, None, ws.u[i])
-            self.linear_fwd_resid(ws.a[i], l + "output.dense.weight", l + "output.dense.bias", ws.x[i + 1], M, H, Fd, ws.h1[i])
+            if ad is None:
+                self.linear_fwd_resid(ws.a[i], l + "output.dense.weight", l + "output.dense.bias", ws.x[i + 1], M, H, Fd, ws.h1[i])
+            else:
+                a_ = f"{l}output.adapters.{ad}."
+                self.linear_fwd(ws.a[i], l + "output.dense.weight", l + "output.dense.bias", ws.yo[i], M, H, Fd)
+                self.linear_fwd(ws.yo[i], a_ + "adapter_down.0.weight", a_ + "adapter_down.0.bias", ws.so[i], M, r, H, EPI_SILU, None, ws.zo[i])
+                self.linear_fwd(ws.so[i], a_ + "adapter_up.weight", a_ + "adapter_up.bias", ws.x[i + 1], M, H, r, EPI_RESID2, ws.h1[i], None, ws.yo[i],
+                                out_f32=True)
         xL = ws.x[cfg["layers"]]
         # final LayerNorm only on the row the pooler consumes (token 0 = text [CLS]); `last_hidden_state` is never
         # used by CLiMB (REF/modeling/vilt.py:123-124), so the other S-1 rows are dead work we skip
@@ -391,7 +409,7 @@ class ViltEngine:
                   ws.clsn, H, F32, ws.fmean, ws.frstd, B, H, st)
         self._gemm_f32(ws.clsn, H, 1, self.p(ENC + "pooler.dense.weight"), H, 1, ws.pooled, H, B, H, H, self.p(ENC + "pooler.dense.bias"), EPI_TANH)
         if save:
-            self.saved = dict(ws=ws, input_ids=input_ids, token_type_ids=token_type_ids)
+            self.saved = dict(ws=ws, input_ids=input_ids, token_type_ids=token_type_ids, adapter=ad)
         return ws.pooled
 
     def linear_fwd_f32out(self, X, wname, bname, Y, M, N, K):
@@ -441,6 +459,8 @@ class ViltEngine:
         lnb = _lib.query("climb_layernorm_bwd_rows_per_block")
         nlnb = (M + lnb - 1) // lnb
         rg = self.requires_grad
+        ad = sv.get("adapter")
+        r = self.layout.adapters[ad] if ad is not None else 0
         # pooler: pooled = tanh(clsn Wp^T + b)
         _lib.call("climb_elementwise", 2, dpooled, ws.pooled, ws.dpre, B * H, 1.0, st)
         pw, pb = ENC + "pooler.dense.weight", ENC + "pooler.dense.bias"
@@ -460,22 +480,33 @@ class ViltEngine:
         csr = _lib.query("climb_colsum_rows_per_block")
         last = f"{ENC}encoder.layer.{cfg['layers'] - 1}."
         _lib.call("climb_colsum", ws.dres, H, F32, None if self.precision == "fp32" else ws.dres_c, H, ws.part, M, H, st)
-        if first_layer < cfg["layers"]:
+        if first_layer < cfg["layers"] and ad is None:
             self.bias_grad_from_part(ws.part.data_ptr(), H, (M + csr - 1) // csr, last + "output.dense.bias", H)
         for i in range(cfg["layers"] - 1, first_layer - 1, -1):
             l = f"{ENC}encoder.layer.{i}."
             # MLP: x_{i+1} = h1 + W2 gelu(u) + b2,  u = W1 hn + b1
-            self.linear_dx(ws.dres_c, l + "output.dense.weight", ws.du, M, H, Fd, EPI_DGELU, ws.u[i])
-            self.dw_async(ws.dres_c, ws.a[i], l + "output.dense.weight", M, H, Fd)
+            if ad is None:
+                dy = ws.dres_c
+                self.dw_async(dy, ws.a[i], l + "output.dense.weight", M, H, Fd)
+            else:   # x_{i+1} = h1 + y + up(silu(down(y))): d(y) = d(x_{i+1}) + down^T(silu'(z) * up^T d(x_{i+1}))
+                dy = self.adapter_backward(ws, f"{l}output.adapters.{ad}.", ws.so[i], ws.zo[i], ws.yo[i], M, H, r)
+                self.dw_async(dy, ws.a[i], l + "output.dense.weight", M, H, Fd, l + "output.dense.bias", ws)
+            self.linear_dx(dy, l + "output.dense.weight", ws.du, M, H, Fd, EPI_DGELU, ws.u[i])
             self.dw_async(ws.du, ws.hn[i], l + "intermediate.dense.weight", M, Fd, H, l + "intermediate.dense.bias", ws)
             self.linear_dx(ws.du, l + "intermediate.dense.weight", ws.dhn, M, Fd, H)
             self.join_side()          # LN backward overwrites d(residual) that dW2 is reading
             _lib.call("climb_layernorm_bwd", ws.dhn, H, adt, ws.h1[i], H, ws.mean2[i], ws.rstd2[i], self.p(l + "layernorm_after.weight"),
                       ws.dres, H, ws.dres, H, None if self.precision == "fp32" else ws.dres_c, H, ws.part, M, H, st)
-            self.reduce3(ws.part, nlnb, H, l + "layernorm_after.weight", l + "layernorm_after.bias", l + "attention.output.dense.bias")
+            self.reduce3(ws.part, nlnb, H, l + "layernorm_after.weight", l + "layernorm_after.bias",
+                         l + "attention.output.dense.bias" if ad is None else None)
             # attention: h1 = x + Wo ctx + bo
-            self.dw_async(ws.dres_c, ws.ctx[i], l + "attention.output.dense.weight", M, H, H)
-            self.linear_dx(ws.dres_c, l + "attention.output.dense.weight", ws.dctx, M, H, H)
+            if ad is None:
+                dy = ws.dres_c
+                self.dw_async(dy, ws.ctx[i], l + "attention.output.dense.weight", M, H, H)
+            else:
+                dy = self.adapter_backward(ws, f"{l}attention.output.adapters.{ad}.", ws.sa[i], ws.za[i], ws.ya[i], M, H, r)
+                self.dw_async(dy, ws.ctx[i], l + "attention.output.dense.weight", M, H, H, l + "attention.output.dense.bias", ws)
+            self.linear_dx(dy, l + "attention.output.dense.weight", ws.dctx, M, H, H)
             self.attn_bwd(ws.qkv[i], ws.key_bias, ws.dctx, ws.ctx[i], ws.lse[i], ws.delta, ws.dqkv, B, ws.S_pad)
             # q/k/v weights and biases are adjacent: one [2304,768] weight-gradient GEMM + one [2304] bias reduction
             self.dw_async(ws.dqkv, ws.xn[i], l + "attention.attention.query.weight", M, 3 * H, H, l + "attention.attention.query.bias", ws)
@@ -486,12 +517,21 @@ class ViltEngine:
                 _lib.call("climb_layernorm_bwd", ws.dxn, H, adt, ws.x[i], H, ws.mean1[i], ws.rstd1[i], self.p(l + "layernorm_before.weight"),
                           ws.dres, H, ws.dres, H, None if self.precision == "fp32" else ws.dres_c, H, ws.part, M, H, st)
                 self.reduce3(ws.part, nlnb, H, l + "layernorm_before.weight", l + "layernorm_before.bias",
-                             f"{ENC}encoder.layer.{i - 1}.output.dense.bias" if i > first_layer else None)
+                             f"{ENC}encoder.layer.{i - 1}.output.dense.bias" if (i > first_layer and ad is None) else None)
             self.join_side()
             self._ready(*lay.layer_range[i])
         if embeddings and first_layer == 0:
             self.embedding_backward(ws, sv)
             self._ready(*lay.embed_range)
+
+    def adapter_backward(self, ws: Workspace, a_: str, s_act, z_pre, y_in, M, H, r):
+        """Backward of out = resid + y + up(silu(down(y))) given d(out) in ws.dres (fp32) / ws.dres_c (operand dtype).
+        Accumulates the adapter's parameter gradients and returns d(y) = d(out) + down^T(silu'(z) * up^T d(out))."""
+        self.dw_async(ws.dres_c, s_act, a_ + "adapter_up.weight", M, H, r, a_ + "adapter_up.bias", ws)
+        self.linear_dx(ws.dres_c, a_ + "adapter_up.weight", ws.dz, M, H, r, EPI_DSILU, z_pre)
+        self.dw_async(ws.dz, y_in, a_ + "adapter_down.0.weight", M, r, H, a_ + "adapter_down.0.bias", ws)
+        self.linear_dx(ws.dz, a_ + "adapter_down.0.weight", ws.dy, M, r, H, EPI_RESID, ws.dres)
+        return ws.dy
 
     def embedding_backward(self, ws: Workspace, sv):
         cfg = self.cfg

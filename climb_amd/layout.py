@@ -90,8 +90,24 @@ def _numel(shape):
     return n
 
 
+ADAPTER_SITES = ("attention.output", "output")     # Houlsby: after the attention out-projection and after the MLP down-projection
+
+
+def adapter_param_shapes(layer: int, task: str, r: int, H: int = 768) -> "OrderedDict[str, tuple]":
+    """adapter-transformers v3 naming (`<site>.adapters.<name>.adapter_down.0.{weight,bias}`, `.adapter_up.{weight,bias}`),
+    relative to the ViltModel.  Parity UNPINNED: the GLAMOR fork is absent (REF/.gitmodules:1-3)."""
+    s: "OrderedDict[str, tuple]" = OrderedDict()
+    for site in ADAPTER_SITES:
+        a = f"encoder.layer.{layer}.{site}.adapters.{task}."
+        s[a + "adapter_down.0.weight"] = (r, H)
+        s[a + "adapter_down.0.bias"] = (r,)
+        s[a + "adapter_up.weight"] = (H, r)
+        s[a + "adapter_up.bias"] = (H,)
+    return s
+
+
 def physical_encoder_order(names: List[str], layers: int) -> List[str]:
-    """Forward order with q/k/v weights adjacent and q/k/v biases adjacent inside each layer."""
+    """Forward order with q/k/v weights adjacent and q/k/v biases adjacent inside each layer; a layer's adapters follow it."""
     out = [n for n in names if n.startswith("embeddings.")]
     for i in range(layers):
         l = f"encoder.layer.{i}."
@@ -102,6 +118,7 @@ def physical_encoder_order(names: List[str], layers: int) -> List[str]:
                 l + "layernorm_after.weight", l + "layernorm_after.bias",
                 l + "intermediate.dense.weight", l + "intermediate.dense.bias",
                 l + "output.dense.weight", l + "output.dense.bias"]
+        out += [n for n in names if n.startswith(l) and ".adapters." in n]
     out += ["layernorm.weight", "layernorm.bias", "pooler.dense.weight", "pooler.dense.bias"]
     assert sorted(out) == sorted(names)
     return out
@@ -110,13 +127,18 @@ def physical_encoder_order(names: List[str], layers: int) -> List[str]:
 class FlatLayout:
     """offset (in elements) / shape of every learner parameter inside the flat buffer."""
 
-    def __init__(self, tasks: List[str], task_cfgs: Dict[str, dict], cfg: dict = VILT_CFG, modality_rows: int = None):
+    def __init__(self, tasks: List[str], task_cfgs: Dict[str, dict], cfg: dict = VILT_CFG, modality_rows: int = None,
+                 adapters: Dict[str, int] = None):
         self.cfg = cfg
         self.tasks = list(tasks)
         if modality_rows is None:
             modality_rows = 3 if "nlvr2" in tasks else 2   # REF/modeling/vilt.py:176-177
         self.modality_rows = modality_rows
+        self.adapters = dict(adapters or {})               # adapter name (task key) -> bottleneck width
         enc = encoder_param_shapes(modality_rows, cfg)
+        for t, r in self.adapters.items():
+            for i in range(cfg["layers"]):
+                enc.update(adapter_param_shapes(i, t, r, cfg["hidden"]))
         self.shapes: "OrderedDict[str, tuple]" = OrderedDict((ENC + n, s) for n, s in enc.items())
         for t in tasks:
             for n, s in head_param_shapes(t, task_cfgs[t], cfg["hidden"]).items():
@@ -126,21 +148,17 @@ class FlatLayout:
         self.physical: List[str] = phys
         self.offset: Dict[str, int] = {}
         off = 0
-        self.layer_range: List[Tuple[int, int]] = []
-        self.embed_range = (0, 0)
-        cur_layer, layer_start = None, 0
         for n in phys:
             self.offset[n] = off
             off += (_numel(self.shapes[n]) + ALIGN - 1) // ALIGN * ALIGN
-            if n == ENC + "embeddings.token_type_embeddings.weight":
-                self.embed_range = (0, off)
-            if n.endswith("output.dense.bias") and ".encoder.layer." in n and ".attention." not in n:
-                start = self.layer_range[-1][1] if self.layer_range else self.embed_range[1]
-                self.layer_range.append((start, off))
             if n == ENC + "pooler.dense.bias":
                 self.encoder_end = off
         self.total = off
-        self.top_range = (self.layer_range[-1][1], self.encoder_end)     # final norm + pooler
+        starts = [self.offset[f"{ENC}encoder.layer.{i}.layernorm_before.weight"] for i in range(cfg["layers"])]
+        top = self.offset[ENC + "layernorm.weight"]
+        self.embed_range = (0, starts[0])
+        self.layer_range: List[Tuple[int, int]] = [(starts[i], starts[i + 1] if i + 1 < len(starts) else top) for i in range(len(starts))]
+        self.top_range = (top, self.encoder_end)                          # final norm + pooler
         self.head_range = {}
         for t in tasks:
             ns = [n for n in phys if n.startswith(f"task_layer.{t}.")]

@@ -19,7 +19,7 @@ import torch
 import torch.nn as nn
 
 from ..engine import ViltEngine
-from ..layout import ENC, FlatLayout, VILT_CFG, encoder_param_shapes
+from ..layout import ENC, FlatLayout, VILT_CFG, encoder_param_shapes, adapter_param_shapes
 from ..optim import FusedAdamW
 from .continual_learner import ContinualLearner, EncoderWrapper
 
@@ -77,6 +77,41 @@ class ViltModelParams(_Node):
                                             modality_type_vocab_size=modality_rows, num_hidden_layers=cfg["layers"])
         _build_tree(self, encoder_param_shapes(modality_rows, cfg))
         self.active_adapters = None
+        self.adapter_dims: Dict[str, int] = {}
+
+    # adapter-transformers style methods the reference reaches through `self.vilt_encoder.vilt.<method>`
+    # (REF/modeling/vilt.py:357-367).  Arithmetic: Houlsby bottleneck, parity unpinned (see cl_algorithms/adapters.py).
+    def add_adapter(self, name: str, config=None):
+        if name in self.adapter_dims:
+            return
+        cfg = dict(config or {})
+        rf = int(cfg.get("reduction_factor", 16))
+        H = self.config.hidden_size
+        r = max(8, (H // rf) // 8 * 8)
+        dev = next(self.parameters()).device
+        for i in range(self.config.num_hidden_layers):
+            shapes = adapter_param_shapes(i, name, r, H)
+            _build_tree(self, shapes)
+        import zlib
+        gen = torch.Generator().manual_seed(zlib.crc32(name.encode()))
+        with torch.no_grad():
+            for n, p in self.named_parameters():
+                if f".adapters.{name}." in n:
+                    new = torch.zeros(p.shape) if n.endswith(".bias") else torch.empty(p.shape).normal_(0.0, 0.02, generator=gen)
+                    p.data = new.to(dev)
+        self.adapter_dims[name] = r
+
+    def train_adapter(self, name: str):
+        """Freeze the base model, train only adapter `name` (heads live outside this module and stay trainable)."""
+        tag = f".adapters.{name}."
+        for n, p in self.named_parameters():
+            p.requires_grad = tag in n
+        self.active_adapters = name
+
+    def set_active_adapters(self, name):
+        if name is not None and name not in self.adapter_dims:
+            raise KeyError(f"no adapter named {name!r}")
+        self.active_adapters = name
 
 
 # ----------------------------------------------------------------------------------------------- engine host
@@ -113,6 +148,8 @@ class _EngineHost:
         eng = self._engine
         if eng is None or eng.flat is None:
             return False
+        if eng.layout.adapters != self.encoder.vilt.adapter_dims:      # adapters were added after binding
+            return False
         for n in self._sentinels:
             p = self._params[n]
             if p.data_ptr() != eng.p(n):
@@ -124,7 +161,7 @@ class _EngineHost:
             named = self.named()
             dev = next(iter(named.values())).device
             rows = named[ENC + "embeddings.token_type_embeddings.weight"].shape[0]
-            layout = FlatLayout(self.tasks, self._arith(), modality_rows=rows)
+            layout = FlatLayout(self.tasks, self._arith(), modality_rows=rows, adapters=self.encoder.vilt.adapter_dims)
             for n, p in named.items():
                 assert tuple(p.shape) == tuple(layout.shapes[n]), (n, tuple(p.shape), layout.shapes[n])
             eng = ViltEngine(layout, dev, self.precision, self._arith())
@@ -142,6 +179,7 @@ class _EngineHost:
         eng = self._engine
         for n, p in self._params.items():
             eng.requires_grad[n] = p.requires_grad
+        eng.active_adapter = self.encoder.vilt.active_adapters
         return eng
 
     # --- gradient views
@@ -478,13 +516,13 @@ class ViltContinualLearner(ContinualLearner):
 
     # --- adapters (REF:357-367); arithmetic of the absent GLAMOR fork is unpinned, see climb_amd/cl_algorithms/adapters.py
     def add_adapter(self, task_key: str, config: Dict):
-        raise NotImplementedError("Houlsby adapters are not built yet (SURVEY.md row A19; BASELINE.json configs[2])")
+        self.vilt_encoder.vilt.add_adapter(task_key, config)
 
     def train_adapter(self, task_key: str):
-        raise NotImplementedError("Houlsby adapters are not built yet")
+        self.vilt_encoder.vilt.train_adapter(task_key)
 
     def set_active_adapters(self, task_key: str):
-        raise NotImplementedError("Houlsby adapters are not built yet")
+        self.vilt_encoder.vilt.set_active_adapters(task_key)
 
     def get_active_adapters(self):
         return self.vilt_encoder.vilt.active_adapters

@@ -60,8 +60,9 @@ int climb_colsum_rows_per_block(void);
 /* ---- GEMM ------------------------------------------------------------------------------------------------------ */
 /* nn.Linear forward / input-grad / weight-grad (HF:325-327, :366-369, :397-400, :410-414; REF/modeling/vilt.py:190-195)
  * on v_mfma_f32_32x32x2_f32 (exact fp32):  C[m,n] = epi(sum_k A[m*sam+k*sak] * B[n*sbn+k*sbk] + bias[n]) + beta*C[m,n]
- * epi: 0 none, 1 GELU (aux_out = pre-activation), 2 + aux residual, 3 * gelu'(aux), 4 tanh */
-int climb_gemm_f32(const float* A, long sam, long sak, const float* B, long sbn, long sbk, float* C, long ldc, int M, int N, int K, const float* bias, int epi, const float* aux, long ldaux, float* aux_out, long ldauxo, float beta, void* stream);
+ * epi: 0 none, 1 GELU (aux_out = pre-activation), 2 + aux residual, 3 * gelu'(aux), 4 tanh, 5 SiLU (aux_out = pre-activation),
+ * 6 * silu'(aux), 7 + aux + aux2 (adapter up-projection with both residuals) */
+int climb_gemm_f32(const float* A, long sam, long sak, const float* B, long sbn, long sbk, float* C, long ldc, int M, int N, int K, const float* bias, int epi, const float* aux, long ldaux, float* aux_out, long ldauxo, float beta, const float* aux2, long ldaux2, void* stream);
 
 /* ---- attention ------------------------------------------------------------------------------------------------- */
 /* HF:322-351 ViltSelfAttention: softmax(Q K^T / sqrt(d) + key_bias) V per (batch, head); scores never leave the CU.
@@ -99,8 +100,9 @@ int climb_transpose_bf16_batched(const void* src, void* dst, const long* table, 
 /* ---- bf16 throughput path (v_mfma_f32_32x32x16_bf16, fp32 accumulate) --------------------------------------------------- */
 /* nn.Linear forward and input-gradient GEMMs (HF:325-327, :366-369, :397-400, :410-414):
  * C[M,N] (c_dtype) = epi(A[M,K] B[N,K]^T + bias); A,B bf16, K contiguous.  epi 1: aux_out (bf16) = pre-activation;
- * epi 2: aux = fp32 residual [M,N]; epi 3: aux = bf16 pre-activation (multiplies by gelu'). */
-int climb_gemm_bf16_nt(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int c_dtype, int M, int N, int K, const float* bias, int epi, const void* aux, long ldaux, void* aux_out, long ldauxo, void* stream);
+ * epi 2: aux = fp32 residual [M,N]; epi 3: aux = bf16 pre-activation (multiplies by gelu'); epi 5/6: SiLU / silu' likewise;
+ * epi 7: aux = fp32 residual, aux2 = bf16 residual (Houlsby adapter up-projection: out = up(s) + sublayer_out + x). */
+int climb_gemm_bf16_nt(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int c_dtype, int M, int N, int K, const float* bias, int epi, const void* aux, long ldaux, void* aux_out, long ldauxo, const void* aux2, long ldaux2, void* stream);
 /* weight gradient: C[N,K] (fp32) += A[M,N]^T B[M,K]; reduction over tokens via LDS transpose reads, split over M with fp32 atomics;
  * dbias (optional, fp32 [N]) += column sums of A = the bias gradient of the same layer (one extra MFMA against an all-ones operand) */
 int climb_gemm_bf16_tn(const void* A, long lda, const void* B, long ldb, float* C, long ldc, int M, int N, int K, float* dbias, void* stream);

@@ -207,8 +207,14 @@ def visual_embed_fixed(P, pixel_values, pixel_mask, cfg=CFG):
     return x, mask
 
 
-def encoder_layer(P, i, x, key_bias, cfg=CFG):
-    """HF:430-451 ViltLayer (pre-LN): h1 = x + Wo.Attn(LN_b(x)); y = h1 + W2.GELU(W1.LN_a(h1))."""
+def _adapt(P, prefix, y):
+    return adapter_forward(y, P[prefix + "adapter_down.0.weight"], P[prefix + "adapter_down.0.bias"], P[prefix + "adapter_up.weight"],
+                           P[prefix + "adapter_up.bias"])
+
+
+def encoder_layer(P, i, x, key_bias, cfg=CFG, adapter=None):
+    """HF:430-451 ViltLayer (pre-LN): h1 = x + Wo.Attn(LN_b(x)); y = h1 + W2.GELU(W1.LN_a(h1)).
+    `adapter` = name of a Houlsby adapter applied to both sub-layer outputs before their residual adds (UNPINNED)."""
     l = f"{ENC}encoder.layer.{i}."
     B, S, H = x.shape
     nh, hd = cfg["heads"], cfg["head_dim"]
@@ -225,14 +231,19 @@ def encoder_layer(P, i, x, key_bias, cfg=CFG):
     probs = torch.softmax(scores, dim=-1)
     ctx = torch.matmul(probs, v).permute(0, 2, 1, 3).reshape(B, S, H)
     attn = F.linear(ctx, P[l + "attention.output.dense.weight"], P[l + "attention.output.dense.bias"])
+    if adapter is not None:
+        attn = _adapt(P, f"{l}attention.output.adapters.{adapter}.", attn)
     h1 = attn + x                                                      # HF:440
     hn = layer_norm(h1, P[l + "layernorm_after.weight"], P[l + "layernorm_after.bias"], cfg["ln_eps"])
     a = gelu(F.linear(hn, P[l + "intermediate.dense.weight"], P[l + "intermediate.dense.bias"]))
-    return F.linear(a, P[l + "output.dense.weight"], P[l + "output.dense.bias"]) + h1   # HF:410-414
+    out = F.linear(a, P[l + "output.dense.weight"], P[l + "output.dense.bias"])
+    if adapter is not None:
+        out = _adapt(P, f"{l}output.adapters.{adapter}.", out)
+    return out + h1                                                    # HF:410-414
 
 
 def encoder_forward(P, enc: Dict[str, torch.Tensor], image_token_type_idx: int = 1, cfg=CFG,
-                    return_sequence: bool = False):
+                    return_sequence: bool = False, adapter=None):
     """REF/modeling/vilt.py:111-124 -> HF:536-647 ViltModel.forward -> pooler_output [B,768]."""
     e = ENC + "embeddings."
     text = text_embed(P, enc["input_ids"], enc["token_type_ids"], cfg)
@@ -246,7 +257,7 @@ def encoder_forward(P, enc: Dict[str, torch.Tensor], image_token_type_idx: int =
     key_bias = torch.zeros(mask.shape, dtype=x.dtype)
     key_bias = key_bias.masked_fill(mask == 0, torch.finfo(x.dtype).min)
     for i in range(cfg["layers"]):
-        x = encoder_layer(P, i, x, key_bias, cfg)
+        x = encoder_layer(P, i, x, key_bias, cfg, adapter)
     seq = layer_norm(x, P[ENC + "layernorm.weight"], P[ENC + "layernorm.bias"], cfg["ln_eps"])  # HF:637
     pooled = torch.tanh(F.linear(seq[:, 0], P[ENC + "pooler.dense.weight"], P[ENC + "pooler.dense.bias"]))  # HF:657-663
     return (pooled, seq) if return_sequence else pooled
@@ -271,7 +282,7 @@ def head_forward(P, task_key: str, pooled, training: bool = False, dropout_keep:
 
 
 def learner_forward(P, task_key: str, enc: Dict[str, torch.Tensor], training: bool = False,
-                    dropout_keep: Optional[torch.Tensor] = None, cfg=CFG):
+                    dropout_keep: Optional[torch.Tensor] = None, cfg=CFG, adapter=None):
     """REF/modeling/vilt.py:218-350: single image / multi-image (NLVR2) / multi-choice (VCR).
 
     `enc` is what `process_inputs` returns for the flattened lists:
@@ -279,7 +290,7 @@ def learner_forward(P, task_key: str, enc: Dict[str, torch.Tensor], training: bo
       vcr:   texts flattened [b*4] (choice j of example i at row 4*i+j, REF:331,:334), images [b]."""
     tc = TASKS[task_key]
     if tc["model_type"] == "classification" and tc["num_images"] == 1:
-        pooled = encoder_forward(P, enc, 1, cfg)
+        pooled = encoder_forward(P, enc, 1, cfg, adapter=adapter)
         return pooled, head_forward(P, task_key, pooled, cfg=cfg)
     if tc["model_type"] == "classification":
         n = tc["num_images"]
@@ -290,7 +301,7 @@ def learner_forward(P, task_key: str, enc: Dict[str, torch.Tensor], training: bo
         for i in range(n):                                             # REF:292-303
             e = dict(input_ids=enc["input_ids"], token_type_ids=enc["token_type_ids"],
                      attention_mask=enc["attention_mask"], pixel_values=pv[:, i], pixel_mask=pm[:, i])
-            outs.append(encoder_forward(P, e, i + 1, cfg))
+            outs.append(encoder_forward(P, e, i + 1, cfg, adapter=adapter))
         pooled = torch.cat(outs, dim=-1)                               # REF:304
         return pooled, head_forward(P, task_key, pooled, cfg=cfg)
     nc = tc["num_choices"]
@@ -302,7 +313,7 @@ def learner_forward(P, task_key: str, enc: Dict[str, torch.Tensor], training: bo
     for i in range(nc):                                                # REF:335-345
         e = dict(input_ids=ids[:, i], token_type_ids=tt[:, i], attention_mask=am[:, i],
                  pixel_values=enc["pixel_values"], pixel_mask=enc["pixel_mask"])
-        outs.append(encoder_forward(P, e, 1, cfg))
+        outs.append(encoder_forward(P, e, 1, cfg, adapter=adapter))
     pooled = torch.stack(outs, dim=0).transpose(0, 1)                  # REF:347  [b, nc, H]
     return pooled, head_forward(P, task_key, pooled, training, dropout_keep, cfg)
 
@@ -404,7 +415,7 @@ def adapter_forward(x, down_w, down_b, up_w, up_b):
 
 # ----------------------------------------------------------------------- train step
 def train_step(P, task_key, enc, target, opt_state=None, lr=None, ewc=None, wd=1e-2, eps=1e-8,
-               dropout_keep=None, trainable=None):
+               dropout_keep=None, trainable=None, adapter=None):
     """REF/train/visionlanguage_tasks/train_vqa.py:135-174 (train_nlvr2.py:110-150 identical but for the loss).
 
     Returns (loss, (pooled, logits), ewc_loss, grads).  If `opt_state` is given an AdamW step follows
@@ -412,7 +423,7 @@ def train_step(P, task_key, enc, target, opt_state=None, lr=None, ewc=None, wd=1
     `ewc` = (fisher, theta_star, lam) or None.  `trainable` = optional set of names with requires_grad."""
     names = list(P.keys()) if trainable is None else [n for n in P if n in trainable]
     leaves = {n: (P[n].detach().clone().requires_grad_(True) if n in names else P[n].detach()) for n in P}
-    pooled, logits = learner_forward(leaves, task_key, enc, training=True, dropout_keep=dropout_keep)
+    pooled, logits = learner_forward(leaves, task_key, enc, training=True, dropout_keep=dropout_keep, adapter=adapter)
     loss = task_loss(task_key, logits, target)
     el = None
     total = loss

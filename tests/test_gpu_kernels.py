@@ -39,7 +39,7 @@ def test_gemm_f32_forward_layout(M, N, K):
     ref = A.double() @ W.double().t() + bias.double()
     Ad, Wd, bd = A.to(dev), W.to(dev), bias.to(dev)
     C = torch.empty(M, N, device=dev)
-    _lib.call("climb_gemm_f32", Ad, K, 1, Wd, K, 1, C, N, M, N, K, bd, 0, None, 0, None, 0, 0.0, _st())
+    _lib.call("climb_gemm_f32", Ad, K, 1, Wd, K, 1, C, N, M, N, K, bd, 0, None, 0, None, 0, 0.0, None, 0, _st())
     assert _rel(C, ref) < 2e-6
 
 
@@ -55,27 +55,27 @@ def test_gemm_f32_strided_variants_and_epilogues():
     dYd, Wd, Xd, Ud = dY.to(dev), W.to(dev), X.to(dev), U.to(dev)
     # input grad with GELU' epilogue: dX = (dY W) * gelu'(U)
     dX = torch.empty(M, K, device=dev)
-    _lib.call("climb_gemm_f32", dYd, N, 1, Wd, 1, K, dX, K, M, K, N, None, 3, Ud, K, None, 0, 0.0, _st())
+    _lib.call("climb_gemm_f32", dYd, N, 1, Wd, 1, K, dX, K, M, K, N, None, 3, Ud, K, None, 0, 0.0, None, 0, _st())
     Ur = U.double().requires_grad_(True)
     gelu(Ur).backward(dY.double() @ W.double())
     assert _rel(dX, Ur.grad) < 5e-6
     # weight grad, accumulating: dW += dY^T X
     dW0 = torch.randn(N, K, generator=g)
     dW = dW0.to(dev).clone()
-    _lib.call("climb_gemm_f32", dYd, 1, N, Xd, 1, K, dW, K, N, K, M, None, 0, None, 0, None, 0, 1.0, _st())
+    _lib.call("climb_gemm_f32", dYd, 1, N, Xd, 1, K, dW, K, N, K, M, None, 0, None, 0, None, 0, 1.0, None, 0, _st())
     assert _rel(dW, dW0.double() + dY.double().t() @ X.double()) < 2e-6
     # forward with GELU (pre-activation saved), residual and tanh epilogues
     b = torch.randn(N, generator=g).to(dev)
     Y = torch.empty(M, N, device=dev)
     pre = torch.empty(M, N, device=dev)
-    _lib.call("climb_gemm_f32", Xd, K, 1, Wd, K, 1, Y, N, M, N, K, b, 1, None, 0, pre, N, 0.0, _st())
+    _lib.call("climb_gemm_f32", Xd, K, 1, Wd, K, 1, Y, N, M, N, K, b, 1, None, 0, pre, N, 0.0, None, 0, _st())
     ref_pre = X.double() @ W.double().t() + b.cpu().double()
     assert _rel(pre, ref_pre) < 2e-6 and _rel(Y, gelu(ref_pre)) < 5e-6
     R = torch.randn(M, N, generator=g).to(dev)
-    _lib.call("climb_gemm_f32", Xd, K, 1, Wd, K, 1, Y, N, M, N, K, b, 2, R, N, None, 0, 0.0, _st())
+    _lib.call("climb_gemm_f32", Xd, K, 1, Wd, K, 1, Y, N, M, N, K, b, 2, R, N, None, 0, 0.0, None, 0, _st())
     assert _rel(Y, ref_pre + R.cpu().double()) < 2e-6
     Xs = (X * 0.05).to(dev)                     # keep tanh out of saturation so the check is meaningful
-    _lib.call("climb_gemm_f32", Xs, K, 1, Wd, K, 1, Y, N, M, N, K, b, 4, None, 0, None, 0, 0.0, _st())
+    _lib.call("climb_gemm_f32", Xs, K, 1, Wd, K, 1, Y, N, M, N, K, b, 4, None, 0, None, 0, 0.0, None, 0, _st())
     assert _rel(Y, torch.tanh((X * 0.05).double() @ W.double().t() + b.cpu().double())) < 5e-6
 
 
@@ -249,17 +249,17 @@ def test_gemm_bf16_nt(M, N, K):
     ref = A.double() @ W.double().t() + bias.double()
     Ad, Wd, bd = A.to(dev), W.to(dev), bias.to(dev)
     C32 = torch.empty(M, N, device=dev)
-    _lib.call("climb_gemm_bf16_nt", Ad, K, Wd, K, C32, N, 0, M, N, K, bd, 0, None, 0, None, 0, _st())
+    _lib.call("climb_gemm_bf16_nt", Ad, K, Wd, K, C32, N, 0, M, N, K, bd, 0, None, 0, None, 0, None, 0, _st())
     assert _rel(C32, ref) < 1e-5
     C16 = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
     U = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
-    _lib.call("climb_gemm_bf16_nt", Ad, K, Wd, K, C16, N, 1, M, N, K, bd, 1, None, 0, U, N, _st())
+    _lib.call("climb_gemm_bf16_nt", Ad, K, Wd, K, C16, N, 1, M, N, K, bd, 1, None, 0, U, N, None, 0, _st())
     assert _rel(U.float(), ref) < 5e-3 and _rel(C16.float(), gelu(ref)) < 5e-3
     R = torch.randn(M, N, generator=g).to(dev)
-    _lib.call("climb_gemm_bf16_nt", Ad, K, Wd, K, C32, N, 0, M, N, K, bd, 2, R, N, None, 0, _st())
+    _lib.call("climb_gemm_bf16_nt", Ad, K, Wd, K, C32, N, 0, M, N, K, bd, 2, R, N, None, 0, None, 0, _st())
     assert _rel(C32, ref + R.cpu().double()) < 1e-5
     Uin = _bf(torch.randn(M, N, generator=g)).to(dev)
-    _lib.call("climb_gemm_bf16_nt", Ad, K, Wd, K, C16, N, 1, M, N, K, None, 3, Uin, N, None, 0, _st())
+    _lib.call("climb_gemm_bf16_nt", Ad, K, Wd, K, C16, N, 1, M, N, K, None, 3, Uin, N, None, 0, None, 0, _st())
     ur = Uin.cpu().double().requires_grad_(True)
     gelu(ur).backward(A.double() @ W.double().t())
     assert _rel(C16.float(), ur.grad) < 5e-3

@@ -372,3 +372,66 @@ def test_bf16_mode_step_vs_oracle(golden_dir):
     o_loss2, _, _, _ = vo.train_step(P2, "vqa", enc, target)
     _close(loss2, o_loss2, BF16_TOL, "loss after one AdamW step")
     assert abs(float(loss2) - float(loss)) > 1e-3 * abs(float(loss)), "the update must change the loss"
+
+
+# ------------------------------------------------------------------------------------------------ Houlsby adapters (unpinned)
+@pytest.mark.parametrize("precision,tol", [("fp32", TOL), ("bf16", 4e-2)])
+def test_houlsby_adapters_vs_oracle_restatement(precision, tol):
+    """BASELINE.json configs[2] arithmetic.  The GLAMOR adapter fork is absent, so this pins the HIP path to the oracle's
+    restatement of public adapter-transformers semantics (out = y + up(swish(down(y)))), not to the reference."""
+    from climb_amd.cl_algorithms import AdapterHandler
+    tasks = ["vqa", "nlvr2"]
+    model, _ = make_model(tasks, 42, precision=precision)
+    args = types.SimpleNamespace(adapter_config="houlsby", adapter_reduction_factor=16, ordered_cl_tasks=tasks)
+    handler = AdapterHandler("vanilla", args)
+    handler.add_adapters_to_model(model)
+    handler.activate_adapter_for_training(task_key="vqa", model=model)
+    assert model.get_active_adapters() == "vqa"
+    n_ad = sum(p.numel() for n, p in model.named_parameters() if ".adapters.vqa." in n)
+    assert n_ad == 12 * 2 * (768 * 48 * 2 + 48 + 768)                      # ~1.8 M trainable per task (SURVEY A19)
+    # make the adapters non-trivial and deterministic, then mirror the weights into the oracle
+    g = torch.Generator().manual_seed(7)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if ".adapters." in n:
+                p.copy_((torch.randn(p.shape, generator=g) * (0.05 if n.endswith("weight") else 0.02)).to(p.device))
+    P = {n: p.detach().cpu().clone() for n, p in model.named_parameters()}
+    trainable = {n for n, p in model.named_parameters() if p.requires_grad}
+    assert all((".adapters.vqa." in n) or n.startswith("task_layer.") for n in trainable)
+    B = 2
+    enc = vo.synthetic_encodings(B, seed=1)
+    target = vo.synthetic_vqa_targets(B, seed=1)
+    images, texts = enc_to_inputs(enc)
+    model.train()
+    loss, (pooled, logits), _, _ = model.fused_forward_backward("vqa", images, texts, target)
+    o_loss, (o_pooled, o_logits), _, oG = vo.train_step(P, "vqa", enc, target, trainable=trainable, adapter="vqa")
+    _close(pooled, o_pooled, tol, "pooled")
+    _close(logits, o_logits, tol, "logits")
+    _close(loss, o_loss, tol, "loss")
+    G = grads_of(model)
+    assert set(G) == set(oG), set(G) ^ set(oG)                              # frozen base: no gradients at all
+    worst = 0.0
+    for n in oG:
+        if precision == "fp32":
+            worst = max(worst, _close(G[n], oG[n], tol, n))
+        else:
+            worst = max(worst, abs(float(G[n].double().norm()) - float(oG[n].double().norm())) / (float(oG[n].double().norm()) + 1e-30))
+    print(f"adapters[{precision}]: worst gradient error {worst:.2e}")
+    assert worst < (tol if precision == "fp32" else 6e-2)
+    # optimizer step touches adapters + the vqa head only
+    before = {n: p.detach().clone() for n, p in model.named_parameters()}
+    opt = model.create_optimizer({"lr": 1e-3, "weight_decay": 1e-2, "adam_epsilon": 1e-8})
+    opt.step()
+    opt.zero_grad()
+    for n, p in model.named_parameters():
+        changed = not torch.equal(p.detach(), before[n])
+        assert changed == ((".adapters.vqa." in n) or n.startswith("task_layer.vqa.")), n
+    # switching the active adapter changes the function; switching back restores it (no interference between tasks)
+    model.eval()
+    with torch.no_grad():
+        l_vqa = model(task_key="vqa", images=images, texts=texts)[1].clone()
+        handler.activate_adapter_for_eval("nlvr2", model)
+        l_other = model(task_key="vqa", images=images, texts=texts)[1].clone()
+        handler.activate_adapter_for_eval("vqa", model)
+        l_back = model(task_key="vqa", images=images, texts=texts)[1].clone()
+    assert torch.equal(l_vqa, l_back) and not torch.allclose(l_vqa, l_other)

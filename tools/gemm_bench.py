@@ -32,7 +32,7 @@ for name, N, K, cdt, epi in [("qkv fwd", 2304, 768, 1, 0), ("out fwd +res", 768,
     bias = torch.randn(N, device=dev)
     aux = torch.randn(M, N, device=dev) if epi == 2 else (torch.randn(M, N, device=dev).bfloat16() if epi == 3 else None)
     auxo = torch.empty(M, N, device=dev, dtype=torch.bfloat16) if epi == 1 else None
-    t = timeit(lambda: _lib.call("climb_gemm_bf16_nt", A, K, W, K, C, N, cdt, M, N, K, bias, epi, aux, N, auxo, N, st()))
+    t = timeit(lambda: _lib.call("climb_gemm_bf16_nt", A, K, W, K, C, N, cdt, M, N, K, bias, epi, aux, N, auxo, N, None, 0, st()))
     f = 2.0 * M * N * K
     tot_t += t; tot_f += f
     print(f"NT {name:14s} N={N:5d} K={K:5d}: {t*1e6:8.1f} us  {f/t/1e12:7.1f} TF")
