@@ -60,9 +60,15 @@ def main():
     model = create_continual_learner_map["vilt"](model_name_or_path="random-init:42", ordered_cl_tasks=tasks, model_config=model_configs["vilt"],
                                                  task_configs=task_configs, device=dev, precision=args.precision)
     model.train()
-    if world > 1:
+    ddp = None
+    if world > 1 or os.environ.get("CLIMB_AMD_FORCE_DDP") == "1":
+        if not dist.is_initialized():       # single-rank smoke of the RCCL path
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29512")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
         from climb_amd.parallel import GradientAllReducer
-        GradientAllReducer(model)       # broadcasts rank 0's weights, hooks bucketed all-reduce into the backward
+        ddp = GradientAllReducer(model)       # broadcasts rank 0's weights, hooks bucketed all-reduce into the backward
+        ddp.world = max(ddp.world, 2) if os.environ.get("CLIMB_AMD_FORCE_DDP") == "1" else ddp.world
     # synthetic batch, resident in HBM before the timed region (per-rank shard: different seed per rank)
     g = torch.Generator().manual_seed(1 + rank)
     texts = dict(input_ids=torch.randint(0, 30522, (B, T), generator=g).to(dev), token_type_ids=torch.zeros(B, T, dtype=torch.long, device=dev),
@@ -107,6 +113,7 @@ def main():
     dt = float(tmax.item())
     events = eng.prof["events"]
     eng.prof = None
+    in_sync = ddp.replicas_in_sync() if ddp is not None else True
 
     if rank == 0:
         ws = eng.workspace(B, T)
@@ -130,6 +137,9 @@ def main():
                                       "12-layer ViLT-B/32 random-init + VQA head", "batch_per_gpu": B, "global_batch": B * world, "seq_len": ws.S,
                           "seq_len_padded": ws.S_pad, "parallelism": f"dp{world}", "final_loss": round(final_loss, 3)},
                "roofline": roof}
+        if ddp is not None:
+            out["replicas_in_sync"] = in_sync
+            out["allreduce_MB_per_step"] = round(ddp.bytes_reduced / 1e6 / (args.steps + args.warmup), 1)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_steps)
         print(json.dumps(out), flush=True)
@@ -145,7 +155,8 @@ def cpu_baseline(steps: int):
     from oracle import vilt_oracle as vo
     # torch's default intra-op thread count already honours the cgroup / affinity limits of this container
     # (os.cpu_count() does not, and oversubscribing OpenMP threads makes the baseline meaningless)
-    cores = torch.get_num_threads()
+    cores = min(torch.get_num_threads(), int(os.environ.get("CLIMB_CPU_THREADS", "32")))      # 32 threads measured fastest at this size on the EPYC host
+    torch.set_num_threads(cores)
     B = 2
     P = vo.init_params(["vqa"], 42)
     state = {}

@@ -62,14 +62,15 @@ __device__ __forceinline__ void nt_store(const u32x4 (&r)[4], unsigned char* __r
 // LDS-DMA staging (global_load_lds_dwordx4): no VGPR round trip and no ds_write pass -- the register-staged path spends
 // more LDS cycles on its 13-cycle ds_write_b128s than on the fragment reads.  The DMA writes LDS linearly
 // (wave-uniform base + lane*16), so the swizzle is applied on the SOURCE side: the lane that owns LDS slot (row, cpos)
-// fetches logical chunk cpos ^ swz(row) of that row.  Wave w issues instructions 4w..4w+3 of the 16 per tile.
+// fetches logical chunk cpos ^ swz(row) of that row.  A [128][64] tile is 16 wave-instructions, dealt evenly to NW waves.
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void gbl_void_t;
+template <int NW>
 __device__ __forceinline__ void nt_glds(const bf16_t* __restrict__ P, long ld, int row0, int k0, int R, unsigned char* __restrict__ S) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int j = wave * 4 + i;
+  for (int i = 0; i < 16 / NW; ++i) {
+    const int j = wave * (16 / NW) + i;
     const int slot = j * 64 + lane, row = slot >> 3, c = (slot & 7) ^ swz(row);
     int grow = row0 + row;
     grow = grow < R ? grow : R - 1;
@@ -77,109 +78,30 @@ __device__ __forceinline__ void nt_glds(const bf16_t* __restrict__ P, long ld, i
   }
 }
 
-template <typename TO, int EPI, bool GLDS>
-__global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ B, long ldb,
-                                                           TO* __restrict__ C, long ldc, int M, int N, int K, const float* __restrict__ bias,
-                                                           const void* __restrict__ aux, long ldaux, bf16_t* __restrict__ aux_out, long ldauxo,
-                                                           const bf16_t* __restrict__ aux2, long ldaux2) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * GB_BM * GB_BK * 2];   // [buf][A|B][128][64] bf16 = 64 KB
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const int wm = wid >> 1, wn = wid & 1, half = lane >> 5, l31 = lane & 31;
-  // XCD-aware tile order.  Blocks are dealt round-robin to the 8 XCDs (private 4 MB L2 each); remap so that every XCD
-  // owns a CONTIGUOUS chunk of a supertile order: groups of 8 M-tiles, inside a group N-tile-major.  The ~64 workgroups an
-  // XCD runs concurrently then cover ~8 A panels x ~8 B panels (~3 MB at K = 768) instead of 64 A panels x 1 B panel, so
-  // both operands are re-read from that L2, not from HBM / Infinity Cache.
-  const int nbm = (M + GB_BM - 1) / GB_BM, nbn = (N + GB_BN - 1) / GB_BN;
-  int bid = blockIdx.x;
-  {
-    const int nwg = nbm * nbn, q = nwg / 8, rr = nwg % 8, xcd = bid % 8, idx = bid / 8;
-    bid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + idx;      // bijective for any nwg
-  }
-  int tm, tn;
-  {
-    const int per_group = 8 * nbn, grp = bid / per_group, in = bid - grp * per_group;
-    const int rows = min(8, nbm - grp * 8);          // last group may hold fewer than 8 M-tiles
-    tn = in / rows;
-    tm = grp * 8 + (in - tn * rows);
-  }
-  const int m0 = tm * GB_BM, n0 = tn * GB_BN;
-  f32x16 acc[2][2];   // [n block][m block]
+// Epilogue: acc[i][j][4g..4g+3] = C[m][n..n+3] with m = mw + j*32 + (lane&31), n = nw + i*32 + 8g + 4*(lane>>5).
+// Bias for all column groups of the lane is fetched up front so its latency overlaps the first stores.
+template <typename TO, int EPI, int NI>
+__device__ __forceinline__ void nt_epilogue(const f32x16 (&acc)[NI][2], int mw, int nw, int M, int N, TO* __restrict__ C, long ldc,
+                                            const float* __restrict__ bias, const void* __restrict__ aux, long ldaux, bf16_t* __restrict__ aux_out,
+                                            long ldauxo, const bf16_t* __restrict__ aux2, long ldaux2) {
+  const int lane = threadIdx.x & 63, half = lane >> 5, l31 = lane & 31;
+  float4 bv[NI][4];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  u32x4 ra[4], rb[4];
-  if (GLDS) {
-    nt_glds(A, lda, m0, 0, M, smem);
-    nt_glds(B, ldb, n0, 0, N, smem + GB_BM * GB_BK * 2);
-  } else {
-    nt_load(ra, A, lda, m0, 0, M, K);
-    nt_load(rb, B, ldb, n0, 0, N, K);
-    nt_store(ra, smem);
-    nt_store(rb, smem + GB_BM * GB_BK * 2);
-  }
-  __syncthreads();
-  const int nk = (K + GB_BK - 1) / GB_BK;
-  for (int kt = 0; kt < nk; ++kt) {
-    unsigned char* As = smem + (kt & 1) * (2 * GB_BM * GB_BK * 2);
-    unsigned char* Bs = As + GB_BM * GB_BK * 2;
-    if (kt + 1 < nk) {
-      if (GLDS) {
-        unsigned char* An = smem + ((kt + 1) & 1) * (2 * GB_BM * GB_BK * 2);
-        nt_glds(A, lda, m0, (kt + 1) * GB_BK, M, An);
-        nt_glds(B, ldb, n0, (kt + 1) * GB_BK, N, An + GB_BM * GB_BK * 2);
-      } else {
-        nt_load(ra, A, lda, m0, (kt + 1) * GB_BK, M, K);
-        nt_load(rb, B, ldb, n0, (kt + 1) * GB_BK, N, K);
-      }
-    }
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      bf16x8 fa[2], fb[2];
-      const int c = 2 * ks + half;
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int row = wm * 64 + j * 32 + l31;
-        fa[j] = as_bf16x8(*reinterpret_cast<const u32x4*>(As + row * 128 + ((c ^ swz(row)) << 4)));
-      }
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int row = wn * 64 + i * 32 + l31;
-        fb[i] = as_bf16x8(*reinterpret_cast<const u32x4*>(Bs + row * 128 + ((c ^ swz(row)) << 4)));
-      }
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[i], fa[j], acc[i][j], 0, 0, 0);
-    }
-    if (!GLDS && kt + 1 < nk) {
-      unsigned char* An = smem + ((kt + 1) & 1) * (2 * GB_BM * GB_BK * 2);
-      nt_store(ra, An);
-      nt_store(rb, An + GB_BM * GB_BK * 2);
-    }
-    __syncthreads();    // with LDS-DMA in flight the compiler drains vmcnt(0) here: tile kt+1 has landed for every wave
-  }
-  // epilogue: acc[i][j][4g..4g+3] = C[m][n..n+3], m = m0 + wm*64 + j*32 + l31, n = n0 + wn*64 + i*32 + 8g + 4*half
-  // bias for all 8 column groups of this lane is fetched up front so its latency overlaps the first stores
-  float4 bv[2][4];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < NI; ++i)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const int n = n0 + wn * 64 + i * 32 + 8 * g + 4 * half;
+      const int n = nw + i * 32 + 8 * g + 4 * half;
       bv[i][g] = (bias && n < N) ? ld4(bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
-    const int m = m0 + wm * 64 + j * 32 + l31;
+    const int m = mw + j * 32 + l31;
     if (m >= M) continue;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int n = n0 + wn * 64 + i * 32 + 8 * g + 4 * half;
+        const int n = nw + i * 32 + 8 * g + 4 * half;
         if (n >= N) continue;
         float4 v = make_float4(acc[i][j][4 * g] + bv[i][g].x, acc[i][j][4 * g + 1] + bv[i][g].y, acc[i][j][4 * g + 2] + bv[i][g].z,
                                acc[i][j][4 * g + 3] + bv[i][g].w);
@@ -208,16 +130,126 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(const bf16_t* __restr
   }
 }
 
+// NI = 32-column blocks per wave: NI = 2 -> 4 waves (2x2, 64x64 each); NI = 1 -> 8 waves (2x4, 64x32 each: twice the
+// waves per CU hiding LDS-DMA / L2 latency for the same LDS footprint, at 1.5x the fragment reads per MFMA).
+template <typename TO, int EPI, bool GLDS, int NI, int ABL = 0>
+__global__ __launch_bounds__(512 / NI)
+void gemm_bf16_nt_kernel(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ B, long ldb, TO* __restrict__ C, long ldc, int M, int N,
+                         int K, const float* __restrict__ bias, const void* __restrict__ aux, long ldaux, bf16_t* __restrict__ aux_out, long ldauxo,
+                         const bf16_t* __restrict__ aux2, long ldaux2) {
+  constexpr int NW = 8 / NI;                       // waves per workgroup
+  constexpr int WNW = NW / 2;                      // waves along N
+  static_assert(GLDS || NI == 2, "the register-staged fallback is written for 256 threads");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * GB_BM * GB_BK * 2];   // [buf][A|B][128][64] bf16 = 64 KB
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int wm = wid / WNW, wn = wid % WNW, half = lane >> 5, l31 = lane & 31;
+  // XCD-aware tile order.  Blocks are dealt round-robin to the 8 XCDs (private 4 MB L2 each); remap so that every XCD
+  // owns a CONTIGUOUS chunk of a supertile order: groups of 8 M-tiles, inside a group N-tile-major.  The ~64 workgroups an
+  // XCD runs concurrently then cover ~8 A panels x ~8 B panels (~3 MB at K = 768) instead of 64 A panels x 1 B panel, so
+  // both operands are re-read from that L2, not from HBM / Infinity Cache.
+  const int nbm = (M + GB_BM - 1) / GB_BM, nbn = (N + GB_BN - 1) / GB_BN;
+  int bid = blockIdx.x;
+  {
+    const int nwg = nbm * nbn, q = nwg / 8, rr = nwg % 8, xcd = bid % 8, idx = bid / 8;
+    bid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + idx;      // bijective for any nwg
+  }
+  int tm, tn;
+  {
+    const int per_group = 8 * nbn, grp = bid / per_group, in = bid - grp * per_group;
+    const int rows = min(8, nbm - grp * 8);          // last group may hold fewer than 8 M-tiles
+    tn = in / rows;
+    tm = grp * 8 + (in - tn * rows);
+  }
+  const int m0 = tm * GB_BM, n0 = tn * GB_BN;
+  f32x16 acc[NI][2];   // [n block][m block]
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  u32x4 ra[4], rb[4];
+  const int nk = (K + GB_BK - 1) / GB_BK;
+#define KOFF(kt_) ((kt_) * GB_BK)
+  if constexpr (GLDS) {
+    nt_glds<NW>(A, lda, m0, KOFF(0), M, smem);
+    nt_glds<NW>(B, ldb, n0, KOFF(0), N, smem + GB_BM * GB_BK * 2);
+  } else {
+    nt_load(ra, A, lda, m0, KOFF(0), M, K);
+    nt_load(rb, B, ldb, n0, KOFF(0), N, K);
+    nt_store(ra, smem);
+    nt_store(rb, smem + GB_BM * GB_BK * 2);
+  }
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    unsigned char* As = smem + (kt & 1) * (2 * GB_BM * GB_BK * 2);
+    unsigned char* Bs = As + GB_BM * GB_BK * 2;
+    if (kt + 1 < nk && ABL != 1) {
+      if constexpr (GLDS) {
+        unsigned char* An = smem + ((kt + 1) & 1) * (2 * GB_BM * GB_BK * 2);
+        nt_glds<NW>(A, lda, m0, KOFF(kt + 1), M, An);
+        nt_glds<NW>(B, ldb, n0, KOFF(kt + 1), N, An + GB_BM * GB_BK * 2);
+      } else {
+        nt_load(ra, A, lda, m0, KOFF(kt + 1), M, K);
+        nt_load(rb, B, ldb, n0, KOFF(kt + 1), N, K);
+      }
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      bf16x8 fa[2], fb[NI];
+      const int c = 2 * ks + half;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int row = wm * 64 + j * 32 + l31;
+        if (ABL == 2 && kt > 0) { asm volatile("" : "+v"(fa[j])); continue; }      // ablation: no LDS reads after the first tile
+        fa[j] = as_bf16x8(*reinterpret_cast<const u32x4*>(As + row * 128 + ((c ^ swz(row)) << 4)));
+      }
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int row = wn * (32 * NI) + i * 32 + l31;
+        if (ABL == 2 && kt > 0) { asm volatile("" : "+v"(fb[i])); continue; }
+        fb[i] = as_bf16x8(*reinterpret_cast<const u32x4*>(Bs + row * 128 + ((c ^ swz(row)) << 4)));
+      }
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[i], fa[j], acc[i][j], 0, 0, 0);
+    }
+    if constexpr (!GLDS) {
+      if (kt + 1 < nk) {
+        unsigned char* An = smem + ((kt + 1) & 1) * (2 * GB_BM * GB_BK * 2);
+        nt_store(ra, An);
+        nt_store(rb, An + GB_BM * GB_BK * 2);
+      }
+    }
+    __syncthreads();    // with LDS-DMA in flight the compiler drains vmcnt(0) here: tile kt+1 has landed for every wave
+  }
+#undef KOFF
+  nt_epilogue<TO, EPI, NI>(acc, m0 + wm * 64, n0 + wn * (32 * NI), M, N, C, ldc, bias, aux, ldaux, aux_out, ldauxo, aux2, ldaux2);
+}
+
+static int g_nt_waves = 8;     // measured on MI355X (r01): 8 waves 537 TF vs 4 waves 514 TF average over the per-layer shapes
+static int g_nt_abl = 0;      // ablation for measurements only: 1 = no global loads after tile 0, 2 = no LDS reads after tile 0
+extern "C" int climb_set_option(int key, int value) {
+  if (key == 1 && (value == 4 || value == 8)) { g_nt_waves = value; return CLIMB_OK; }
+  if (key == 2) { g_nt_abl = value; return CLIMB_OK; }
+  return CLIMB_EINVAL;
+}
+
 template <typename TO>
 static int nt_dispatch(const bf16_t* A, long lda, const bf16_t* B, long ldb, TO* C, long ldc, int M, int N, int K, const float* bias, int epi,
                        const void* aux, long ldaux, bf16_t* aux_out, long ldauxo, const bf16_t* aux2, long ldaux2, hipStream_t st) {
   const int nwg = ((M + GB_BM - 1) / GB_BM) * ((N + GB_BN - 1) / GB_BN);
-  dim3 grid(nwg), blk(256);
+  dim3 grid(nwg);
   const bool glds = (K % GB_BK) == 0;      // the DMA path cannot zero-fill a ragged K tail
-#define NT_LAUNCH(E)                                                                                                                      \
-  do {                                                                                                                                    \
-    if (glds) hipLaunchKernelGGL((gemm_bf16_nt_kernel<TO, E, true>), grid, blk, 0, st, A, lda, B, ldb, C, ldc, M, N, K, bias, aux, ldaux, aux_out, ldauxo, aux2, ldaux2); \
-    else hipLaunchKernelGGL((gemm_bf16_nt_kernel<TO, E, false>), grid, blk, 0, st, A, lda, B, ldb, C, ldc, M, N, K, bias, aux, ldaux, aux_out, ldauxo, aux2, ldaux2);    \
+#define NT_ARGS A, lda, B, ldb, C, ldc, M, N, K, bias, aux, ldaux, aux_out, ldauxo, aux2, ldaux2
+#define NT_LAUNCH(E)                                                                                                           \
+  do {                                                                                                                         \
+    if (glds && g_nt_abl == 1 && E == EPI_NONE) hipLaunchKernelGGL((gemm_bf16_nt_kernel<TO, EPI_NONE, true, 2, 1>), grid, dim3(256), 0, st, NT_ARGS); \
+    else if (glds && g_nt_abl == 2 && E == EPI_NONE) hipLaunchKernelGGL((gemm_bf16_nt_kernel<TO, EPI_NONE, true, 2, 2>), grid, dim3(256), 0, st, NT_ARGS); \
+    else if (glds && g_nt_waves == 8) hipLaunchKernelGGL((gemm_bf16_nt_kernel<TO, E, true, 1>), grid, dim3(512), 0, st, NT_ARGS);   \
+    else if (glds) hipLaunchKernelGGL((gemm_bf16_nt_kernel<TO, E, true, 2>), grid, dim3(256), 0, st, NT_ARGS);                 \
+    else hipLaunchKernelGGL((gemm_bf16_nt_kernel<TO, E, false, 2>), grid, dim3(256), 0, st, NT_ARGS);                          \
   } while (0)
   switch (epi) {
     case EPI_NONE: NT_LAUNCH(EPI_NONE); break;
@@ -230,6 +262,7 @@ static int nt_dispatch(const bf16_t* A, long lda, const bf16_t* B, long ldb, TO*
     default: return CLIMB_EINVAL;
   }
 #undef NT_LAUNCH
+#undef NT_ARGS
   LAUNCH_CHECK();
   return CLIMB_OK;
 }
@@ -424,6 +457,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_tn_kernel(const bf16_t* __restr
       }
   }
 }
+
 
 // C[N,K] (fp32, ldc) += A[M,N]^T B[M,K]; A, B bf16 row-major (lda, ldb).  N % 8 == 0, K % 8 == 0.
 // dbias (optional, fp32 [N]) += column sums of A  (the bias gradient of the same linear layer, fused)

@@ -26,6 +26,8 @@ int climb_version(void);
 const char* climb_arch(void);
 const char* climb_error_string(int code);
 int climb_device_sync(void);
+/* tuning switches for A/B measurements: key 1 = waves per workgroup of the bf16 NT GEMM (4 or 8) */
+int climb_set_option(int key, int value);
 
 /* ---- embeddings -------------------------------------------------------------------------------------------------- */
 /* HF:237-269 TextEmbeddings.forward + HF:208-210: x[b,t,:] = LN(word[ids]+type[tt]+pos[t])*gamma+beta + modality[0].
