@@ -143,7 +143,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_steps)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 
@@ -155,7 +155,7 @@ def cpu_baseline(steps: int):
     from oracle import vilt_oracle as vo
     # torch's default intra-op thread count already honours the cgroup / affinity limits of this container
     # (os.cpu_count() does not, and oversubscribing OpenMP threads makes the baseline meaningless)
-    cores = min(torch.get_num_threads(), int(os.environ.get("CLIMB_CPU_THREADS", "32")))      # 32 threads measured fastest at this size on the EPYC host
+    cores = min(torch.get_num_threads(), int(os.environ.get("CLIMB_CPU_THREADS", "16")))      # measured on the EPYC 9575F host at B=2: 16 threads 5.6 samples/s, 32 -> 4.1, 64 -> 2.0, 128 -> 0.7
     torch.set_num_threads(cores)
     B = 2
     P = vo.init_params(["vqa"], 42)

@@ -65,12 +65,12 @@ __device__ __forceinline__ void nt_store(const u32x4 (&r)[4], unsigned char* __r
 // fetches logical chunk cpos ^ swz(row) of that row.  A [128][64] tile is 16 wave-instructions, dealt evenly to NW waves.
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void gbl_void_t;
-template <int NW>
+template <int NW, int ROWS = 128>
 __device__ __forceinline__ void nt_glds(const bf16_t* __restrict__ P, long ld, int row0, int k0, int R, unsigned char* __restrict__ S) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-  for (int i = 0; i < 16 / NW; ++i) {
-    const int j = wave * (16 / NW) + i;
+  for (int i = 0; i < ROWS / 8 / NW; ++i) {
+    const int j = wave * (ROWS / 8 / NW) + i;
     const int slot = j * 64 + lane, row = slot >> 3, c = (slot & 7) ^ swz(row);
     int grow = row0 + row;
     grow = grow < R ? grow : R - 1;
@@ -132,7 +132,7 @@ __device__ __forceinline__ void nt_epilogue(const f32x16 (&acc)[NI][2], int mw, 
 
 // NI = 32-column blocks per wave: NI = 2 -> 4 waves (2x2, 64x64 each); NI = 1 -> 8 waves (2x4, 64x32 each: twice the
 // waves per CU hiding LDS-DMA / L2 latency for the same LDS footprint, at 1.5x the fragment reads per MFMA).
-template <typename TO, int EPI, bool GLDS, int NI, int ABL = 0>
+template <typename TO, int EPI, bool GLDS, int NI>
 __global__ __launch_bounds__(512 / NI)
 void gemm_bf16_nt_kernel(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ B, long ldb, TO* __restrict__ C, long ldc, int M, int N,
                          int K, const float* __restrict__ bias, const void* __restrict__ aux, long ldaux, bf16_t* __restrict__ aux_out, long ldauxo,
@@ -184,7 +184,7 @@ void gemm_bf16_nt_kernel(const bf16_t* __restrict__ A, long lda, const bf16_t* _
   for (int kt = 0; kt < nk; ++kt) {
     unsigned char* As = smem + (kt & 1) * (2 * GB_BM * GB_BK * 2);
     unsigned char* Bs = As + GB_BM * GB_BK * 2;
-    if (kt + 1 < nk && ABL != 1) {
+    if (kt + 1 < nk) {
       if constexpr (GLDS) {
         unsigned char* An = smem + ((kt + 1) & 1) * (2 * GB_BM * GB_BK * 2);
         nt_glds<NW>(A, lda, m0, KOFF(kt + 1), M, An);
@@ -201,13 +201,11 @@ void gemm_bf16_nt_kernel(const bf16_t* __restrict__ A, long lda, const bf16_t* _
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int row = wm * 64 + j * 32 + l31;
-        if (ABL == 2 && kt > 0) { asm volatile("" : "+v"(fa[j])); continue; }      // ablation: no LDS reads after the first tile
         fa[j] = as_bf16x8(*reinterpret_cast<const u32x4*>(As + row * 128 + ((c ^ swz(row)) << 4)));
       }
 #pragma unroll
       for (int i = 0; i < NI; ++i) {
         const int row = wn * (32 * NI) + i * 32 + l31;
-        if (ABL == 2 && kt > 0) { asm volatile("" : "+v"(fb[i])); continue; }
         fb[i] = as_bf16x8(*reinterpret_cast<const u32x4*>(Bs + row * 128 + ((c ^ swz(row)) << 4)));
       }
 #pragma unroll
@@ -228,11 +226,74 @@ void gemm_bf16_nt_kernel(const bf16_t* __restrict__ A, long lda, const bf16_t* _
   nt_epilogue<TO, EPI, NI>(acc, m0 + wm * 64, n0 + wn * (32 * NI), M, N, C, ldc, bias, aux, ldaux, aux_out, ldauxo, aux2, ldaux2);
 }
 
+
+// 64 x 128 tile variant (4 waves side by side along N, each 64 x 32; LDS 2 x 24 KB -> three workgroups per CU).
+// Same fragments, swizzle, DMA staging and epilogue; used where 128 x 128 tiles leave the last round of workgroups mostly empty.
+template <typename TO, int EPI>
+__global__ __launch_bounds__(256) void gemm_bf16_nt64_kernel(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ B, long ldb,
+                                                             TO* __restrict__ C, long ldc, int M, int N, int K, const float* __restrict__ bias,
+                                                             const void* __restrict__ aux, long ldaux, bf16_t* __restrict__ aux_out, long ldauxo,
+                                                             const bf16_t* __restrict__ aux2, long ldaux2) {
+  constexpr int ABYTES = 64 * GB_BK * 2, BBYTES = GB_BN * GB_BK * 2, STAGE = ABYTES + BBYTES;     // 8 KB + 16 KB
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
+  const int lane = threadIdx.x & 63, wn = threadIdx.x >> 6, half = lane >> 5, l31 = lane & 31;
+  const int nbm = (M + 63) / 64, nbn = (N + GB_BN - 1) / GB_BN;
+  int bid = blockIdx.x;
+  {
+    const int nwg = nbm * nbn, q = nwg / 8, rr = nwg % 8, xcd = bid % 8, idx = bid / 8;
+    bid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + idx;
+  }
+  int tm, tn;
+  {
+    const int per_group = 16 * nbn, grp = bid / per_group, in = bid - grp * per_group;      // 16 M-tiles of 64 = the same 1024-row supertile
+    const int rows = min(16, nbm - grp * 16);
+    tn = in / rows;
+    tm = grp * 16 + (in - tn * rows);
+  }
+  const int m0 = tm * 64, n0 = tn * GB_BN;
+  f32x16 acc[1][2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[0][j][r] = 0.f;
+  const int nk = K / GB_BK;
+  nt_glds<4, 64>(A, lda, m0, 0, M, smem);
+  nt_glds<4, 128>(B, ldb, n0, 0, N, smem + ABYTES);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const unsigned char* As = smem + (kt & 1) * STAGE;
+    const unsigned char* Bs = As + ABYTES;
+    if (kt + 1 < nk) {
+      unsigned char* An = smem + ((kt + 1) & 1) * STAGE;
+      nt_glds<4, 64>(A, lda, m0, (kt + 1) * GB_BK, M, An);
+      nt_glds<4, 128>(B, ldb, n0, (kt + 1) * GB_BK, N, An + ABYTES);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int c = 2 * ks + half;
+      bf16x8 fa[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int row = j * 32 + l31;
+        fa[j] = as_bf16x8(*reinterpret_cast<const u32x4*>(As + row * 128 + ((c ^ swz(row)) << 4)));
+      }
+      const int rowb = wn * 32 + l31;
+      const bf16x8 fb = as_bf16x8(*reinterpret_cast<const u32x4*>(Bs + rowb * 128 + ((c ^ swz(rowb)) << 4)));
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb, fa[j], acc[0][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  nt_epilogue<TO, EPI, 1>(acc, m0, n0 + wn * 32, M, N, C, ldc, bias, aux, ldaux, aux_out, ldauxo, aux2, ldaux2);
+}
+
+static int g_tn_target = 512;
 static int g_nt_waves = 8;     // measured on MI355X (r01): 8 waves 537 TF vs 4 waves 514 TF average over the per-layer shapes
-static int g_nt_abl = 0;      // ablation for measurements only: 1 = no global loads after tile 0, 2 = no LDS reads after tile 0
+static int g_nt_small_m = 1;   // 64x128 tiles for shapes whose 128x128 tiling quantises badly on 512 workgroup slots
 extern "C" int climb_set_option(int key, int value) {
   if (key == 1 && (value == 4 || value == 8)) { g_nt_waves = value; return CLIMB_OK; }
-  if (key == 2) { g_nt_abl = value; return CLIMB_OK; }
+  if (key == 2) { g_nt_small_m = value; return CLIMB_OK; }
+  if (key == 3 && value > 0) { g_tn_target = value; return CLIMB_OK; }
   return CLIMB_EINVAL;
 }
 
@@ -242,11 +303,15 @@ static int nt_dispatch(const bf16_t* A, long lda, const bf16_t* B, long ldb, TO*
   const int nwg = ((M + GB_BM - 1) / GB_BM) * ((N + GB_BN - 1) / GB_BN);
   dim3 grid(nwg);
   const bool glds = (K % GB_BK) == 0;      // the DMA path cannot zero-fill a ragged K tail
+  // tile-height choice: 2 workgroups of 128x128 (or 3 of 64x128) fit a CU; pick the tiling whose last wave of workgroups
+  // is fuller (the 768-wide GEMMs leave 576 = 512 + 64 tiles of 128x128: a nearly empty second round)
+  const int nwg64 = ((M + 63) / 64) * ((N + GB_BN - 1) / GB_BN);
+  auto waste = [](int tiles, int slots) { int r = tiles % slots; return r == 0 ? 0.0 : (double)(slots - r) / ((tiles + slots - 1) / slots * (double)slots); };
+  const bool use64 = glds && g_nt_small_m == 1 && waste(nwg64, 768) + 0.10 < waste(nwg, 512);
 #define NT_ARGS A, lda, B, ldb, C, ldc, M, N, K, bias, aux, ldaux, aux_out, ldauxo, aux2, ldaux2
 #define NT_LAUNCH(E)                                                                                                           \
   do {                                                                                                                         \
-    if (glds && g_nt_abl == 1 && E == EPI_NONE) hipLaunchKernelGGL((gemm_bf16_nt_kernel<TO, EPI_NONE, true, 2, 1>), grid, dim3(256), 0, st, NT_ARGS); \
-    else if (glds && g_nt_abl == 2 && E == EPI_NONE) hipLaunchKernelGGL((gemm_bf16_nt_kernel<TO, EPI_NONE, true, 2, 2>), grid, dim3(256), 0, st, NT_ARGS); \
+    if (use64) hipLaunchKernelGGL((gemm_bf16_nt64_kernel<TO, E>), dim3(nwg64), dim3(256), 0, st, NT_ARGS); \
     else if (glds && g_nt_waves == 8) hipLaunchKernelGGL((gemm_bf16_nt_kernel<TO, E, true, 1>), grid, dim3(512), 0, st, NT_ARGS);   \
     else if (glds) hipLaunchKernelGGL((gemm_bf16_nt_kernel<TO, E, true, 2>), grid, dim3(256), 0, st, NT_ARGS);                 \
     else hipLaunchKernelGGL((gemm_bf16_nt_kernel<TO, E, false, 2>), grid, dim3(256), 0, st, NT_ARGS);                          \
@@ -366,9 +431,11 @@ __global__ __launch_bounds__(256) void gemm_bf16_tn_kernel(const bf16_t* __restr
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  // bias gradient db[n] = sum_m dY[m][n] rides along as dY^T . 1: the k-tile-0 workgroups issue one extra MFMA per dY
-  // fragment against an all-ones operand (every column of the result holds the column sum)
-  const bool do_bias = dbias != nullptr && k0 == 0 && wk == 0;
+  // bias gradient db[n] = sum_m dY[m][n] rides along as dY^T . 1: one extra MFMA per dY fragment against an all-ones operand
+  // (every column of the result holds the column sum).  The reduction steps are dealt round-robin to the k-tiles that share
+  // this n-tile, so every workgroup carries the same small share of the extra work (no slow tail).
+  const int nkt = (K + 127) / 128, ktile = tile / nbn;
+  const bool do_bias = dbias != nullptr && wk == 0;
   f32x16 accb[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -416,7 +483,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_tn_kernel(const bf16_t* __restr
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-      if (do_bias) {
+      if (do_bias && (t % nkt) == ktile) {
         accb[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], ones, accb[0], 0, 0, 0);
         accb[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1], ones, accb[1], 0, 0, 0);
       }
@@ -450,10 +517,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_tn_kernel(const bf16_t* __restr
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int n = n0 + wn * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (n < N) {
-          if (ATOMIC) atomicAdd(dbias + n, accb[i][r]);
-          else dbias[n] += accb[i][r];
-        }
+        if (n < N) atomicAdd(dbias + n, accb[i][r]);       // several k-tiles (and splits) contribute
       }
   }
 }
@@ -465,7 +529,8 @@ extern "C" int climb_gemm_bf16_tn(const void* A, long lda, const void* B, long l
                                   void* stream) {
   if (M <= 0 || N <= 0 || K <= 0 || (N % 8) || (K % 8) || (lda % 8) || (ldb % 8) || !al16p(A) || !al16p(B)) return CLIMB_EINVAL;
   const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
-  int splits = (512 + tiles - 1) / tiles;                         // aim at ~2 workgroups per CU
+  int splits = g_tn_target / tiles;                               // as many token-range splits as fit ONE round of 2 workgroups per CU
+                                                                  // (measured: 432 workgroups 579 TF vs 576 workgroups 436 TF)
   const int max_splits = (M + 4 * TN_BR - 1) / (4 * TN_BR);       // at least 4 LDS tiles of work per split
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;

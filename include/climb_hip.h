@@ -26,7 +26,7 @@ int climb_version(void);
 const char* climb_arch(void);
 const char* climb_error_string(int code);
 int climb_device_sync(void);
-/* tuning switches for A/B measurements: key 1 = waves per workgroup of the bf16 NT GEMM (4 or 8) */
+/* tuning switches for A/B measurements: key 1 = waves per workgroup of the bf16 NT GEMM (4 or 8); key 2 = allow 64x128 tiles (0/1) */
 int climb_set_option(int key, int value);
 
 /* ---- embeddings -------------------------------------------------------------------------------------------------- */

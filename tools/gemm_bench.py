@@ -25,8 +25,10 @@ def timeit(fn, iters=20):
 
 if os.environ.get("NT_WAVES") is not None:
     _lib.call("climb_set_option", 1, int(os.environ["NT_WAVES"]))
-if os.environ.get("ABL") is not None:
-    _lib.call("climb_set_option", 2, int(os.environ["ABL"]))
+if os.environ.get("TN_TARGET") is not None:
+    _lib.call("climb_set_option", 3, int(os.environ["TN_TARGET"]))
+if os.environ.get("NT_SMALL_M") is not None:
+    _lib.call("climb_set_option", 2, int(os.environ["NT_SMALL_M"]))
 tot_t = tot_f = 0.0
 for name, N, K, cdt, epi in [("qkv fwd", 2304, 768, 1, 0), ("out fwd +res", 768, 768, 0, 2), ("up fwd gelu", 3072, 768, 1, 1), ("down fwd +res", 768, 3072, 0, 2),
                              ("du dgelu", 3072, 768, 1, 3), ("dhn", 768, 3072, 1, 0), ("dctx", 768, 768, 1, 0), ("dxn", 768, 2304, 1, 0)]:
