@@ -435,3 +435,57 @@ def test_houlsby_adapters_vs_oracle_restatement(precision, tol):
         handler.activate_adapter_for_eval("vqa", model)
         l_back = model(task_key="vqa", images=images, texts=texts)[1].clone()
     assert torch.equal(l_vqa, l_back) and not torch.allclose(l_vqa, l_other)
+
+
+# ------------------------------------------------------------------------------------------------ full size (bs = 64) properties
+def _rand_batch(B, seed, dev):
+    g = torch.Generator().manual_seed(seed)
+    texts = dict(input_ids=torch.randint(0, 30522, (B, 40), generator=g), token_type_ids=torch.zeros(B, 40, dtype=torch.long),
+                 attention_mask=torch.ones(B, 40, dtype=torch.long))
+    lens = torch.randint(5, 41, (B,), generator=g)
+    for b in range(B):
+        texts["attention_mask"][b, lens[b]:] = 0
+    pixels = torch.randn(B, 3, 384, 384, generator=g)
+    target = torch.zeros(B, 3129)
+    target[torch.arange(B), torch.randint(0, 3129, (B,), generator=g)] = 1.0
+    return pixels.to(dev), {k: v.to(dev) for k, v in texts.items()}, target.to(dev)
+
+
+def test_full_size_batch_permutation_and_mode_agreement():
+    """BASELINE.json configs[1] size (64 sequences x 185 tokens), where the CPU oracle would take minutes: size-independent
+    properties instead.  (1) samples are independent: permuting the batch permutes pooled/logits and leaves the loss and every
+    gradient unchanged (up to fp32 summation order); (2) the bf16 throughput mode agrees with the fp32 parity mode."""
+    dev = _dev()
+    B = 64
+    pixels, texts, target = _rand_batch(B, 11, dev)
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(3)).to(dev)
+    model, _ = make_model(["vqa"], 42, precision="fp32")
+    model.train()
+    loss, (pooled, logits), _, _ = model.fused_forward_backward("vqa", pixels, texts, target)
+    pooled, logits = pooled.clone(), logits.clone()
+    G = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+    model._host.drop_grads()
+    loss_p, (pooled_p, logits_p), _, _ = model.fused_forward_backward("vqa", pixels[perm], {k: v[perm] for k, v in texts.items()}, target[perm])
+    assert torch.equal(pooled_p, pooled[perm]) and torch.equal(logits_p, logits[perm]), "per-sample outputs must not depend on batch position"
+    _close(loss_p, loss, 1e-5, "loss under permutation")
+    for n, p in model.named_parameters():
+        if p.grad is not None and not n.endswith("attention.key.bias"):
+            _close(p.grad, G[n], 1e-4, f"grad {n} under permutation")
+    assert bool(torch.isfinite(logits).all()) and float(loss) > 0
+    # bf16 mode on the same weights / batch
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    del model
+    torch.cuda.empty_cache()
+    m16, _ = make_model(["vqa"], 42, precision="bf16")
+    m16.load_state_dict(sd)
+    m16.train()
+    loss16, (pooled16, logits16), _, _ = m16.fused_forward_backward("vqa", pixels, texts, target)
+    _close(loss16, loss, BF16_TOL, "bf16 vs fp32 loss")
+    _close(logits16, logits, BF16_TOL, "bf16 vs fp32 logits")
+    _close(pooled16, pooled, 5e-2, "bf16 vs fp32 pooled")
+    agree = float((logits16.argmax(-1) == logits.argmax(-1)).float().mean())
+    print(f"bs=64: bf16/fp32 argmax agreement {agree:.3f}")
+    gq = "vilt_encoder.vilt.encoder.layer.0.attention.attention.query.weight"
+    g16 = dict(m16.named_parameters())[gq].grad
+    rel = float((g16.double().cpu().norm() - G[gq].double().cpu().norm()).abs() / G[gq].double().cpu().norm())
+    assert rel < 3e-2, rel
