@@ -28,11 +28,16 @@ __device__ __forceinline__ bf16x8 to_bf16x8(u32x4 v) {
 }
 __device__ __forceinline__ int crow(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 
-// stage rows [0, nrows) x 64 bf16 of a strided global matrix into the swizzled LDS image
+// stage rows [0, nrows) x 64 bf16 of a strided global matrix into the swizzled LDS image with LDS-DMA
+// (global_load_lds_dwordx4: asynchronous, no VGPRs, no ds_write pass; the destination is linear per wave-instruction, so
+// the swizzle goes on the per-lane SOURCE address).  nrows is a multiple of 8; the caller's __syncthreads() drains vmcnt.
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void gbl_void_t;
 __device__ __forceinline__ void stage_image(unsigned char* __restrict__ S, const bf16_t* __restrict__ src, long ld, int nrows, int tid, int nthreads) {
-  for (int e = tid; e < nrows * 8; e += nthreads) {
-    const int row = e >> 3, c = e & 7;
-    *reinterpret_cast<u32x4*>(S + row * 128 + ((c ^ aswz(row)) << 4)) = *reinterpret_cast<const u32x4*>(src + (long)row * ld + c * 8);
+  const int lane = tid & 63, wave = tid >> 6, nwaves = nthreads >> 6;
+  for (int j = wave; j < nrows / 8; j += nwaves) {
+    const int slot = j * 64 + lane, row = slot >> 3, c = (slot & 7) ^ aswz(row);
+    __builtin_amdgcn_global_load_lds((gbl_void_t*)(src + (long)row * ld + c * 8), (lds_void_t*)(S + j * 1024), 16, 0, 0);
   }
 }
 // row fragment: image row (row0 + lane&31), d = 16*ks + 8*(lane>>5) .. +7
@@ -79,7 +84,7 @@ __device__ __forceinline__ void store_acc(bf16_t* __restrict__ dst, const f32x16
 
 // ------------------------------------------------------------------------------------------------------ forward
 // dynamic LDS: Ks[S_pad][128 B] | Vs[S_pad][128 B] | bias_s[S_pad] f32
-__global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ key_bias,
+__global__ __launch_bounds__(576) void attn_fwd_bf16_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ key_bias,
                                                             bf16_t* __restrict__ ctx, float* __restrict__ lse_out, int S_pad, int heads, float scale) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* Ks = smem;
@@ -147,7 +152,10 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16_t* __rest
   }
 }
 
-static int pick_waves(int NB) { return (NB % 3 == 0) ? 3 : 4; }
+
+// one wave per 32-row block: the per-workgroup latency chain (stage K/V -> load Q -> scores -> softmax -> P.V -> store) is
+// walked once instead of NB/3 times, and a CU holds 3 workgroups x NB waves
+static int pick_waves(int NB) { return NB <= 9 ? NB : 8; }
 
 extern "C" int climb_attn_fwd_bf16(const void* qkv, const float* key_bias, void* ctx, float* lse, int B, int S_pad, int heads, int head_dim,
                                    void* stream) {
@@ -167,8 +175,10 @@ extern "C" int climb_attn_fwd_bf16(const void* qkv, const float* key_bias, void*
 // PHASE 1 (dK, dV):  outer = key block (K, V rows in registers), inner = queries (Q, dO images in LDS)
 //     S = Q K^T, dP = dO V^T, P, dS;  dV^T += dO^T P,  dK^T += Q^T dS
 // dynamic LDS: Xs[S_pad][128 B] | Ys[S_pad][128 B] | bias_s | lse_s | delta_s
+// launch bound 576 (= 9 waves, 3 per SIMD) caps the kernel at 168 VGPRs: three workgroups stay resident per CU, which is worth
+// more than the 17 spilled dwords of phase 1 (measured: 63 us vs 80 us per layer with a 256-thread bound)
 template <int PHASE>
-__global__ __launch_bounds__(256) void attn_bwd_bf16_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ key_bias,
+__global__ __launch_bounds__(576) void attn_bwd_bf16_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ key_bias,
                                                             const bf16_t* __restrict__ dctx, const float* __restrict__ lse,
                                                             const float* __restrict__ delta, bf16_t* __restrict__ dqkv, int S_pad, int heads,
                                                             float scale) {
@@ -262,7 +272,7 @@ extern "C" int climb_attn_bwd_bf16(const void* qkv, const float* key_bias, const
   e = hipFuncSetAttribute((const void*)attn_bwd_bf16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
   const float scale = 1.0f / sqrtf((float)head_dim);
-  const int nthreads = 64 * pick_waves(S_pad / 32);
+  const int nthreads = 64 * ((S_pad / 32) % 3 == 0 ? 3 : 4);     // measured at S_pad = 192: 3-4 waves 63 us, 6 waves 78 us (register pressure)
   hipLaunchKernelGGL((attn_bwd_bf16_kernel<0>), dim3(B * heads), dim3(nthreads), lds, (hipStream_t)stream, (const bf16_t*)qkv, key_bias,
                      (const bf16_t*)dctx, lse, delta, (bf16_t*)dqkv, S_pad, heads, scale);
   LAUNCH_CHECK();
