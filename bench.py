@@ -127,8 +127,14 @@ def main():
         k_flops = sum(f for _, _, f in events) * (ws.S / ws.S_pad)
         k_time = sum(k_ms) * 1e-3
         achieved = k_flops / k_time / 1e12 if k_time > 0 else 0.0
+        traffic = None
+        try:        # HBM bytes per launch from the committed PMC passes (rocprofv3 cannot be driven from inside the timed run)
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+            traffic = tj[dominant]["hbm_bytes_per_launch"] if args.precision == "bf16" and B == 64 else None
+        except Exception:
+            traffic = None
         roof = {"bound": "mfma", "kernel": dominant, "achieved": round(achieved, 2), "peak": PEAK[args.precision], "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK[args.precision], 4), "traffic": None,
+                "frac": round(achieved / PEAK[args.precision], 4), "traffic": traffic,
                 "launches_per_step": len(events) // max(1, n_prof_steps), "event_sampled_steps": n_prof_steps, "avg_launch_us": round(1e3 * sum(k_ms) / max(1, len(k_ms)), 2),
                 "kernel_time_frac_of_step": round(k_time / n_prof_steps / (dt / args.steps), 4),
                 "whole_step_tflops": round(FLOP_PER_SAMPLE * B * args.steps / dt / 1e12, 2),
