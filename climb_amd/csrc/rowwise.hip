@@ -449,13 +449,48 @@ extern "C" int climb_im2col(const float* pixels, void* out, int out_dtype, int B
   return CLIMB_OK;
 }
 
+// Per-sample valid patch extent of a padded, variable-resolution batch (HF:96-99): the processor puts every image top-left
+// on the batch canvas, so h = #valid rows in patch column 0, w = #valid columns in patch row 0 (mask read at each patch's
+// top-left pixel = nearest down-sampling).  dims[b] = {h, w}.
+__global__ void patch_grid_dims_kernel(const long* __restrict__ mask, int Hh, int Ww, int P, int* __restrict__ dims) {
+  const int b = blockIdx.x;
+  const long* m = mask + (long)b * Hh * Ww;
+  if (threadIdx.x == 0) {
+    int h = 0, w = 0;
+    for (int py = 0; py < Hh / P; ++py) h += m[(long)py * P * Ww] != 0;
+    for (int px = 0; px < Ww / P; ++px) w += m[px * P] != 0;
+    dims[2 * b] = h;
+    dims[2 * b + 1] = w;
+  }
+}
+extern "C" int climb_patch_grid_dims(const long* pixel_mask, int B, int H, int W, int P, int* dims, void* stream) {
+  if (B <= 0 || H % P || W % P) return CLIMB_EINVAL;
+  hipLaunchKernelGGL(patch_grid_dims_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, pixel_mask, H, W, P, dims);
+  LAUNCH_CHECK();
+  return CLIMB_OK;
+}
+
+// bilinear (align_corners=True) source taps of output index `o` when a length-`in` axis is resized to `out` (HF:104-111 via
+// torch.nn.functional.interpolate): src = o * (in-1)/(out-1)
+__device__ __forceinline__ void bilinear_tap(int o, int out, int in, int& i0, int& i1, float& l1) {
+  const float scale = out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f;
+  const float src = scale * (float)o;
+  i0 = (int)src;
+  i1 = i0 + (i0 < in - 1 ? 1 : 0);
+  l1 = src - (float)i0;
+}
+
 // Image rows of the embedding (HF:168-173 cls/pos add, HF:211-213 modality add, HF:216 concat):
 //   x[b, T, :]       = cls + pos[0] + modality[type_b]
-//   x[b, T+1+p, :]   = proj[b*NP + p, :] + pos[1+p] + modality[type_b]
+//   x[b, T+1+p, :]   = proj[b*NP + p, :] + pos(p) + modality[type_b]          p in raster order over the gh x gw canvas
 //   x[b, S.., :]     = 0  (rows S..S_pad-1 are padding; masked as keys)
+// dims == NULL: every image fills the canvas and the canvas is the table's own g0 x g0 grid (pos(p) = pos[1+p]).
+// dims != NULL (variable resolution, HF:92-178): patch (py, px) of sample b is valid iff py < h_b and px < w_b; valid patches get
+// the position table resized to (h_b, w_b) on the fly; invalid canvas patches become zero rows and are masked in key_bias
+// (the reference keeps max_b(h*w) randomly ordered rows instead -- same pooled output, see oracle.visual_embed_general).
 __global__ void assemble_image_kernel(const float* __restrict__ proj, const float* __restrict__ cls, const float* __restrict__ pos,
-                                      const float* __restrict__ mod, const int* __restrict__ img_type, float* __restrict__ x, int B, int T,
-                                      int NP, int S_pad, int H) {
+                                      const float* __restrict__ mod, const int* __restrict__ img_type, const int* __restrict__ dims,
+                                      float* __restrict__ x, float* __restrict__ key_bias, int B, int T, int NP, int gw, int g0, int S_pad, int H) {
   const int rows = S_pad - T;
   const long n4 = (long)B * rows * H / 4;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
@@ -463,39 +498,69 @@ __global__ void assemble_image_kernel(const float* __restrict__ proj, const floa
     int c = (int)(e % H); long r = e / H;
     int rr = (int)(r % rows); int b = (int)(r / rows);
     float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (rr <= NP) {
-      float4 p = ld4(pos + (long)rr * H + c), m = ld4(mod + (long)img_type[b] * H + c);
-      float4 v = (rr == 0) ? ld4(cls + c) : ld4(proj + ((long)b * NP + rr - 1) * H + c);
+    bool valid = rr <= NP;
+    if (rr == 0) {
+      float4 p = ld4(pos + c), m = ld4(mod + (long)img_type[b] * H + c), v = ld4(cls + c);
       o = make_float4(v.x + p.x + m.x, v.y + p.y + m.y, v.z + p.z + m.z, v.w + p.w + m.w);
+    } else if (rr <= NP) {
+      float4 p;
+      if (dims) {
+        const int hb = dims[2 * b], wb = dims[2 * b + 1];
+        const int py = (rr - 1) / gw, px = (rr - 1) - py * gw;
+        valid = py < hb && px < wb;
+        if (valid) {
+          int y0, y1, x0, x1; float ly, lx;
+          bilinear_tap(py, hb, g0, y0, y1, ly);
+          bilinear_tap(px, wb, g0, x0, x1, lx);
+          const float4 a00 = ld4(pos + (long)(1 + y0 * g0 + x0) * H + c), a01 = ld4(pos + (long)(1 + y0 * g0 + x1) * H + c);
+          const float4 a10 = ld4(pos + (long)(1 + y1 * g0 + x0) * H + c), a11 = ld4(pos + (long)(1 + y1 * g0 + x1) * H + c);
+          const float w00 = (1.f - ly) * (1.f - lx), w01 = (1.f - ly) * lx, w10 = ly * (1.f - lx), w11 = ly * lx;
+          p = make_float4(w00 * a00.x + w01 * a01.x + w10 * a10.x + w11 * a11.x, w00 * a00.y + w01 * a01.y + w10 * a10.y + w11 * a11.y,
+                          w00 * a00.z + w01 * a01.z + w10 * a10.z + w11 * a11.z, w00 * a00.w + w01 * a01.w + w10 * a10.w + w11 * a11.w);
+        }
+      } else {
+        p = ld4(pos + (long)rr * H + c);
+      }
+      if (valid) {
+        float4 m = ld4(mod + (long)img_type[b] * H + c), v = ld4(proj + ((long)b * NP + rr - 1) * H + c);
+        o = make_float4(v.x + p.x + m.x, v.y + p.y + m.y, v.z + p.z + m.z, v.w + p.w + m.w);
+      }
     }
     st4(x + ((long)b * S_pad + T + rr) * H + c, o);
+    if (dims && c == 0) key_bias[(long)b * S_pad + T + rr] = valid ? 0.f : -3.0e38f;
   }
 }
-extern "C" int climb_assemble_image(const float* proj, const float* cls, const float* pos, const float* mod, const int* img_type, float* x, int B,
-                                    int T, int NP, int S_pad, int H, void* stream) {
-  if (H % 4 || T + 1 + NP > S_pad) return CLIMB_EINVAL;
+extern "C" int climb_assemble_image(const float* proj, const float* cls, const float* pos, const float* mod, const int* img_type, const int* dims,
+                                    float* x, float* key_bias, int B, int T, int NP, int gw, int g0, int S_pad, int H, void* stream) {
+  if (H % 4 || T + 1 + NP > S_pad || (dims == nullptr && NP != g0 * g0) || (dims && !key_bias) || NP % gw) return CLIMB_EINVAL;
   long n4 = (long)B * (S_pad - T) * H / 4;
   int grid = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
-  hipLaunchKernelGGL(assemble_image_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, proj, cls, pos, mod, img_type, x, B, T, NP, S_pad, H);
+  hipLaunchKernelGGL(assemble_image_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, proj, cls, pos, mod, img_type, dims, x, key_bias, B, T, NP,
+                     gw, g0, S_pad, H);
   LAUNCH_CHECK();
   return CLIMB_OK;
 }
 
 // Backward of the image rows.  One thread per (image row rr in [0,NP], 4 columns): loops over the batch.
-//   dproj[b*NP+p, :] = cast(dres[b, T+1+p, :]);  dpos[rr, :] += sum_b dres[b, T+rr, :];  dcls += sum_b dres[b, T, :]
-//   part[rr][type][:] = sum_{b: type_b == type} dres[b, T+rr, :]   (colreduce'd over rr into dmodality by the caller)
+//   dproj[b*NP+p, :] = cast(dres[b, T+1+p, :]) (0 for invalid canvas patches);  dcls += sum_b dres[b, T, :]
+//   part[rr][type][:] = sum_{b: type_b == type, row valid} dres[b, T+rr, :]   (colreduce'd over rr into dmodality by the caller)
+//   dims == NULL: dpos[rr, :] += sum_b dres[b, T+rr, :].   dims != NULL: only dpos[0] here; the patch rows' share of dpos is the
+//   transpose of the bilinear resize, done by pos_interp_bwd_kernel.
 template <typename TO>
-__global__ void image_embed_bwd_kernel(const float* __restrict__ dres, const int* __restrict__ img_type, TO* __restrict__ dproj, float* dpos,
-                                       float* dcls, float* __restrict__ part, int B, int T, int NP, int S_pad, int H, int ntypes) {
+__global__ void image_embed_bwd_kernel(const float* __restrict__ dres, const int* __restrict__ img_type, const int* __restrict__ dims,
+                                       TO* __restrict__ dproj, float* dpos, float* dcls, float* __restrict__ part, int B, int T, int NP, int gw,
+                                       int S_pad, int H, int ntypes) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int per_row = H / 4;
   if (i >= (NP + 1) * per_row) return;
   const int rr = i / per_row, c = (i - rr * per_row) * 4;
+  const int py = rr > 0 ? (rr - 1) / gw : 0, px = rr > 0 ? (rr - 1) - py * gw : 0;
   float4 tot = make_float4(0.f, 0.f, 0.f, 0.f);
   float4 pt[3];
   pt[0] = pt[1] = pt[2] = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int b = 0; b < B; ++b) {
-    float4 v = ld4(dres + ((long)b * S_pad + T + rr) * H + c);
+    const bool valid = rr == 0 || dims == nullptr || (py < dims[2 * b] && px < dims[2 * b + 1]);
+    float4 v = valid ? ld4(dres + ((long)b * S_pad + T + rr) * H + c) : make_float4(0.f, 0.f, 0.f, 0.f);
     tot.x += v.x; tot.y += v.y; tot.z += v.z; tot.w += v.w;
     int ty = img_type[b];
 #pragma unroll
@@ -503,7 +568,7 @@ __global__ void image_embed_bwd_kernel(const float* __restrict__ dres, const int
       if (ty == k) { pt[k].x += v.x; pt[k].y += v.y; pt[k].z += v.z; pt[k].w += v.w; }
     if (rr > 0 && dproj) st4(dproj + ((long)b * NP + rr - 1) * H + c, v);
   }
-  if (dpos) {
+  if (dpos && (rr == 0 || dims == nullptr)) {
     float4 o = ld4(dpos + (long)rr * H + c);
     st4(dpos + (long)rr * H + c, make_float4(o.x + tot.x, o.y + tot.y, o.z + tot.z, o.w + tot.w));
   }
@@ -513,18 +578,62 @@ __global__ void image_embed_bwd_kernel(const float* __restrict__ dres, const int
   }
   for (int k = 0; k < ntypes && k < 3; ++k) st4(part + ((long)rr * ntypes + k) * H + c, pt[k]);
 }
+// Transpose of the per-sample bilinear resize: dpos[1 + ty*g0 + tx, :] += sum_b sum_{py<h_b} sum_{px<w_b} wy(py,ty) wx(px,tx) dres[b, T+1+py*gw+px, :].
+// Gather form (no atomics on the table within a block): one thread per (table row ty, 4 columns) keeps the g0 entries of that row
+// in registers and walks only the output rows whose taps touch ty; batch chunks (blockIdx.y) are combined with atomics.
+#define PIB_G0 12
+__global__ __launch_bounds__(192) void pos_interp_bwd_kernel(const float* __restrict__ dres, const int* __restrict__ dims, float* dpos, int B, int T,
+                                                             int gw, int S_pad, int H, int bchunk) {
+  const int ty = blockIdx.x, c = threadIdx.x * 4;
+  if (c >= H) return;
+  float4 acc[PIB_G0];
+#pragma unroll
+  for (int t = 0; t < PIB_G0; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int b0 = blockIdx.y * bchunk, b1 = min(B, b0 + bchunk);
+  for (int b = b0; b < b1; ++b) {
+    const int hb = dims[2 * b], wb = dims[2 * b + 1];
+    for (int py = 0; py < hb; ++py) {
+      int y0, y1; float ly;
+      bilinear_tap(py, hb, PIB_G0, y0, y1, ly);
+      const float wy = (y0 == ty ? 1.f - ly : 0.f) + (y1 == ty ? ly : 0.f);
+      if (wy == 0.f) continue;
+      const float* row = dres + ((long)b * S_pad + T + 1 + (long)py * gw) * H + c;
+      for (int px = 0; px < wb; ++px) {
+        int x0, x1; float lx;
+        bilinear_tap(px, wb, PIB_G0, x0, x1, lx);
+        const float4 v = ld4(row + (long)px * H);
+        const float w0 = wy * (1.f - lx), w1 = wy * lx;
+#pragma unroll
+        for (int t = 0; t < PIB_G0; ++t) {
+          const float w = (t == x0 ? w0 : 0.f) + (t == x1 ? w1 : 0.f);
+          acc[t].x += w * v.x; acc[t].y += w * v.y; acc[t].z += w * v.z; acc[t].w += w * v.w;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < PIB_G0; ++t) {
+    float* d = dpos + (long)(1 + ty * PIB_G0 + t) * H + c;
+    atomicAdd(d, acc[t].x); atomicAdd(d + 1, acc[t].y); atomicAdd(d + 2, acc[t].z); atomicAdd(d + 3, acc[t].w);
+  }
+}
 // part: (NP+1)*ntypes*H floats
-extern "C" int climb_image_embed_bwd(const float* dres, const int* img_type, void* dproj, int dproj_dtype, float* dpos, float* dcls, float* part,
-                                     int B, int T, int NP, int S_pad, int H, int ntypes, void* stream) {
-  if (H % 4 || ntypes > 3) return CLIMB_EINVAL;
+extern "C" int climb_image_embed_bwd(const float* dres, const int* img_type, const int* dims, void* dproj, int dproj_dtype, float* dpos, float* dcls,
+                                     float* part, int B, int T, int NP, int gw, int g0, int S_pad, int H, int ntypes, void* stream) {
+  if (H % 4 || ntypes > 3 || NP % gw || (dims && g0 != PIB_G0) || H > 768) return CLIMB_EINVAL;
   int n = (NP + 1) * (H / 4);
   hipStream_t st = (hipStream_t)stream;
   if (dproj_dtype == CLIMB_DT_F32)
-    hipLaunchKernelGGL((image_embed_bwd_kernel<float>), dim3((n + 127) / 128), dim3(128), 0, st, dres, img_type, (float*)dproj, dpos, dcls, part, B, T, NP, S_pad, H, ntypes);
+    hipLaunchKernelGGL((image_embed_bwd_kernel<float>), dim3((n + 127) / 128), dim3(128), 0, st, dres, img_type, dims, (float*)dproj, dpos, dcls, part, B, T, NP, gw, S_pad, H, ntypes);
   else if (dproj_dtype == CLIMB_DT_BF16)
-    hipLaunchKernelGGL((image_embed_bwd_kernel<bf16_t>), dim3((n + 127) / 128), dim3(128), 0, st, dres, img_type, (bf16_t*)dproj, dpos, dcls, part, B, T, NP, S_pad, H, ntypes);
+    hipLaunchKernelGGL((image_embed_bwd_kernel<bf16_t>), dim3((n + 127) / 128), dim3(128), 0, st, dres, img_type, dims, (bf16_t*)dproj, dpos, dcls, part, B, T, NP, gw, S_pad, H, ntypes);
   else return CLIMB_EINVAL;
   LAUNCH_CHECK();
+  if (dims && dpos) {
+    const int bchunk = 8;
+    hipLaunchKernelGGL(pos_interp_bwd_kernel, dim3(PIB_G0, (B + bchunk - 1) / bchunk), dim3(192), 0, st, dres, dims, dpos, B, T, gw, S_pad, H, bchunk);
+    LAUNCH_CHECK();
+  }
   return CLIMB_OK;
 }
 

@@ -34,12 +34,14 @@ def _round_up(x, m):
 class Workspace:
     """Activation + scratch buffers for one (B, T) shape; allocated once, reused every step."""
 
-    def __init__(self, eng: "ViltEngine", B: int, T: int):
+    def __init__(self, eng: "ViltEngine", B: int, T: int, gh: int = None, gw: int = None):
         cfg = eng.cfg
         dev = eng.device
         H, Fd, L, nh = cfg["hidden"], cfg["ffn"], cfg["layers"], cfg["heads"]
         self.B, self.T = B, T
-        self.NP = (cfg["image"] // cfg["patch"]) ** 2
+        g0 = cfg["image"] // cfg["patch"]
+        self.gh, self.gw = gh or g0, gw or g0         # patch canvas of the (padded) batch
+        self.NP = self.gh * self.gw
         self.S = T + 1 + self.NP
         self.S_pad = _round_up(self.S, 32)
         self.M = B * self.S_pad
@@ -51,6 +53,7 @@ class Workspace:
             return torch.empty(shape, dtype=dt, device=dev)
         self.key_bias = buf((B, self.S_pad))
         self.img_type = torch.empty((B,), dtype=torch.int32, device=dev)
+        self.dims = torch.empty((B, 2), dtype=torch.int32, device=dev)     # valid patch extent per sample (variable resolution)
         self.tmean, self.trstd = buf((B * T,)), buf((B * T,))
         self.a_patch = buf((B * self.NP, cfg["channels"] * cfg["patch"] ** 2), adt)
         self.proj = buf((B * self.NP, H))
@@ -169,13 +172,14 @@ class ViltEngine:
                 return True
         return False
 
-    def workspace(self, B: int, T: int) -> Workspace:
-        key = (B, T)
+    def workspace(self, B: int, T: int, gh: int = None, gw: int = None) -> Workspace:
+        g0 = self.cfg["image"] // self.cfg["patch"]
+        key = (B, T, gh or g0, gw or g0)
         ws = self._ws.get(key)
         if ws is None:
-            if len(self._ws) >= 3:      # bound HBM use when batch shapes vary (last partial batch, replay batches)
+            if len(self._ws) >= 3:      # bound HBM use when batch shapes vary (last partial batch, replay batches, canvases)
                 self._ws.pop(next(iter(self._ws)))
-            ws = self._ws[key] = Workspace(self, B, T)
+            ws = self._ws[key] = Workspace(self, B, T, gh, gw)
         return ws
 
     # ------------------------------------------------------------------ GEMM dispatch
@@ -346,16 +350,26 @@ class ViltEngine:
         return F32 if self.precision == "fp32" else BF16
 
     # ------------------------------------------------------------------ encoder forward
-    def encoder_forward(self, input_ids, token_type_ids, attention_mask, pixel_values, img_type: torch.Tensor, save: bool = True):
-        """[B,T] int64 ids/types/mask, [B,3,Hh,Ww] fp32 pixels (full-size, unmasked: row F2 is next), img_type int32 [B]
-        (HF `image_token_type_idx` per sequence).  Returns pooled [B,H] fp32 (HF:636-663 pooler_output)."""
+    def encoder_forward(self, input_ids, token_type_ids, attention_mask, pixel_values, img_type: torch.Tensor, save: bool = True,
+                        pixel_mask: Optional[torch.Tensor] = None):
+        """[B,T] int64 ids/types/mask, [B,3,Hc,Wc] fp32 pixels, img_type int32 [B] (HF `image_token_type_idx` per sequence).
+        `pixel_mask` None = every image fills the 384x384 canvas (benchmark shape); int64 [B,Hc,Wc] = padded variable-resolution
+        batch as `ViltProcessor` produces it (HF:92-178 path).  Returns pooled [B,H] fp32 (HF:636-663 pooler_output)."""
         cfg, L = self.cfg, self.layout
         B, T = input_ids.shape
         H, Fd, nh = cfg["hidden"], cfg["ffn"], cfg["heads"]
-        if pixel_values.shape[1:] != (cfg["channels"], cfg["image"], cfg["image"]):
-            raise NotImplementedError(f"fixed-resolution path only: expected [B,{cfg['channels']},{cfg['image']},{cfg['image']}] pixels, "
-                                      f"got {tuple(pixel_values.shape)} (variable-resolution visual_embed is SURVEY.md row F2)")
-        ws = self.workspace(B, T)
+        P_ = cfg["patch"]
+        Hc, Wc = int(pixel_values.shape[-2]), int(pixel_values.shape[-1])
+        g0 = cfg["image"] // P_
+        if pixel_values.shape[1] != cfg["channels"] or Hc % P_ or Wc % P_:
+            raise ValueError(f"pixels must be [B,{cfg['channels']},H,W] with H, W multiples of {P_}; got {tuple(pixel_values.shape)}")
+        if pixel_mask is None and (Hc, Wc) != (cfg["image"], cfg["image"]):
+            raise ValueError("a canvas other than 384x384 needs its pixel_mask (variable-resolution path)")
+        gh, gw = Hc // P_, Wc // P_
+        if T + 1 + gh * gw > 288:
+            raise NotImplementedError(f"sequence of {T + 1 + gh * gw} tokens exceeds the 288 this build sizes its attention tiles for")
+        ws = self.workspace(B, T, gh, gw)
+        var = pixel_mask is not None
         st = _stream()
         adt = self.adt
         self.refresh_shadow()
@@ -367,12 +381,15 @@ class ViltEngine:
                   self.p(e + "text_embeddings.token_type_embeddings.weight"), self.p(e + "text_embeddings.position_embeddings.weight"),
                   self.p(e + "text_embeddings.LayerNorm.weight"), self.p(e + "text_embeddings.LayerNorm.bias"),
                   self.p(e + "token_type_embeddings.weight"), cfg["ln_eps"], x0, B, T, ws.S_pad, H, ws.tmean, ws.trstd, st)
-        _lib.call("climb_im2col", pixel_values, ws.a_patch, adt, B, cfg["channels"], cfg["image"], cfg["image"], cfg["patch"], st)
+        _lib.call("climb_im2col", pixel_values, ws.a_patch, adt, B, cfg["channels"], Hc, Wc, P_, st)
+        if var:
+            _lib.call("climb_patch_grid_dims", pixel_mask, B, Hc, Wc, P_, ws.dims, st)
         Kp = cfg["channels"] * cfg["patch"] ** 2
         self.linear_fwd_f32out(ws.a_patch, e + "patch_embeddings.projection.weight", e + "patch_embeddings.projection.bias", ws.proj,
                                B * ws.NP, H, Kp)
         _lib.call("climb_assemble_image", ws.proj, self.p(e + "cls_token"), self.p(e + "position_embeddings"),
-                  self.p(e + "token_type_embeddings.weight"), ws.img_type, x0, B, T, ws.NP, ws.S_pad, H, st)
+                  self.p(e + "token_type_embeddings.weight"), ws.img_type, ws.dims if var else None, x0, ws.key_bias, B, T, ws.NP, gw, g0,
+                  ws.S_pad, H, st)
         M = ws.M
         ad = self.active_adapter
         r = self.layout.adapters[ad] if ad is not None else 0
@@ -409,7 +426,7 @@ class ViltEngine:
                   ws.clsn, H, F32, ws.fmean, ws.frstd, B, H, st)
         self._gemm_f32(ws.clsn, H, 1, self.p(ENC + "pooler.dense.weight"), H, 1, ws.pooled, H, B, H, H, self.p(ENC + "pooler.dense.bias"), EPI_TANH)
         if save:
-            self.saved = dict(ws=ws, input_ids=input_ids, token_type_ids=token_type_ids, adapter=ad)
+            self.saved = dict(ws=ws, input_ids=input_ids, token_type_ids=token_type_ids, adapter=ad, var=var)
         return ws.pooled
 
     def linear_fwd_f32out(self, X, wname, bname, Y, M, N, K):
@@ -540,9 +557,10 @@ class ViltEngine:
         e = ENC + "embeddings."
         rg = self.requires_grad
         ntypes = self.layout.shapes[e + "token_type_embeddings.weight"][0]
-        _lib.call("climb_image_embed_bwd", ws.dres, ws.img_type, ws.dproj, self.adt,
+        g0 = cfg["image"] // cfg["patch"]
+        _lib.call("climb_image_embed_bwd", ws.dres, ws.img_type, ws.dims if sv.get("var") else None, ws.dproj, self.adt,
                   self.g(e + "position_embeddings") if rg[e + "position_embeddings"] else None,
-                  self.g(e + "cls_token") if rg[e + "cls_token"] else None, ws.part, B, T, ws.NP, ws.S_pad, H, ntypes, st)
+                  self.g(e + "cls_token") if rg[e + "cls_token"] else None, ws.part, B, T, ws.NP, ws.gw, g0, ws.S_pad, H, ntypes, st)
         self.bias_grad_from_part(ws.part.data_ptr(), ntypes * H, ws.NP + 1, e + "token_type_embeddings.weight", ntypes * H)
         Kp = cfg["channels"] * cfg["patch"] ** 2
         self.linear_dw(ws.dproj, ws.a_patch, e + "patch_embeddings.projection.weight", B * ws.NP, H, Kp, e + "patch_embeddings.projection.bias", ws)

@@ -237,7 +237,7 @@ class _EngineHost:
         sentinel = self.any_encoder_grad() if torch.is_grad_enabled() else None
         if sentinel is None:
             return eng.encoder_forward(enc["input_ids"], enc["token_type_ids"], enc["attention_mask"], enc["pixel_values"], img_type,
-                                       save=False).clone()
+                                       save=False, pixel_mask=enc.get("pixel_mask")).clone()
         return _EncoderFn.apply(sentinel, self, enc, img_type)
 
     def head(self, task_key: str, pooled_in: torch.Tensor, training: bool) -> torch.Tensor:
@@ -256,7 +256,8 @@ class _EncoderFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, sentinel, host, enc, img_type):
         eng = host._engine
-        pooled = eng.encoder_forward(enc["input_ids"], enc["token_type_ids"], enc["attention_mask"], enc["pixel_values"], img_type)
+        pooled = eng.encoder_forward(enc["input_ids"], enc["token_type_ids"], enc["attention_mask"], enc["pixel_values"], img_type,
+                                     pixel_mask=enc.get("pixel_mask"))
         ctx.host = host
         return pooled.clone()
 
@@ -323,9 +324,7 @@ class ViltEncoderWrapper(EncoderWrapper):
                 enc["token_type_ids"] = torch.zeros_like(enc["input_ids"])
             if "attention_mask" not in enc:
                 enc["attention_mask"] = torch.ones_like(enc["input_ids"])
-            if "pixel_mask" not in enc:
-                pv = enc["pixel_values"]
-                enc["pixel_mask"] = torch.ones((pv.shape[0], pv.shape[-2], pv.shape[-1]), dtype=torch.long, device=pv.device)
+            # no pixel_mask key == "every image fills the 384x384 canvas" (the engine's fixed-resolution fast path)
             return {k: v.to(dev, non_blocking=True) for k, v in enc.items()}
         if self.processor is None:
             raise RuntimeError("no ViltProcessor attached: pass tensor encodings (texts=dict(input_ids=...), images=pixel tensor) "
@@ -429,6 +428,8 @@ class ViltContinualLearner(ContinualLearner):
             nc = tc["num_choices"]
             enc = dict(enc)
             enc["pixel_values"] = enc["pixel_values"].repeat_interleave(nc, dim=0)     # choice j of example i at row nc*i+j (REF:331-334)
+            if "pixel_mask" in enc:
+                enc["pixel_mask"] = enc["pixel_mask"].repeat_interleave(nc, dim=0)
             enc["image_token_type_idx"] = 1
             return enc, ("choice", nc)
         n = tc["num_images"]
@@ -495,7 +496,8 @@ class ViltContinualLearner(ContinualLearner):
         img_type = it if isinstance(it, torch.Tensor) else torch.full((B,), int(it), dtype=torch.int32, device=eng.device)
         if host.ddp is not None:
             host.ddp.begin()
-        pooled_seq = eng.encoder_forward(enc["input_ids"], enc["token_type_ids"], enc["attention_mask"], enc["pixel_values"], img_type)
+        pooled_seq = eng.encoder_forward(enc["input_ids"], enc["token_type_ids"], enc["attention_mask"], enc["pixel_values"], img_type,
+                                         pixel_mask=enc.get("pixel_mask"))
         pooled = self._shape_pooled(pooled_seq, kind)
         logits, hs = eng.head_forward(task_key, pooled, self.training, dropout_keep)
         target = target.to(eng.device, non_blocking=True)

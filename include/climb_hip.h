@@ -38,10 +38,16 @@ int climb_embed_text_fwd(const long* ids, const long* tts, const float* word, co
 int climb_embed_text_bwd(const long* ids, const long* tts, const float* word, const float* type, const float* pos, const float* gamma, const float* mean, const float* rstd, const float* dres, int B, int T, int S_pad, int H, float* dword, float* dpos, float* dpre, float* part, float* part2, void* stream);
 /* HF:292-300 Conv2d(3,768,k=32,s=32) as a GEMM: out[(b*NP + py*gw + px), c*P*P + ky*P + kx] = pixels[b,c,py*P+ky,px*P+kx] */
 int climb_im2col(const float* pixels, void* out, int out_dtype, int B, int C, int H, int W, int P, void* stream);
-/* HF:168-173, :211-216: image rows of the embedding = proj/cls + position + modality[img_type[b]]; padding rows zeroed */
-int climb_assemble_image(const float* proj, const float* cls, const float* pos, const float* mod, const int* img_type, float* x, int B, int T, int NP, int S_pad, int H, void* stream);
-/* backward of the image rows; part[(NP+1)][ntypes][H] modality partials (reduce with climb_colreduce, stride ntypes*H) */
-int climb_image_embed_bwd(const float* dres, const int* img_type, void* dproj, int dproj_dtype, float* dpos, float* dcls, float* part, int B, int T, int NP, int S_pad, int H, int ntypes, void* stream);
+/* HF:96-99: per-sample valid patch extent {h, w} of a padded variable-resolution batch (pixel_mask int64 [B,H,W]) */
+int climb_patch_grid_dims(const long* pixel_mask, int B, int H, int W, int P, int* dims, void* stream);
+/* HF:168-173, :211-216 (+ HF:92-166 when dims != NULL): image rows of the embedding = proj/cls + position + modality[img_type[b]].
+ * Canvas of NP = gh*gw patches in raster order; dims == NULL: all patches valid and gh = gw = g0 (position table used as is);
+ * dims != NULL: patch (py,px) valid iff py < h_b && px < w_b, position table resized bilinearly (align_corners) to (h_b,w_b) on the
+ * fly, invalid patches written as zero rows and masked in key_bias.  Padding rows zeroed. */
+int climb_assemble_image(const float* proj, const float* cls, const float* pos, const float* mod, const int* img_type, const int* dims, float* x, float* key_bias, int B, int T, int NP, int gw, int g0, int S_pad, int H, void* stream);
+/* backward of the image rows; part[(NP+1)][ntypes][H] modality partials (reduce with climb_colreduce, stride ntypes*H);
+ * with dims the position-table gradient is the transpose of the bilinear resize (gather kernel, g0 = 12) */
+int climb_image_embed_bwd(const float* dres, const int* img_type, const int* dims, void* dproj, int dproj_dtype, float* dpos, float* dcls, float* part, int B, int T, int NP, int gw, int g0, int S_pad, int H, int ntypes, void* stream);
 /* HF:623-627 additive key mask as a [B,S_pad] vector: 0 keep, -3e38 masked text token or padding row */
 int climb_key_bias(const long* attn_mask, float* bias, int B, int T, int S, int S_pad, void* stream);
 

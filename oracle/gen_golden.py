@@ -91,6 +91,40 @@ def case_single_image(task, tasks, B, fname, ragged=False, wseed=42, dseed=1):
     return model, P
 
 
+VARRES_SIZES = [(384, 512), (288, 384), (384, 384), (352, 640)]      # (H, W) multiples of 32, shortest edge <= 384, longest <= 640
+
+
+def case_varres(fname, tasks=("vqa", "nlvr2"), wseed=42, dseed=9):
+    """Row F2: padded variable-resolution batch through the reference's own masked visual_embed (random patch selection)."""
+    print(f"[{fname}] variable-resolution batch {VARRES_SIZES}")
+    tasks = list(tasks)
+    B = len(VARRES_SIZES)
+    P = vo.init_params(tasks, wseed)
+    enc = vo.synthetic_varres_encodings(VARRES_SIZES, seed=dseed)
+    target = vo.synthetic_vqa_targets(B, seed=dseed)
+    model = ri.build_reference_learner(tasks, P)
+    model.train()
+    trainer = ri.make_trainer("vqa")
+    batch = {"raw_texts": [""] * B, "images": None, "target_scores": target}
+    model.zero_grad()
+    loss, (pooled, logits), _, _ = run_ref_step(model, trainer, enc, batch)
+    G = ref_grads(model)
+    o_loss, (o_pooled, o_logits), _, o_G = vo.train_step(P, "vqa", enc, target)
+    check("pooled", o_pooled, pooled, 2e-5)
+    check("logits", o_logits, logits, 2e-5)
+    check("loss", o_loss, loss, 2e-5)
+    assert torch.equal(o_logits.argmax(-1), logits.argmax(-1))
+    gn, gh = tensor_summary(G)
+    on, _ = tensor_summary({n: o_G[n] for n in G})
+    check("grad norms (all tensors)", on, gn, 1e-4)
+    pe = vo.ENC + "embeddings.position_embeddings"
+    check("grad position_embeddings (bilinear taps)", o_G[pe], G[pe], 2e-4)
+    np.savez_compressed(os.path.join(OUT, fname), pooled=pooled.detach().numpy(), logits=logits.detach().numpy(),
+                        loss=np.float64(loss.item()), grad_names=np.array(list(G.keys())), grad_norms=gn, grad_heads=gh,
+                        sizes=np.array(VARRES_SIZES),
+                        meta=np.array([f"task=vqa;tasks={','.join(tasks)};B={B};wseed={wseed};dseed={dseed};varres=1"]))
+
+
 def case_steps(fname, steps=10, B=2, tasks=("vqa", "nlvr2"), wseed=42):
     """BASELINE config 1: ViLT sequential-FT on VQAv2, batch=2, 10 steps, with the reference's optimizer + schedule
     (REF/train/visionlanguage_tasks/train_vqa.py:197-205; max_steps=steps so warm-up = 1 step)."""
@@ -322,6 +356,9 @@ def main():
     assert ri.reference_available(), "needs /root/reference (build container only)"
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(os.cpu_count() or 8)
+    if len(sys.argv) > 1 and sys.argv[1] == "varres":
+        case_varres("vqa_b4_varres.npz")
+        return
     case_single_image("vqa", ["vqa", "nlvr2"], 2, "vqa_b2.npz")
     case_single_image("vqa", ["vqa", "nlvr2"], 3, "vqa_b3_ragged.npz", ragged=True, dseed=2)
     case_single_image("snli-ve", ["snli-ve", "vcr"], 2, "snlive_b2.npz", dseed=8)
@@ -331,6 +368,7 @@ def main():
     case_fisher("fisher_3x2.npz")
     case_replay("replay_b2.npz")
     case_steps("vqa_b2_10steps.npz")
+    case_varres("vqa_b4_varres.npz")
     print("golden fixtures written to", OUT)
 
 

@@ -150,6 +150,28 @@ def synthetic_encodings(batch: int, seed: int = 1, text_len: int = 40, image: in
                 pixel_mask=torch.ones(batch, image, image, dtype=torch.long))
 
 
+def synthetic_varres_encodings(sizes, seed: int = 1, text_len: int = 40, cfg: dict = CFG) -> Dict[str, torch.Tensor]:
+    """Padded variable-resolution batch as `ViltProcessor` produces it (HF image_processing: both sides multiples of 32, images
+    placed top-left on a canvas of the batch maximum, zeros elsewhere, `pixel_mask` = 1 on real pixels); ragged text lengths."""
+    rng = np.random.default_rng([seed, 17])
+    B = len(sizes)
+    Hc, Wc = max(h for h, _ in sizes), max(w for _, w in sizes)
+    px = np.zeros((B, cfg["channels"], Hc, Wc), dtype=np.float32)
+    pm = np.zeros((B, Hc, Wc), dtype=np.int64)
+    for b, (h, w) in enumerate(sizes):
+        px[b, :, :h, :w] = rng.standard_normal((cfg["channels"], h, w), dtype=np.float32)
+        pm[b, :h, :w] = 1
+    ids = rng.integers(0, cfg["vocab"], size=(B, text_len), dtype=np.int64)
+    am = np.ones((B, text_len), dtype=np.int64)
+    lens = rng.integers(3, text_len + 1, size=(B,))
+    lens[0] = text_len
+    for b in range(B):
+        am[b, lens[b]:] = 0
+        ids[b, lens[b]:] = 0
+    return dict(input_ids=torch.from_numpy(ids), token_type_ids=torch.zeros(B, text_len, dtype=torch.long), attention_mask=torch.from_numpy(am),
+                pixel_values=torch.from_numpy(px), pixel_mask=torch.from_numpy(pm))
+
+
 def synthetic_vqa_targets(batch: int, seed: int = 1, num_labels: int = 3129) -> torch.Tensor:
     """Soft VQA scores in {0,.3,.6,.9,1} (REF/utils/vqa_utils.py:10-20,48-53): up to three answers per row."""
     rng = np.random.default_rng([seed, 11])
@@ -212,6 +234,41 @@ def _adapt(P, prefix, y):
                            P[prefix + "adapter_up.bias"])
 
 
+def visual_embed_general(P, pixel_values, pixel_mask, cfg=CFG):
+    """HF:92-178 visual_embed for padded, variable-resolution batches, restated deterministically.
+
+    The reference down-samples `pixel_mask` to the patch grid (HF:96-97), reads each sample's valid extent (h, w) off the first
+    column / row (HF:98-99), resizes the 12x12 position table to (h, w) bilinearly with align_corners=True and zero-pads it
+    to the canvas (HF:103-118), then keeps `max_b(h*w)` patches per sample: all valid ones in a RANDOM order plus, for smaller
+    images, randomly chosen invalid (masked) patches (HF:131-166).  Self-attention with masked keys followed by pooling of
+    the text [CLS] row does not depend on the order of patch rows, nor on the content or number of masked rows, so this
+    restatement keeps EVERY canvas patch in raster order, zeroes the invalid ones and masks them: same pooled output up
+    to fp32 reassociation, no RNG, and no host synchronisation to size the sequence."""
+    e = ENC + "embeddings."
+    B, C, Hh, Ww = pixel_values.shape
+    p = cfg["patch"]
+    gh, gw = Hh // p, Ww // p
+    g0 = cfg["image"] // p
+    x = F.conv2d(pixel_values, P[e + "patch_embeddings.projection.weight"], P[e + "patch_embeddings.projection.bias"], stride=p)
+    m = pixel_mask[:, ::p, ::p][:, :gh, :gw]                       # nearest down-sampling picks the top-left pixel of each patch
+    hb = m[:, :, 0].sum(dim=1)
+    wb = m[:, 0, :].sum(dim=1)
+    pos_tab = P[e + "position_embeddings"]
+    spatial = pos_tab[:, 1:, :].transpose(1, 2).reshape(1, -1, g0, g0)
+    pos = torch.zeros(B, x.shape[1], gh, gw, dtype=x.dtype)
+    valid = torch.zeros(B, gh, gw, dtype=torch.long)
+    for b in range(B):
+        h, w = int(hb[b]), int(wb[b])
+        pos[b, :, :h, :w] = F.interpolate(spatial, size=(h, w), mode="bilinear", align_corners=True)[0]
+        valid[b, :h, :w] = 1
+    x = (x + pos) * valid[:, None].to(x.dtype)                     # invalid canvas patches: zero rows, masked below
+    x = x.flatten(2).transpose(1, 2)
+    cls = P[e + "cls_token"].expand(B, -1, -1) + pos_tab[:, :1, :]
+    x = torch.cat([cls, x], dim=1)
+    mask = torch.cat([torch.ones(B, 1, dtype=torch.long), valid.flatten(1)], dim=1)
+    return x, mask
+
+
 def encoder_layer(P, i, x, key_bias, cfg=CFG, adapter=None):
     """HF:430-451 ViltLayer (pre-LN): h1 = x + Wo.Attn(LN_b(x)); y = h1 + W2.GELU(W1.LN_a(h1)).
     `adapter` = name of a Houlsby adapter applied to both sub-layer outputs before their residual adds (UNPINNED)."""
@@ -247,10 +304,16 @@ def encoder_forward(P, enc: Dict[str, torch.Tensor], image_token_type_idx: int =
     """REF/modeling/vilt.py:111-124 -> HF:536-647 ViltModel.forward -> pooler_output [B,768]."""
     e = ENC + "embeddings."
     text = text_embed(P, enc["input_ids"], enc["token_type_ids"], cfg)
-    img, img_mask = visual_embed_fixed(P, enc["pixel_values"], enc["pixel_mask"], cfg)
-    tt = P[e + "token_type_embeddings.weight"]
+    pv, pm = enc["pixel_values"], enc["pixel_mask"]
+    if pv.shape[-2:] == (cfg["image"], cfg["image"]) and bool((pm == 1).all()):
+        img, img_mask = visual_embed_fixed(P, pv, pm, cfg)
+        tt = P[e + "token_type_embeddings.weight"]
+        img = img + tt[image_token_type_idx]                           # HF:211-213
+    else:
+        img, img_mask = visual_embed_general(P, pv, pm, cfg)
+        tt = P[e + "token_type_embeddings.weight"]
+        img = img + tt[image_token_type_idx] * img_mask[..., None].to(img.dtype)      # masked filler rows stay zero
     text = text + tt[0]                                                # HF:208-210
-    img = img + tt[image_token_type_idx]                               # HF:211-213
     x = torch.cat([text, img], dim=1)                                  # HF:216
     mask = torch.cat([enc["attention_mask"], img_mask], dim=1)         # HF:217
     # HF:623-627 create_bidirectional_mask: additive, finfo.min where masked

@@ -489,3 +489,44 @@ def test_full_size_batch_permutation_and_mode_agreement():
     g16 = dict(m16.named_parameters())[gq].grad
     rel = float((g16.double().cpu().norm() - G[gq].double().cpu().norm()).abs() / G[gq].double().cpu().norm())
     assert rel < 3e-2, rel
+
+
+# ------------------------------------------------------------------------------------------------ variable resolution (row F2)
+@pytest.mark.parametrize("precision,tol", [("fp32", TOL), ("bf16", BF16_TOL)])
+def test_variable_resolution_batch_vs_reference(golden_dir, precision, tol):
+    """Padded variable-resolution batch (HF:92-178 masked visual_embed with per-sample bilinear position resize): the HIP path keeps
+    every canvas patch in raster order and masks the invalid ones; the reference shuffles and pads randomly.  Pooled output,
+    logits, loss and all gradients must agree (golden = the reference's own run)."""
+    z = np.load(os.path.join(golden_dir, "vqa_b4_varres.npz"))
+    m = _meta(z)
+    sizes = [tuple(int(v) for v in r) for r in z["sizes"]]
+    B = len(sizes)
+    model, P = make_model(m["tasks"].split(","), int(m["wseed"]), precision=precision)
+    enc = vo.synthetic_varres_encodings(sizes, seed=int(m["dseed"]))
+    target = vo.synthetic_vqa_targets(B, seed=int(m["dseed"]))
+    texts = dict(input_ids=enc["input_ids"], token_type_ids=enc["token_type_ids"], attention_mask=enc["attention_mask"])
+    images = dict(pixel_values=enc["pixel_values"], pixel_mask=enc["pixel_mask"])
+    model.train()
+    loss, (pooled, logits), _, _ = model.fused_forward_backward("vqa", images, texts, target)
+    _close(pooled, z["pooled"], tol, "pooled vs reference")
+    _close(logits, z["logits"], tol, "logits vs reference")
+    _close(loss, z["loss"], tol, "loss vs reference")
+    G = grads_of(model)
+    names = [str(n) for n in z["grad_names"]]
+    norms, heads = _summary(G, names)
+    if precision == "fp32":
+        assert np.array_equal(logits.argmax(-1).cpu().numpy(), z["logits"].argmax(-1))
+        _close(norms, z["grad_norms"], tol, "grad norms vs reference")
+        _close(heads, z["grad_heads"], tol, "grad heads vs reference")
+        _, _, _, oG = vo.train_step(P, "vqa", enc, target)
+        for n in (vo.ENC + "embeddings.position_embeddings", vo.ENC + "embeddings.patch_embeddings.projection.weight", vo.ENC + "embeddings.cls_token",
+                  vo.ENC + "embeddings.token_type_embeddings.weight", vo.ENC + "encoder.layer.0.attention.attention.value.weight"):
+            _close(G[n], oG[n], tol, n)          # incl. the transpose of the bilinear position resize
+    else:
+        big = z["grad_norms"] > 1e-3 * z["grad_norms"].max()
+        assert (np.abs(norms - z["grad_norms"])[big] / z["grad_norms"][big]).max() < 6e-2
+    # the autograd-facing path accepts the same encodings
+    model.eval()
+    with torch.no_grad():
+        out = model(task_key="vqa", images=images, texts=texts)
+    _close(out[1], z["logits"], tol, "eval logits")

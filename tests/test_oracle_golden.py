@@ -183,3 +183,22 @@ def test_poly_schedule_matches_transformers():
         assert abs(opt.param_groups[0]["lr"] - vo.poly_lr(s, 1e-4, 3, 30)) < 1e-12
         opt.step()
         sch.step()
+
+
+def test_variable_resolution_general_visual_embed(golden_dir):
+    """the deterministic restatement (all canvas patches in raster order, invalid ones zeroed + masked) against the
+    reference's random masked patch selection with per-sample bilinear position resize."""
+    z = np.load(os.path.join(golden_dir, "vqa_b4_varres.npz"))
+    m = _meta(z)
+    sizes = [tuple(int(v) for v in r) for r in z["sizes"]]
+    P = vo.init_params(m["tasks"].split(","), int(m["wseed"]))
+    enc = vo.synthetic_varres_encodings(sizes, seed=int(m["dseed"]))
+    target = vo.synthetic_vqa_targets(len(sizes), seed=int(m["dseed"]))
+    loss, (pooled, logits), _, G = vo.train_step(P, "vqa", enc, target)
+    _close(pooled, z["pooled"], 2e-5, "pooled")
+    _close(logits, z["logits"], 2e-5, "logits")
+    _close(loss, z["loss"], 2e-5, "loss")
+    names = [str(n) for n in z["grad_names"]]
+    norms, heads = _summary(G, names)
+    _close(norms, z["grad_norms"], 1e-4, "grad norms")
+    _close(heads, z["grad_heads"], 1e-4, "grad heads")
