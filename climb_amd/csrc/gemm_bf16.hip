@@ -80,8 +80,8 @@ __device__ __forceinline__ void nt_glds(const bf16_t* __restrict__ P, long ld, i
 
 // Epilogue: acc[i][j][4g..4g+3] = C[m][n..n+3] with m = mw + j*32 + (lane&31), n = nw + i*32 + 8g + 4*(lane>>5).
 // Bias for all column groups of the lane is fetched up front so its latency overlaps the first stores.
-template <typename TO, int EPI, int NI>
-__device__ __forceinline__ void nt_epilogue(const f32x16 (&acc)[NI][2], int mw, int nw, int M, int N, TO* __restrict__ C, long ldc,
+template <typename TO, int EPI, int NI, int MJ = 2>
+__device__ __forceinline__ void nt_epilogue(const f32x16 (&acc)[NI][MJ], int mw, int nw, int M, int N, TO* __restrict__ C, long ldc,
                                             const float* __restrict__ bias, const void* __restrict__ aux, long ldaux, bf16_t* __restrict__ aux_out,
                                             long ldauxo, const bf16_t* __restrict__ aux2, long ldaux2) {
   const int lane = threadIdx.x & 63, half = lane >> 5, l31 = lane & 31;
@@ -94,7 +94,7 @@ __device__ __forceinline__ void nt_epilogue(const f32x16 (&acc)[NI][2], int mw, 
       bv[i][g] = (bias && n < N) ? ld4(bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
+  for (int j = 0; j < MJ; ++j) {
     const int m = mw + j * 32 + l31;
     if (m >= M) continue;
 #pragma unroll
@@ -287,12 +287,78 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt64_kernel(const bf16_t* __res
   nt_epilogue<TO, EPI, 1>(acc, m0, n0 + wn * 32, M, N, C, ldc, bias, aux, ldaux, aux_out, ldauxo, aux2, ldaux2);
 }
 
+
+// 96 x 192 tile variant: 6 waves side by side along N, each 96 x 32 (three 32x32 blocks sharing one weight fragment).
+// 12288 x {768, 2304, 3072} outputs split into exactly {512, 1536, 2048} such tiles = {1, 3, 4} FULL rounds of two
+// workgroups per CU (LDS 2 x 36 KB), where 128 x 128 gives 1.125 / 3.375 / 4.5 rounds: no under-filled last round.
+#define N96_BM 96
+#define N96_BN 192
+template <typename TO, int EPI>
+__global__ __launch_bounds__(384) void gemm_bf16_nt96_kernel(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ B, long ldb,
+                                                             TO* __restrict__ C, long ldc, int M, int N, int K, const float* __restrict__ bias,
+                                                             const void* __restrict__ aux, long ldaux, bf16_t* __restrict__ aux_out, long ldauxo,
+                                                             const bf16_t* __restrict__ aux2, long ldaux2) {
+  constexpr int ABYTES = N96_BM * GB_BK * 2, BBYTES = N96_BN * GB_BK * 2, STAGE = ABYTES + BBYTES;     // 12 KB + 24 KB
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
+  const int lane = threadIdx.x & 63, wn = threadIdx.x >> 6, half = lane >> 5, l31 = lane & 31;
+  const int nbm = (M + N96_BM - 1) / N96_BM, nbn = (N + N96_BN - 1) / N96_BN;
+  int bid = blockIdx.x;
+  {
+    const int nwg = nbm * nbn, q = nwg / 8, rr = nwg % 8, xcd = bid % 8, idx = bid / 8;
+    bid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + idx;
+  }
+  int tm, tn;
+  {
+    const int per_group = 8 * nbn, grp = bid / per_group, in = bid - grp * per_group;      // supertile: 768 rows x all N-tiles per L2
+    const int rows = min(8, nbm - grp * 8);
+    tn = in / rows;
+    tm = grp * 8 + (in - tn * rows);
+  }
+  const int m0 = tm * N96_BM, n0 = tn * N96_BN;
+  f32x16 acc[1][3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[0][j][r] = 0.f;
+  const int nk = K / GB_BK;
+  nt_glds<6, N96_BM>(A, lda, m0, 0, M, smem);
+  nt_glds<6, N96_BN>(B, ldb, n0, 0, N, smem + ABYTES);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const unsigned char* As = smem + (kt & 1) * STAGE;
+    const unsigned char* Bs = As + ABYTES;
+    if (kt + 1 < nk) {
+      unsigned char* An = smem + ((kt + 1) & 1) * STAGE;
+      nt_glds<6, N96_BM>(A, lda, m0, (kt + 1) * GB_BK, M, An);
+      nt_glds<6, N96_BN>(B, ldb, n0, (kt + 1) * GB_BK, N, An + ABYTES);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int c = 2 * ks + half;
+      bf16x8 fa[3];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int row = j * 32 + l31;
+        fa[j] = as_bf16x8(*reinterpret_cast<const u32x4*>(As + row * 128 + ((c ^ swz(row)) << 4)));
+      }
+      const int rowb = wn * 32 + l31;
+      const bf16x8 fb = as_bf16x8(*reinterpret_cast<const u32x4*>(Bs + rowb * 128 + ((c ^ swz(rowb)) << 4)));
+#pragma unroll
+      for (int j = 0; j < 3; ++j) acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb, fa[j], acc[0][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  nt_epilogue<TO, EPI, 1, 3>(acc, m0, n0 + wn * 32, M, N, C, ldc, bias, aux, ldaux, aux_out, ldauxo, aux2, ldaux2);
+}
+
 static int g_tn_target = 512;
 static int g_nt_waves = 8;     // measured on MI355X (r01): 8 waves 537 TF vs 4 waves 514 TF average over the per-layer shapes
+static int g_nt_96 = 1;        // 96x192 tiles when they tile the problem into full rounds
 static int g_nt_small_m = 1;   // 64x128 tiles for shapes whose 128x128 tiling quantises badly on 512 workgroup slots
 extern "C" int climb_set_option(int key, int value) {
   if (key == 1 && (value == 4 || value == 8)) { g_nt_waves = value; return CLIMB_OK; }
   if (key == 2) { g_nt_small_m = value; return CLIMB_OK; }
+  if (key == 4) { g_nt_96 = value; return CLIMB_OK; }
   if (key == 3 && value > 0) { g_tn_target = value; return CLIMB_OK; }
   return CLIMB_EINVAL;
 }
@@ -307,11 +373,14 @@ static int nt_dispatch(const bf16_t* A, long lda, const bf16_t* B, long ldb, TO*
   // is fuller (the 768-wide GEMMs leave 576 = 512 + 64 tiles of 128x128: a nearly empty second round)
   const int nwg64 = ((M + 63) / 64) * ((N + GB_BN - 1) / GB_BN);
   auto waste = [](int tiles, int slots) { int r = tiles % slots; return r == 0 ? 0.0 : (double)(slots - r) / ((tiles + slots - 1) / slots * (double)slots); };
+  const int nwg96 = ((M + N96_BM - 1) / N96_BM) * ((N + N96_BN - 1) / N96_BN);
+  const bool use96 = glds && g_nt_96 == 1 && (M % N96_BM) == 0 && (N % N96_BN) == 0 && nwg96 == 512;      // exactly one full round (measured: better than 64x128 there, worse than 128x128 on multi-round shapes)
   const bool use64 = glds && g_nt_small_m == 1 && waste(nwg64, 768) + 0.10 < waste(nwg, 512);
 #define NT_ARGS A, lda, B, ldb, C, ldc, M, N, K, bias, aux, ldaux, aux_out, ldauxo, aux2, ldaux2
 #define NT_LAUNCH(E)                                                                                                           \
   do {                                                                                                                         \
-    if (use64) hipLaunchKernelGGL((gemm_bf16_nt64_kernel<TO, E>), dim3(nwg64), dim3(256), 0, st, NT_ARGS); \
+    if (use96) hipLaunchKernelGGL((gemm_bf16_nt96_kernel<TO, E>), dim3(nwg96), dim3(384), 0, st, NT_ARGS); \
+    else if (use64) hipLaunchKernelGGL((gemm_bf16_nt64_kernel<TO, E>), dim3(nwg64), dim3(256), 0, st, NT_ARGS); \
     else if (glds && g_nt_waves == 8) hipLaunchKernelGGL((gemm_bf16_nt_kernel<TO, E, true, 1>), grid, dim3(512), 0, st, NT_ARGS);   \
     else if (glds) hipLaunchKernelGGL((gemm_bf16_nt_kernel<TO, E, true, 2>), grid, dim3(256), 0, st, NT_ARGS);                 \
     else hipLaunchKernelGGL((gemm_bf16_nt_kernel<TO, E, false, 2>), grid, dim3(256), 0, st, NT_ARGS);                          \

@@ -25,6 +25,8 @@ def timeit(fn, iters=20):
 
 if os.environ.get("NT_WAVES") is not None:
     _lib.call("climb_set_option", 1, int(os.environ["NT_WAVES"]))
+if os.environ.get("NT96") is not None:
+    _lib.call("climb_set_option", 4, int(os.environ["NT96"]))
 if os.environ.get("TN_TARGET") is not None:
     _lib.call("climb_set_option", 3, int(os.environ["TN_TARGET"]))
 if os.environ.get("NT_SMALL_M") is not None:
