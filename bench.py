@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="sequences per GPU per step")
     ap.add_argument("--precision", default=os.environ.get("CLIMB_AMD_PRECISION", "bf16"), choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch the step's kernels eagerly instead of replaying a captured hipGraph")
     ap.add_argument("--cpu-steps", type=int, default=6)
     args = ap.parse_args()
 
@@ -83,8 +84,11 @@ def main():
     sched = polynomial_decay_schedule_with_warmup(opt, max(1, int(0.1 * total_steps)), total_steps, 0.0, 1.0)
     opt.zero_grad()
 
-    def step():
-        loss, _, _, _ = model.fused_forward_backward("vqa", pixels, texts, target)
+    use_graph = not args.no_graph and world == 1 and os.environ.get("CLIMB_AMD_FORCE_DDP") != "1"
+    fwd_bwd = model.graphed_forward_backward if use_graph else model.fused_forward_backward
+
+    def step(eager=False):
+        loss, _, _, _ = (model.fused_forward_backward if eager else fwd_bwd)("vqa", pixels, texts, target)
         opt.step()
         sched.step()
         opt.zero_grad()
@@ -104,8 +108,9 @@ def main():
     fence()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        eng.prof = prof if i % prof_every == 0 else None
-        loss = step()
+        sampled = i % prof_every == 0          # event-instrumented steps launch eagerly (graph nodes cannot carry per-kernel events)
+        eng.prof = prof if sampled else None
+        loss = step(eager=sampled)
     eng.prof = None
     fence()
     dt = time.perf_counter() - t0
@@ -141,7 +146,7 @@ def main():
                 "whole_step_frac": round(FLOP_PER_SAMPLE * B * args.steps / dt / 1e12 / PEAK[args.precision], 4)}
         out = {"metric": "image-text pairs/sec on ViLT VQAv2 fine-tune step", "value": round(value, 2), "unit": "samples/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
-               "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+               "vs_baseline": None, "dtype": args.precision, "data": "synthetic", "hip_graph": use_graph,
                "config": {"workload": "BASELINE.json configs[1]: ViLT sequential-FT VQAv2 step (fwd+BCE+bwd+AdamW), 384x384 image + 40 tokens, "
                                       "12-layer ViLT-B/32 random-init + VQA head", "batch_per_gpu": B, "global_batch": B * world, "seq_len": ws.S,
                           "seq_len_padded": ws.S_pad, "parallelism": f"dp{world}", "final_loss": round(final_loss, 3)},

@@ -161,8 +161,12 @@ extern "C" int climb_attn_fwd_bf16(const void* qkv, const float* key_bias, void*
                                    void* stream) {
   if (head_dim != AB_D || S_pad % 32 || S_pad <= 0 || S_pad > 512) return CLIMB_EUNSUPPORTED;
   size_t lds = (size_t)S_pad * 256 + (size_t)S_pad * 4;
-  hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) return (int)e;
+  static size_t lds_set = 0;          // raise the dynamic-LDS cap once per size (not a stream operation: keep it out of graph capture)
+  if (lds > lds_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    lds_set = lds;
+  }
   hipLaunchKernelGGL(attn_fwd_bf16_kernel, dim3(B * heads), dim3(64 * pick_waves(S_pad / 32)), lds, (hipStream_t)stream, (const bf16_t*)qkv, key_bias,
                      (bf16_t*)ctx, lse, S_pad, heads, 1.0f / sqrtf((float)head_dim));
   LAUNCH_CHECK();
@@ -267,10 +271,14 @@ extern "C" int climb_attn_bwd_bf16(const void* qkv, const float* key_bias, const
                                    int S_pad, int heads, int head_dim, void* stream) {
   if (head_dim != AB_D || S_pad % 32 || S_pad <= 0 || S_pad > 512) return CLIMB_EUNSUPPORTED;
   size_t lds = (size_t)S_pad * 256 + (size_t)S_pad * 12;
-  hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_bf16_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) return (int)e;
-  e = hipFuncSetAttribute((const void*)attn_bwd_bf16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) return (int)e;
+  static size_t lds_set = 0;
+  if (lds > lds_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_bf16_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute((const void*)attn_bwd_bf16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    lds_set = lds;
+  }
   const float scale = 1.0f / sqrtf((float)head_dim);
   const int nthreads = 64 * ((S_pad / 32) % 3 == 0 ? 3 : 4);     // measured at S_pad = 192: 3-4 waves 63 us, 6 waves 78 us (register pressure)
   hipLaunchKernelGGL((attn_bwd_bf16_kernel<0>), dim3(B * heads), dim3(nthreads), lds, (hipStream_t)stream, (const bf16_t*)qkv, key_bias,

@@ -145,8 +145,12 @@ extern "C" int climb_attn_fwd_f32(const float* qkv, const float* key_bias, float
   int CK = S_pad <= AF_MAXKEYS ? S_pad : ((S_pad / 32 + 1) / 2) * 32;
   if (CK > AF_MAXKEYS) return CLIMB_EUNSUPPORTED;
   size_t lds = (size_t)(CK * AF_LDK + CK * AF_D + 4 * 32 * AF_LDK + S_pad) * sizeof(float);
-  hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) return (int)e;
+  static size_t lds_set = 0;
+  if (lds > lds_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    lds_set = lds;
+  }
   hipLaunchKernelGGL(attn_fwd_f32_kernel, dim3(B * heads), dim3(256), lds, (hipStream_t)stream, qkv, key_bias, ctx, lse, S_pad, heads, CK,
                      1.0f / sqrtf((float)head_dim));
   LAUNCH_CHECK();
@@ -318,10 +322,14 @@ extern "C" int climb_attn_bwd_f32(const float* qkv, const float* key_bias, const
   int CK = S_pad <= AF_MAXKEYS ? S_pad : ((S_pad / 32 + 1) / 2) * 32;
   if (CK > AF_MAXKEYS) return CLIMB_EUNSUPPORTED;
   size_t lds = (size_t)(2 * CK * AF_LDK + 4 * 32 * AF_LDK + 3 * S_pad) * sizeof(float);
-  hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_f32_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) return (int)e;
-  e = hipFuncSetAttribute((const void*)attn_bwd_f32_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) return (int)e;
+  static size_t lds_set = 0;
+  if (lds > lds_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_f32_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute((const void*)attn_bwd_f32_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    lds_set = lds;
+  }
   const float scale = 1.0f / sqrtf((float)head_dim);
   hipLaunchKernelGGL((attn_bwd_f32_kernel<0>), dim3(B * heads), dim3(256), lds, (hipStream_t)stream, qkv, key_bias, dctx, lse, delta, dqkv, S_pad,
                      heads, CK, scale);

@@ -516,6 +516,54 @@ class ViltContinualLearner(ContinualLearner):
         host.after_backward()
         return loss, (pooled, logits), ewc_task, ewc_loss
 
+    # --- the same step captured once into a hipGraph and replayed: the ~330 kernel launches of a step become one graph launch
+    # (HIP streams and graphs instead of a tracing compiler).  Inputs are copied into static buffers; the returned tensors are
+    # the graph's static outputs (overwritten by the next replay).  Falls back to the eager path under data parallelism / EWC.
+    def graphed_forward_backward(self, task_key: str, images, texts, target: torch.Tensor, ewc=None, dropout_keep=None):
+        host = self._host
+        if host.ddp is not None or dropout_keep is not None or not isinstance(texts, dict) or (self.training and self.task_configs[task_key]["model_type"] == "multi-choice"):
+            return self.fused_forward_backward(task_key, images, texts, target, ewc, dropout_keep)
+        eng = host.engine()
+        img = images if isinstance(images, dict) else {"pixel_values": images}
+        flags = tuple(sorted(n for n, p in host._params.items() if not p.requires_grad))
+        key = (task_key, self.training, eng.active_adapter, hash(flags), tuple(target.shape), target.dtype,
+               tuple((k, tuple(v.shape)) for k, v in sorted(texts.items())), tuple((k, tuple(v.shape)) for k, v in sorted(img.items())))
+        graphs = self.__dict__.setdefault("_graphs", {})
+        cs = graphs.get(key)
+        if cs is None or cs["engine"] is not eng:
+            dev = eng.device
+            st_texts = {k: v.to(dev).clone() for k, v in texts.items()}
+            st_img = {k: v.to(dev).clone() for k, v in img.items()}
+            st_target = target.to(dev).clone()
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):                  # warm-up off the capture: allocates workspaces, raises LDS caps
+                for _ in range(2):
+                    self.fused_forward_backward(task_key, st_img, st_texts, st_target)
+            torch.cuda.current_stream().wait_stream(side)
+            host.drop_grads()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                out = self.fused_forward_backward(task_key, st_img, st_texts, st_target)
+            touched = list(eng.touched)
+            host.drop_grads()                              # capture does not execute; start from clean gradients
+            cs = graphs[key] = dict(graph=g, texts=st_texts, img=st_img, target=st_target, out=out, touched=touched, engine=eng)
+        host.before_backward()
+        for k, v in texts.items():
+            cs["texts"][k].copy_(v, non_blocking=True)
+        for k, v in img.items():
+            cs["img"][k].copy_(v, non_blocking=True)
+        cs["target"].copy_(target, non_blocking=True)
+        eng.refresh_shadow()
+        cs["graph"].replay()
+        eng.touched.extend(t for t in cs["touched"] if t not in eng.touched)
+        loss, output, _, _ = cs["out"]
+        ewc_task, ewc_loss = None, None
+        if ewc is not None and ewc.do_ewc():
+            ewc_task, ewc_loss = ewc.add_penalty_gradient(self)
+        host.after_backward()
+        return loss, output, ewc_task, ewc_loss
+
     # --- adapters (REF:357-367); arithmetic of the absent GLAMOR fork is unpinned, see climb_amd/cl_algorithms/adapters.py
     def add_adapter(self, task_key: str, config: Dict):
         self.vilt_encoder.vilt.add_adapter(task_key, config)
