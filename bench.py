@@ -31,7 +31,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="sequences per GPU per step")
     ap.add_argument("--precision", default=os.environ.get("CLIMB_AMD_PRECISION", "bf16"), choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-graph", action="store_true", help="launch the step's kernels eagerly instead of replaying a captured hipGraph")
+    ap.add_argument("--graph", action="store_true", help="replay the step as a captured hipGraph (measured equal to eager launches at bs=64: the GPU, not the host, is the bottleneck)")
     ap.add_argument("--cpu-steps", type=int, default=6)
     args = ap.parse_args()
 
@@ -84,7 +84,7 @@ def main():
     sched = polynomial_decay_schedule_with_warmup(opt, max(1, int(0.1 * total_steps)), total_steps, 0.0, 1.0)
     opt.zero_grad()
 
-    use_graph = not args.no_graph and world == 1 and os.environ.get("CLIMB_AMD_FORCE_DDP") != "1"
+    use_graph = args.graph and world == 1 and os.environ.get("CLIMB_AMD_FORCE_DDP") != "1"
     fwd_bwd = model.graphed_forward_backward if use_graph else model.fused_forward_backward
 
     def step(eager=False):
