@@ -101,7 +101,7 @@ template <int BM, int BN>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, long sam, long sak, int modeA, const float* __restrict__ B,
                                                        long sbn, long sbk, int modeB, float* C, long ldc, int M, int N, int K,
                                                        const float* __restrict__ bias, int epi, const float* aux, long ldaux, float* aux_out,
-                                                       long ldauxo, float beta, const float* aux2, long ldaux2) {
+                                                       long ldauxo, float beta, const float* aux2, long ldaux2, int kper) {
   constexpr int WM = BM / 2, WN = BN / 2;   // per-wave tile
   constexpr int TM = WM / 32, TN = WN / 32; // 32x32 MFMA blocks per wave
   __shared__ __attribute__((aligned(16))) float As[GF_BK * (BM + GF_PAD)];
@@ -119,10 +119,15 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
 
   TileRegs<BM> ta;
   TileRegs<BN> tb;
-  tile_load<BM>(ta, A, sam, sak, m0, 0, M, K, modeA);
-  tile_load<BN>(tb, B, sbn, sbk, n0, 0, N, K, modeB);
+  // split-K (skinny GEMMs of the task heads: M = batch, long K): blockIdx.z owns k in [kbeg, kend) and adds its partial sum with
+  // fp32 atomics into a C the launcher zeroed; kper == 0 means no split
+  const int kbeg = kper ? blockIdx.z * kper : 0;
+  const int Kfull = K;
+  if (kper) K = min(K, kbeg + kper);
+  tile_load<BM>(ta, A, sam, sak, m0, kbeg, M, K, modeA);
+  tile_load<BN>(tb, B, sbn, sbk, n0, kbeg, N, K, modeB);
   const int half = lane >> 5, l31 = lane & 31;
-  for (int k0 = 0; k0 < K; k0 += GF_BK) {
+  for (int k0 = kbeg; k0 < K; k0 += GF_BK) {
     __syncthreads();  // previous tile fully consumed
     tile_store<BM>(ta, As, modeA);
     tile_store<BN>(tb, Bs, modeB);
@@ -151,7 +156,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
     for (int j = 0; j < TN; ++j) {
       const int n = n0 + wn * WN + j * 32 + l31;
       if (n >= N) continue;
-      const float bv = bias ? bias[n] : 0.f;
+      const float bv = (bias && kbeg == 0) ? bias[n] : 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -165,6 +170,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
         else if (epi == EPI_DSILU) v *= dsilu_f(aux[(long)m * ldaux + n]);
         else if (epi == EPI_RESID2) v += aux[(long)m * ldaux + n] + aux2[(long)m * ldaux2 + n];
         float* cp = C + (long)m * ldc + n;
+        if (kper) { atomicAdd(cp, v); continue; }
         if (beta != 0.f) v += beta * (*cp);
         *cp = v;
       }
@@ -174,9 +180,14 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
 static inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 // C[m,n] (ldc) = epi(sum_k A[m*sam + k*sak] * B[n*sbn + k*sbk] + bias[n]) + beta*C
+__global__ void zero_rows_kernel(float* __restrict__ C, long ldc, int N) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n < N) C[(long)blockIdx.y * ldc + n] = 0.f;
+}
+
 extern "C" int climb_gemm_f32(const float* A, long sam, long sak, const float* B, long sbn, long sbk, float* C, long ldc, int M, int N, int K,
                               const float* bias, int epi, const float* aux, long ldaux, float* aux_out, long ldauxo, float beta, const float* aux2,
-                              long ldaux2, void* stream) {
+                              long ldaux2, int allow_splitk, void* stream) {
   if (M <= 0 || N <= 0 || K <= 0) return CLIMB_EINVAL;
   if ((epi == EPI_RESID || epi == EPI_DGELU || epi == EPI_DSILU || epi == EPI_RESID2) && !aux) return CLIMB_EINVAL;
   if ((epi == EPI_GELU || epi == EPI_SILU) && !aux_out) return CLIMB_EINVAL;
@@ -188,15 +199,33 @@ extern "C" int climb_gemm_f32(const float* A, long sam, long sak, const float* B
   };
   const int modeA = pick(A, sam, sak, M, K), modeB = pick(B, sbn, sbk, N, K);
   hipStream_t st = (hipStream_t)stream;
+  const long tiles64 = (long)((M + 63) / 64) * ((N + 63) / 64);
+  if (allow_splitk && epi == EPI_NONE && (beta == 0.f || beta == 1.f) && tiles64 <= 64 && K >= 512) {
+    int splits = (int)(256 / tiles64);
+    if (splits > K / 128) splits = K / 128;
+    if (splits > 1) {
+      int kper = ((K + splits - 1) / splits + GF_BK - 1) / GF_BK * GF_BK;
+      splits = (K + kper - 1) / kper;
+      if (beta == 0.f) {   // a kernel, not hipMemset2DAsync: memset2D nodes with a pitch did not replay correctly under hipGraph capture
+        hipLaunchKernelGGL(zero_rows_kernel, dim3((N + 255) / 256, M), dim3(256), 0, st, C, ldc, N);
+        LAUNCH_CHECK();
+      }
+      dim3 grid((N + 63) / 64, (M + 63) / 64, splits);
+      hipLaunchKernelGGL((gemm_f32_kernel<64, 64>), grid, dim3(256), 0, st, A, sam, sak, modeA, B, sbn, sbk, modeB, C, ldc, M, N, K, bias, epi, aux,
+                         ldaux, aux_out, ldauxo, beta, aux2, ldaux2, kper);
+      LAUNCH_CHECK();
+      return CLIMB_OK;
+    }
+  }
   const long tiles128 = (long)((M + 127) / 128) * ((N + 127) / 128);
   if (tiles128 >= 192) {
     dim3 grid((N + 127) / 128, (M + 127) / 128);
     hipLaunchKernelGGL((gemm_f32_kernel<128, 128>), grid, dim3(256), 0, st, A, sam, sak, modeA, B, sbn, sbk, modeB, C, ldc, M, N, K, bias, epi, aux,
-                       ldaux, aux_out, ldauxo, beta, aux2, ldaux2);
+                       ldaux, aux_out, ldauxo, beta, aux2, ldaux2, 0);
   } else {
     dim3 grid((N + 63) / 64, (M + 63) / 64);
     hipLaunchKernelGGL((gemm_f32_kernel<64, 64>), grid, dim3(256), 0, st, A, sam, sak, modeA, B, sbn, sbk, modeB, C, ldc, M, N, K, bias, epi, aux,
-                       ldaux, aux_out, ldauxo, beta, aux2, ldaux2);
+                       ldaux, aux_out, ldauxo, beta, aux2, ldaux2, 0);
   }
   LAUNCH_CHECK();
   return CLIMB_OK;

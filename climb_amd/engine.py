@@ -186,8 +186,9 @@ class ViltEngine:
     # forward:  Y[M,N] = X[M,K] W[N,K]^T ; input grad: dX[M,K] = dY[M,N] W[N,K] ; weight grad: dW[N,K] += dY^T X
     def _gemm_f32(self, A, sam, sak, Bm, sbn, sbk, C, ldc, M, N, K, bias=None, epi=EPI_NONE, aux=None, ldaux=0, aux_out=None, ldauxo=0, beta=0.0,
                   aux2=None, ldaux2=0):
+        # split-K (atomic partial sums) only in the throughput mode: the fp32 parity mode stays run-to-run deterministic
         self._timed_call("gemm_f32", 2.0 * M * N * K, "climb_gemm_f32", A, sam, sak, Bm, sbn, sbk, C, ldc, M, N, K, bias, epi, aux, ldaux, aux_out,
-                         ldauxo, beta, aux2, ldaux2, _stream())
+                         ldauxo, beta, aux2, ldaux2, 1 if self.precision == "bf16" else 0, _stream())
 
     def linear_fwd(self, X, wname, bname, Y, M, N, K, epi=EPI_NONE, aux=None, aux_out=None, aux2=None, out_f32=False):
         if self.precision == "fp32":

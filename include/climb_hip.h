@@ -69,8 +69,9 @@ int climb_colsum_rows_per_block(void);
 /* nn.Linear forward / input-grad / weight-grad (HF:325-327, :366-369, :397-400, :410-414; REF/modeling/vilt.py:190-195)
  * on v_mfma_f32_32x32x2_f32 (exact fp32):  C[m,n] = epi(sum_k A[m*sam+k*sak] * B[n*sbn+k*sbk] + bias[n]) + beta*C[m,n]
  * epi: 0 none, 1 GELU (aux_out = pre-activation), 2 + aux residual, 3 * gelu'(aux), 4 tanh, 5 SiLU (aux_out = pre-activation),
- * 6 * silu'(aux), 7 + aux + aux2 (adapter up-projection with both residuals) */
-int climb_gemm_f32(const float* A, long sam, long sak, const float* B, long sbn, long sbk, float* C, long ldc, int M, int N, int K, const float* bias, int epi, const float* aux, long ldaux, float* aux_out, long ldauxo, float beta, const float* aux2, long ldaux2, void* stream);
+ * 6 * silu'(aux), 7 + aux + aux2 (adapter up-projection with both residuals).  allow_splitk != 0 lets skinny problems (few output tiles,
+ * long K; epi 0 only) split K across workgroups with fp32 atomics (sum order then varies from run to run) */
+int climb_gemm_f32(const float* A, long sam, long sak, const float* B, long sbn, long sbk, float* C, long ldc, int M, int N, int K, const float* bias, int epi, const float* aux, long ldaux, float* aux_out, long ldauxo, float beta, const float* aux2, long ldaux2, int allow_splitk, void* stream);
 
 /* ---- attention ------------------------------------------------------------------------------------------------- */
 /* HF:322-351 ViltSelfAttention: softmax(Q K^T / sqrt(d) + key_bias) V per (batch, head); scores never leave the CU.

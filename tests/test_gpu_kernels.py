@@ -39,8 +39,27 @@ def test_gemm_f32_forward_layout(M, N, K):
     ref = A.double() @ W.double().t() + bias.double()
     Ad, Wd, bd = A.to(dev), W.to(dev), bias.to(dev)
     C = torch.empty(M, N, device=dev)
-    _lib.call("climb_gemm_f32", Ad, K, 1, Wd, K, 1, C, N, M, N, K, bd, 0, None, 0, None, 0, 0.0, None, 0, _st())
+    _lib.call("climb_gemm_f32", Ad, K, 1, Wd, K, 1, C, N, M, N, K, bd, 0, None, 0, None, 0, 0.0, None, 0, 0, _st())
     assert _rel(C, ref) < 2e-6
+
+
+def test_gemm_f32_splitk_skinny():
+    """task-head shapes (M = batch): split-K with atomic partial sums, beta = 0 (zeroed by the launcher) and beta = 1"""
+    from climb_amd import _lib
+    dev = _dev()
+    g = torch.Generator().manual_seed(9)
+    M, N, K = 64, 1536, 3129
+    A = torch.randn(M, 3132, generator=g)[:, :K]
+    W = torch.randn(K, N, generator=g) * 0.05         # B(n, k) = W[k*N + n]
+    bias = torch.randn(N, generator=g)
+    Ad, Wd = torch.zeros(M, 3132).copy_(torch.nn.functional.pad(A, (0, 3))).to(dev), W.to(dev)
+    C = torch.full((M, N), 7.0, device=dev)
+    _lib.call("climb_gemm_f32", Ad, 3132, 1, Wd, 1, N, C, N, M, N, K, bias.to(dev), 0, None, 0, None, 0, 0.0, None, 0, 1, _st())
+    ref = A.double() @ W.double() + bias.double()
+    assert _rel(C, ref) < 2e-6
+    C2 = torch.ones(M, N, device=dev)
+    _lib.call("climb_gemm_f32", Ad, 3132, 1, Wd, 1, N, C2, N, M, N, K, None, 0, None, 0, None, 0, 1.0, None, 0, 1, _st())
+    assert _rel(C2, 1 + A.double() @ W.double()) < 2e-6
 
 
 def test_gemm_f32_strided_variants_and_epilogues():
@@ -55,27 +74,27 @@ def test_gemm_f32_strided_variants_and_epilogues():
     dYd, Wd, Xd, Ud = dY.to(dev), W.to(dev), X.to(dev), U.to(dev)
     # input grad with GELU' epilogue: dX = (dY W) * gelu'(U)
     dX = torch.empty(M, K, device=dev)
-    _lib.call("climb_gemm_f32", dYd, N, 1, Wd, 1, K, dX, K, M, K, N, None, 3, Ud, K, None, 0, 0.0, None, 0, _st())
+    _lib.call("climb_gemm_f32", dYd, N, 1, Wd, 1, K, dX, K, M, K, N, None, 3, Ud, K, None, 0, 0.0, None, 0, 0, _st())
     Ur = U.double().requires_grad_(True)
     gelu(Ur).backward(dY.double() @ W.double())
     assert _rel(dX, Ur.grad) < 5e-6
     # weight grad, accumulating: dW += dY^T X
     dW0 = torch.randn(N, K, generator=g)
     dW = dW0.to(dev).clone()
-    _lib.call("climb_gemm_f32", dYd, 1, N, Xd, 1, K, dW, K, N, K, M, None, 0, None, 0, None, 0, 1.0, None, 0, _st())
+    _lib.call("climb_gemm_f32", dYd, 1, N, Xd, 1, K, dW, K, N, K, M, None, 0, None, 0, None, 0, 1.0, None, 0, 0, _st())
     assert _rel(dW, dW0.double() + dY.double().t() @ X.double()) < 2e-6
     # forward with GELU (pre-activation saved), residual and tanh epilogues
     b = torch.randn(N, generator=g).to(dev)
     Y = torch.empty(M, N, device=dev)
     pre = torch.empty(M, N, device=dev)
-    _lib.call("climb_gemm_f32", Xd, K, 1, Wd, K, 1, Y, N, M, N, K, b, 1, None, 0, pre, N, 0.0, None, 0, _st())
+    _lib.call("climb_gemm_f32", Xd, K, 1, Wd, K, 1, Y, N, M, N, K, b, 1, None, 0, pre, N, 0.0, None, 0, 0, _st())
     ref_pre = X.double() @ W.double().t() + b.cpu().double()
     assert _rel(pre, ref_pre) < 2e-6 and _rel(Y, gelu(ref_pre)) < 5e-6
     R = torch.randn(M, N, generator=g).to(dev)
-    _lib.call("climb_gemm_f32", Xd, K, 1, Wd, K, 1, Y, N, M, N, K, b, 2, R, N, None, 0, 0.0, None, 0, _st())
+    _lib.call("climb_gemm_f32", Xd, K, 1, Wd, K, 1, Y, N, M, N, K, b, 2, R, N, None, 0, 0.0, None, 0, 0, _st())
     assert _rel(Y, ref_pre + R.cpu().double()) < 2e-6
     Xs = (X * 0.05).to(dev)                     # keep tanh out of saturation so the check is meaningful
-    _lib.call("climb_gemm_f32", Xs, K, 1, Wd, K, 1, Y, N, M, N, K, b, 4, None, 0, None, 0, 0.0, None, 0, _st())
+    _lib.call("climb_gemm_f32", Xs, K, 1, Wd, K, 1, Y, N, M, N, K, b, 4, None, 0, None, 0, 0.0, None, 0, 0, _st())
     assert _rel(Y, torch.tanh((X * 0.05).double() @ W.double().t() + b.cpu().double())) < 5e-6
 
 
