@@ -10,7 +10,7 @@ from typing import Dict, List, Tuple
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "climb_hip.h")
-LIB_PATH = os.path.join(_HERE, "csrc", "libclimb_hip.so")
+LIB_PATH = os.environ.get("CLIMB_AMD_LIB") or os.path.join(_HERE, "csrc", "libclimb_hip.so")   # override: developer builds of the same ABI
 
 _PROTO = re.compile(r"^\s*(int|const char\*)\s+(climb_\w+)\s*\(([^)]*)\)\s*;", re.M)
 

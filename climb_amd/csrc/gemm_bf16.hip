@@ -78,98 +78,130 @@ __device__ __forceinline__ void nt_glds(const bf16_t* __restrict__ P, long ld, i
   }
 }
 
-// Epilogue: acc[i][j][4g..4g+3] = C[m][n..n+3] with m = mw + j*32 + (lane&31), n = nw + i*32 + 8g + 4*(lane>>5).
-// Bias for all column groups of the lane is fetched up front so its latency overlaps the first stores.
-template <typename TO, int EPI, int NI, int MJ = 2>
-__device__ __forceinline__ void nt_epilogue(const f32x16 (&acc)[NI][MJ], int mw, int nw, int M, int N, TO* __restrict__ C, long ldc,
-                                            const float* __restrict__ bias, const void* __restrict__ aux, long ldaux, bf16_t* __restrict__ aux_out,
-                                            long ldauxo, const bf16_t* __restrict__ aux2, long ldaux2) {
-  const int lane = threadIdx.x & 63, half = lane >> 5, l31 = lane & 31;
-  float4 bv[NI][4];
+// Epilogue.  In the 32x32 accumulator layout a lane owns ONE output row and 4-column groups of it, so a direct store touches 32
+// different rows with 8-16 bytes each: 8x the memory transactions of a row-contiguous store, and measured (r01 ablation: 633 -> 448
+// us per layer with the epilogue removed) the dominant cost of the K = 768 GEMMs.  Instead every wave turns its 32 x (NI*32)
+// block through a PRIVATE fp32 LDS region (the k-loop buffers are free by then) and then walks it row-major: 16 B of LDS per lane,
+// NI*8 lanes per row, so bias / residual / pre-activation are read and C / aux_out written as whole 128-byte lines.
+// Staged row r holds 16-byte chunk c at chunk position (c & ~7) | ((c ^ r) & 7): the transposing ds_write_b128s (8 consecutive
+// rows, same chunk) and the row-major ds_read_b128s are both bank-conflict free.  No workgroup barrier: the region is per wave
+// and LDS operations of one wave execute in order.
+// The residual / pre-activation operand of the epilogue, fetched BEFORE the k-loop in the same row-major lane assignment the
+// epilogue uses: its latency (measured: 36 us per layer when loaded in the epilogue) disappears under the MFMAs.
+template <int EPI, int CNT>
+struct AuxRegs {
+  float4 r[CNT];     // fp32 residual            (EPI_RESID, EPI_RESID2)
+  uint2 h[CNT];      // 4 bf16: pre-activation   (EPI_DGELU, EPI_DSILU) or second residual (EPI_RESID2)
+};
+template <int EPI, int NI, int MJ>
+__device__ __forceinline__ void nt_aux_prefetch(AuxRegs<EPI, NI * 4 * MJ>& ax, int mw, int nw, int M, int N, const void* __restrict__ aux, long ldaux,
+                                                const bf16_t* __restrict__ aux2, long ldaux2) {
+  constexpr int CPR = NI * 8;
+  const int lane = threadIdx.x & 63;
 #pragma unroll
-  for (int i = 0; i < NI; ++i)
+  for (int j = 0; j < MJ; ++j)
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int n = nw + i * 32 + 8 * g + 4 * half;
-      bv[i][g] = (bias && n < N) ? ld4(bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int p = 0; p < NI * 4; ++p) {
+      const int q = p * 64 + lane, r = q / CPR, c = q % CPR;
+      const int m = min(mw + j * 32 + r, M - 1), n = min(nw + c * 4, N - 4);       // clamped: out-of-range results are never used
+      if (EPI == EPI_RESID || EPI == EPI_RESID2) ax.r[j * NI * 4 + p] = ld4(reinterpret_cast<const float*>(aux) + (long)m * ldaux + n);
+      if (EPI == EPI_DGELU || EPI == EPI_DSILU) ax.h[j * NI * 4 + p] = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(aux) + (long)m * ldaux + n);
+      if (EPI == EPI_RESID2) ax.h[j * NI * 4 + p] = *reinterpret_cast<const uint2*>(aux2 + (long)m * ldaux2 + n);
     }
+}
+__device__ __forceinline__ float4 bf16x4_to_f32(uint2 r) {
+  return make_float4(__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16), __uint_as_float(r.y & 0xffff0000u));
+}
+
+template <typename TO, int EPI, int NI, int MJ>
+__device__ __forceinline__ void nt_epilogue(const f32x16 (&acc)[NI][MJ], const AuxRegs<EPI, NI * 4 * MJ>& ax, unsigned char* __restrict__ stage, int mw,
+                                            int nw, int M, int N, TO* __restrict__ C, long ldc, const float* __restrict__ bias,
+                                            bf16_t* __restrict__ aux_out, long ldauxo) {
+  constexpr int CPR = NI * 8, PITCH = NI * 128;          // chunks / bytes per staged row
+  const int lane = threadIdx.x & 63, half = lane >> 5, l31 = lane & 31;
 #pragma unroll
   for (int j = 0; j < MJ; ++j) {
-    const int m = mw + j * 32 + l31;
-    if (m >= M) continue;
 #pragma unroll
     for (int i = 0; i < NI; ++i)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int n = nw + i * 32 + 8 * g + 4 * half;
-        if (n >= N) continue;
-        float4 v = make_float4(acc[i][j][4 * g] + bv[i][g].x, acc[i][j][4 * g + 1] + bv[i][g].y, acc[i][j][4 * g + 2] + bv[i][g].z,
-                               acc[i][j][4 * g + 3] + bv[i][g].w);
-        if (EPI == EPI_GELU) {
-          st4(aux_out + (long)m * ldauxo + n, v);
-          v = make_float4(gelu_fast(v.x), gelu_fast(v.y), gelu_fast(v.z), gelu_fast(v.w));
-        } else if (EPI == EPI_RESID) {
-          const float4 rv = ld4(reinterpret_cast<const float*>(aux) + (long)m * ldaux + n);
-          v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
-        } else if (EPI == EPI_DGELU) {
-          const float4 uv = ld4(reinterpret_cast<const bf16_t*>(aux) + (long)m * ldaux + n);
-          v.x *= dgelu_fast(uv.x); v.y *= dgelu_fast(uv.y); v.z *= dgelu_fast(uv.z); v.w *= dgelu_fast(uv.w);
-        } else if (EPI == EPI_SILU) {
-          st4(aux_out + (long)m * ldauxo + n, v);
-          v = make_float4(silu_f(v.x), silu_f(v.y), silu_f(v.z), silu_f(v.w));
-        } else if (EPI == EPI_DSILU) {
-          const float4 uv = ld4(reinterpret_cast<const bf16_t*>(aux) + (long)m * ldaux + n);
-          v.x *= dsilu_f(uv.x); v.y *= dsilu_f(uv.y); v.z *= dsilu_f(uv.z); v.w *= dsilu_f(uv.w);
-        } else if (EPI == EPI_RESID2) {
-          const float4 rv = ld4(reinterpret_cast<const float*>(aux) + (long)m * ldaux + n);
-          const float4 yv = ld4(aux2 + (long)m * ldaux2 + n);
-          v.x += rv.x + yv.x; v.y += rv.y + yv.y; v.z += rv.z + yv.z; v.w += rv.w + yv.w;
-        }
-        st4(C + (long)m * ldc + n, v);
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<float4*>(stage + l31 * PITCH + ((i * 8 + ((2 * g + half) ^ (l31 & 7))) << 4)) =
+            make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+#pragma unroll
+    for (int p = 0; p < NI * 4; ++p) {
+      const int q = p * 64 + lane, r = q / CPR, c = q % CPR;
+      float4 v = *reinterpret_cast<const float4*>(stage + r * PITCH + (((c & ~7) | ((c ^ r) & 7)) << 4));
+      const int m = mw + j * 32 + r, n = nw + c * 4;
+      if (m >= M || n >= N) continue;
+      if (bias) {
+        const float4 bv = ld4(bias + n);
+        v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
       }
+      if (EPI == EPI_GELU) {
+        st4(aux_out + (long)m * ldauxo + n, v);
+        v = make_float4(gelu_fast(v.x), gelu_fast(v.y), gelu_fast(v.z), gelu_fast(v.w));
+      } else if (EPI == EPI_RESID) {
+        const float4 rv = ax.r[j * NI * 4 + p];
+        v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+      } else if (EPI == EPI_DGELU) {
+        const float4 uv = bf16x4_to_f32(ax.h[j * NI * 4 + p]);
+        v.x *= dgelu_fast(uv.x); v.y *= dgelu_fast(uv.y); v.z *= dgelu_fast(uv.z); v.w *= dgelu_fast(uv.w);
+      } else if (EPI == EPI_SILU) {
+        st4(aux_out + (long)m * ldauxo + n, v);
+        v = make_float4(silu_f(v.x), silu_f(v.y), silu_f(v.z), silu_f(v.w));
+      } else if (EPI == EPI_DSILU) {
+        const float4 uv = bf16x4_to_f32(ax.h[j * NI * 4 + p]);
+        v.x *= dsilu_f(uv.x); v.y *= dsilu_f(uv.y); v.z *= dsilu_f(uv.z); v.w *= dsilu_f(uv.w);
+      } else if (EPI == EPI_RESID2) {
+        const float4 rv = ax.r[j * NI * 4 + p];
+        const float4 yv = bf16x4_to_f32(ax.h[j * NI * 4 + p]);
+        v.x += rv.x + yv.x; v.y += rv.y + yv.y; v.z += rv.z + yv.z; v.w += rv.w + yv.w;
+      }
+      st4(C + (long)m * ldc + n, v);
+    }
   }
 }
 
-// NI = 32-column blocks per wave: NI = 2 -> 4 waves (2x2, 64x64 each); NI = 1 -> 8 waves (2x4, 64x32 each: twice the
-// waves per CU hiding LDS-DMA / L2 latency for the same LDS footprint, at 1.5x the fragment reads per MFMA).
-template <typename TO, int EPI, bool GLDS, int NI>
-__global__ __launch_bounds__(512 / NI)
+// XCD-aware tile order.  Blocks are dealt round-robin to the 8 XCDs (private 4 MB L2 each); remap so that every XCD owns a
+// CONTIGUOUS chunk of a supertile order: groups of GM M-tiles, inside a group N-tile-major.  The ~64 workgroups an XCD runs
+// concurrently then cover ~8 A panels x ~8 B panels (~3 MB at K = 768) instead of 64 A panels x 1 B panel, so both operands are
+// re-read from that L2, not from HBM / Infinity Cache.
+template <int GM>
+__device__ __forceinline__ void nt_tile(int nbm, int nbn, int& tm, int& tn) {
+  const int nwg = nbm * nbn, q = nwg / 8, rr = nwg % 8, xcd = blockIdx.x % 8, idx = blockIdx.x / 8;
+  const int bid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + idx;      // bijective for any nwg
+  const int per_group = GM * nbn, grp = bid / per_group, in = bid - grp * per_group;
+  const int rows = min(GM, nbm - grp * GM);          // last group may hold fewer than GM M-tiles
+  tn = in / rows;
+  tm = grp * GM + (in - tn * rows);
+}
+
+// 128 x 128 tile; waves arranged (8/MJ/2) x 2, each owning MJ*32 rows x 64 columns: MJ = 1 -> 8 waves (twice the waves per CU
+// hiding LDS-DMA / L2 latency for the same LDS footprint, at 1.5x the fragment reads per MFMA); MJ = 2 -> 4 waves.
+template <typename TO, int EPI, bool GLDS, int MJ>
+__global__ __launch_bounds__(512 / MJ)
 void gemm_bf16_nt_kernel(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ B, long ldb, TO* __restrict__ C, long ldc, int M, int N,
                          int K, const float* __restrict__ bias, const void* __restrict__ aux, long ldaux, bf16_t* __restrict__ aux_out, long ldauxo,
                          const bf16_t* __restrict__ aux2, long ldaux2) {
-  constexpr int NW = 8 / NI;                       // waves per workgroup
-  constexpr int WNW = NW / 2;                      // waves along N
-  static_assert(GLDS || NI == 2, "the register-staged fallback is written for 256 threads");
+  constexpr int NW = 8 / MJ;                       // waves per workgroup
+  static_assert(GLDS || MJ == 2, "the register-staged fallback is written for 256 threads");
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * GB_BM * GB_BK * 2];   // [buf][A|B][128][64] bf16 = 64 KB
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const int wm = wid / WNW, wn = wid % WNW, half = lane >> 5, l31 = lane & 31;
-  // XCD-aware tile order.  Blocks are dealt round-robin to the 8 XCDs (private 4 MB L2 each); remap so that every XCD
-  // owns a CONTIGUOUS chunk of a supertile order: groups of 8 M-tiles, inside a group N-tile-major.  The ~64 workgroups an
-  // XCD runs concurrently then cover ~8 A panels x ~8 B panels (~3 MB at K = 768) instead of 64 A panels x 1 B panel, so
-  // both operands are re-read from that L2, not from HBM / Infinity Cache.
-  const int nbm = (M + GB_BM - 1) / GB_BM, nbn = (N + GB_BN - 1) / GB_BN;
-  int bid = blockIdx.x;
-  {
-    const int nwg = nbm * nbn, q = nwg / 8, rr = nwg % 8, xcd = bid % 8, idx = bid / 8;
-    bid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + idx;      // bijective for any nwg
-  }
+  const int wm = wid >> 1, wn = wid & 1, half = lane >> 5, l31 = lane & 31;
   int tm, tn;
-  {
-    const int per_group = 8 * nbn, grp = bid / per_group, in = bid - grp * per_group;
-    const int rows = min(8, nbm - grp * 8);          // last group may hold fewer than 8 M-tiles
-    tn = in / rows;
-    tm = grp * 8 + (in - tn * rows);
-  }
+  nt_tile<8>((M + GB_BM - 1) / GB_BM, (N + GB_BN - 1) / GB_BN, tm, tn);
   const int m0 = tm * GB_BM, n0 = tn * GB_BN;
-  f32x16 acc[NI][2];   // [n block][m block]
+  f32x16 acc[2][MJ];   // [n block][m block]
 #pragma unroll
-  for (int i = 0; i < NI; ++i)
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < MJ; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   u32x4 ra[4], rb[4];
   const int nk = (K + GB_BK - 1) / GB_BK;
+  AuxRegs<EPI, 8 * MJ> ax;
+  nt_aux_prefetch<EPI, 2, MJ>(ax, m0 + wm * (32 * MJ), n0 + wn * 64, M, N, aux, ldaux, aux2, ldaux2);
 #define KOFF(kt_) ((kt_) * GB_BK)
   if constexpr (GLDS) {
     nt_glds<NW>(A, lda, m0, KOFF(0), M, smem);
@@ -196,22 +228,22 @@ void gemm_bf16_nt_kernel(const bf16_t* __restrict__ A, long lda, const bf16_t* _
     }
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      bf16x8 fa[2], fb[NI];
+      bf16x8 fa[MJ], fb[2];
       const int c = 2 * ks + half;
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int row = wm * 64 + j * 32 + l31;
+      for (int j = 0; j < MJ; ++j) {
+        const int row = wm * (32 * MJ) + j * 32 + l31;
         fa[j] = as_bf16x8(*reinterpret_cast<const u32x4*>(As + row * 128 + ((c ^ swz(row)) << 4)));
       }
 #pragma unroll
-      for (int i = 0; i < NI; ++i) {
-        const int row = wn * (32 * NI) + i * 32 + l31;
+      for (int i = 0; i < 2; ++i) {
+        const int row = wn * 64 + i * 32 + l31;
         fb[i] = as_bf16x8(*reinterpret_cast<const u32x4*>(Bs + row * 128 + ((c ^ swz(row)) << 4)));
       }
 #pragma unroll
-      for (int i = 0; i < NI; ++i)
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[i], fa[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < MJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[i], fa[j], acc[i][j], 0, 0, 0);
     }
     if constexpr (!GLDS) {
       if (kt + 1 < nk) {
@@ -223,11 +255,12 @@ void gemm_bf16_nt_kernel(const bf16_t* __restrict__ A, long lda, const bf16_t* _
     __syncthreads();    // with LDS-DMA in flight the compiler drains vmcnt(0) here: tile kt+1 has landed for every wave
   }
 #undef KOFF
-  nt_epilogue<TO, EPI, NI>(acc, m0 + wm * 64, n0 + wn * (32 * NI), M, N, C, ldc, bias, aux, ldaux, aux_out, ldauxo, aux2, ldaux2);
+  // every wave is past the last k-tile (barrier above): the buffers become the per-wave staging regions (8 KB each)
+  nt_epilogue<TO, EPI, 2, MJ>(acc, ax, smem + wid * 8192, m0 + wm * (32 * MJ), n0 + wn * 64, M, N, C, ldc, bias, aux_out, ldauxo);
 }
 
 
-// 64 x 128 tile variant (4 waves side by side along N, each 64 x 32; LDS 2 x 24 KB -> three workgroups per CU).
+// 64 x 128 tile variant (4 waves as 2 x 2, each 32 x 64; LDS 2 x 24 KB -> three workgroups per CU).
 // Same fragments, swizzle, DMA staging and epilogue; used where 128 x 128 tiles leave the last round of workgroups mostly empty.
 template <typename TO, int EPI>
 __global__ __launch_bounds__(256) void gemm_bf16_nt64_kernel(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ B, long ldb,
@@ -236,27 +269,18 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt64_kernel(const bf16_t* __res
                                                              const bf16_t* __restrict__ aux2, long ldaux2) {
   constexpr int ABYTES = 64 * GB_BK * 2, BBYTES = GB_BN * GB_BK * 2, STAGE = ABYTES + BBYTES;     // 8 KB + 16 KB
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
-  const int lane = threadIdx.x & 63, wn = threadIdx.x >> 6, half = lane >> 5, l31 = lane & 31;
-  const int nbm = (M + 63) / 64, nbn = (N + GB_BN - 1) / GB_BN;
-  int bid = blockIdx.x;
-  {
-    const int nwg = nbm * nbn, q = nwg / 8, rr = nwg % 8, xcd = bid % 8, idx = bid / 8;
-    bid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + idx;
-  }
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, wm = wid >> 1, wn = wid & 1, half = lane >> 5, l31 = lane & 31;
   int tm, tn;
-  {
-    const int per_group = 16 * nbn, grp = bid / per_group, in = bid - grp * per_group;      // 16 M-tiles of 64 = the same 1024-row supertile
-    const int rows = min(16, nbm - grp * 16);
-    tn = in / rows;
-    tm = grp * 16 + (in - tn * rows);
-  }
+  nt_tile<16>((M + 63) / 64, (N + GB_BN - 1) / GB_BN, tm, tn);      // 16 M-tiles of 64 = the same 1024-row supertile
   const int m0 = tm * 64, n0 = tn * GB_BN;
-  f32x16 acc[1][2];
+  f32x16 acc[2][1];
 #pragma unroll
-  for (int j = 0; j < 2; ++j)
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[0][j][r] = 0.f;
+    for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.f;
   const int nk = K / GB_BK;
+  AuxRegs<EPI, 8> ax;
+  nt_aux_prefetch<EPI, 2, 1>(ax, m0 + wm * 32, n0 + wn * 64, M, N, aux, ldaux, aux2, ldaux2);
   nt_glds<4, 64>(A, lda, m0, 0, M, smem);
   nt_glds<4, 128>(B, ldb, n0, 0, N, smem + ABYTES);
   __syncthreads();
@@ -271,24 +295,24 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt64_kernel(const bf16_t* __res
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const int c = 2 * ks + half;
-      bf16x8 fa[2];
+      const int rowa = wm * 32 + l31;
+      const bf16x8 fa = as_bf16x8(*reinterpret_cast<const u32x4*>(As + rowa * 128 + ((c ^ swz(rowa)) << 4)));
+      bf16x8 fb[2];
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int row = j * 32 + l31;
-        fa[j] = as_bf16x8(*reinterpret_cast<const u32x4*>(As + row * 128 + ((c ^ swz(row)) << 4)));
+      for (int i = 0; i < 2; ++i) {
+        const int rowb = wn * 64 + i * 32 + l31;
+        fb[i] = as_bf16x8(*reinterpret_cast<const u32x4*>(Bs + rowb * 128 + ((c ^ swz(rowb)) << 4)));
       }
-      const int rowb = wn * 32 + l31;
-      const bf16x8 fb = as_bf16x8(*reinterpret_cast<const u32x4*>(Bs + rowb * 128 + ((c ^ swz(rowb)) << 4)));
 #pragma unroll
-      for (int j = 0; j < 2; ++j) acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb, fa[j], acc[0][j], 0, 0, 0);
+      for (int i = 0; i < 2; ++i) acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[i], fa, acc[i][0], 0, 0, 0);
     }
     __syncthreads();
   }
-  nt_epilogue<TO, EPI, 1>(acc, m0, n0 + wn * 32, M, N, C, ldc, bias, aux, ldaux, aux_out, ldauxo, aux2, ldaux2);
+  nt_epilogue<TO, EPI, 2, 1>(acc, ax, smem + wid * 8192, m0 + wm * 32, n0 + wn * 64, M, N, C, ldc, bias, aux_out, ldauxo);
 }
 
 
-// 96 x 192 tile variant: 6 waves side by side along N, each 96 x 32 (three 32x32 blocks sharing one weight fragment).
+// 96 x 192 tile variant: 6 waves as 3 x 2, each 32 x 96 (three 32x32 blocks sharing one token fragment).
 // 12288 x {768, 2304, 3072} outputs split into exactly {512, 1536, 2048} such tiles = {1, 3, 4} FULL rounds of two
 // workgroups per CU (LDS 2 x 36 KB), where 128 x 128 gives 1.125 / 3.375 / 4.5 rounds: no under-filled last round.
 #define N96_BM 96
@@ -300,27 +324,18 @@ __global__ __launch_bounds__(384) void gemm_bf16_nt96_kernel(const bf16_t* __res
                                                              const bf16_t* __restrict__ aux2, long ldaux2) {
   constexpr int ABYTES = N96_BM * GB_BK * 2, BBYTES = N96_BN * GB_BK * 2, STAGE = ABYTES + BBYTES;     // 12 KB + 24 KB
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
-  const int lane = threadIdx.x & 63, wn = threadIdx.x >> 6, half = lane >> 5, l31 = lane & 31;
-  const int nbm = (M + N96_BM - 1) / N96_BM, nbn = (N + N96_BN - 1) / N96_BN;
-  int bid = blockIdx.x;
-  {
-    const int nwg = nbm * nbn, q = nwg / 8, rr = nwg % 8, xcd = bid % 8, idx = bid / 8;
-    bid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + idx;
-  }
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, wm = wid >> 1, wn = wid & 1, half = lane >> 5, l31 = lane & 31;
   int tm, tn;
-  {
-    const int per_group = 8 * nbn, grp = bid / per_group, in = bid - grp * per_group;      // supertile: 768 rows x all N-tiles per L2
-    const int rows = min(8, nbm - grp * 8);
-    tn = in / rows;
-    tm = grp * 8 + (in - tn * rows);
-  }
+  nt_tile<8>((M + N96_BM - 1) / N96_BM, (N + N96_BN - 1) / N96_BN, tm, tn);      // supertile: 768 rows x all N-tiles per L2
   const int m0 = tm * N96_BM, n0 = tn * N96_BN;
-  f32x16 acc[1][3];
+  f32x16 acc[3][1];
 #pragma unroll
-  for (int j = 0; j < 3; ++j)
+  for (int i = 0; i < 3; ++i)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[0][j][r] = 0.f;
+    for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.f;
   const int nk = K / GB_BK;
+  AuxRegs<EPI, 12> ax;
+  nt_aux_prefetch<EPI, 3, 1>(ax, m0 + wm * 32, n0 + wn * 96, M, N, aux, ldaux, aux2, ldaux2);
   nt_glds<6, N96_BM>(A, lda, m0, 0, M, smem);
   nt_glds<6, N96_BN>(B, ldb, n0, 0, N, smem + ABYTES);
   __syncthreads();
@@ -335,20 +350,21 @@ __global__ __launch_bounds__(384) void gemm_bf16_nt96_kernel(const bf16_t* __res
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const int c = 2 * ks + half;
-      bf16x8 fa[3];
+      const int rowa = wm * 32 + l31;
+      const bf16x8 fa = as_bf16x8(*reinterpret_cast<const u32x4*>(As + rowa * 128 + ((c ^ swz(rowa)) << 4)));
+      bf16x8 fb[3];
 #pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        const int row = j * 32 + l31;
-        fa[j] = as_bf16x8(*reinterpret_cast<const u32x4*>(As + row * 128 + ((c ^ swz(row)) << 4)));
+      for (int i = 0; i < 3; ++i) {
+        const int rowb = wn * 96 + i * 32 + l31;
+        fb[i] = as_bf16x8(*reinterpret_cast<const u32x4*>(Bs + rowb * 128 + ((c ^ swz(rowb)) << 4)));
       }
-      const int rowb = wn * 32 + l31;
-      const bf16x8 fb = as_bf16x8(*reinterpret_cast<const u32x4*>(Bs + rowb * 128 + ((c ^ swz(rowb)) << 4)));
 #pragma unroll
-      for (int j = 0; j < 3; ++j) acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb, fa[j], acc[0][j], 0, 0, 0);
+      for (int i = 0; i < 3; ++i) acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[i], fa, acc[i][0], 0, 0, 0);
     }
     __syncthreads();
   }
-  nt_epilogue<TO, EPI, 1, 3>(acc, m0, n0 + wn * 32, M, N, C, ldc, bias, aux, ldaux, aux_out, ldauxo, aux2, ldaux2);
+  // 6 waves x 12 KB of staging = the 72 KB of k-loop buffers
+  nt_epilogue<TO, EPI, 3, 1>(acc, ax, smem + wid * 12288, m0 + wm * 32, n0 + wn * 96, M, N, C, ldc, bias, aux_out, ldauxo);
 }
 
 static int g_tn_target = 512;

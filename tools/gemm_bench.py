@@ -23,35 +23,38 @@ def timeit(fn, iters=20):
     return e0.elapsed_time(e1) / iters * 1e-3
 
 
-if os.environ.get("NT_WAVES") is not None:
-    _lib.call("climb_set_option", 1, int(os.environ["NT_WAVES"]))
-if os.environ.get("NT96") is not None:
-    _lib.call("climb_set_option", 4, int(os.environ["NT96"]))
-if os.environ.get("TN_TARGET") is not None:
-    _lib.call("climb_set_option", 3, int(os.environ["TN_TARGET"]))
-if os.environ.get("NT_SMALL_M") is not None:
-    _lib.call("climb_set_option", 2, int(os.environ["NT_SMALL_M"]))
-tot_t = tot_f = 0.0
-for name, N, K, cdt, epi in [("qkv fwd", 2304, 768, 1, 0), ("out fwd +res", 768, 768, 0, 2), ("up fwd gelu", 3072, 768, 1, 1), ("down fwd +res", 768, 3072, 0, 2),
-                             ("du dgelu", 3072, 768, 1, 3), ("dhn", 768, 3072, 1, 0), ("dctx", 768, 768, 1, 0), ("dxn", 768, 2304, 1, 0)]:
-    A = torch.randn(M, K, device=dev).bfloat16()
-    W = (torch.randn(N, K, device=dev) * 0.05).bfloat16()
-    C = torch.empty(M, N, device=dev, dtype=torch.bfloat16 if cdt else torch.float32)
-    bias = torch.randn(N, device=dev)
-    aux = torch.randn(M, N, device=dev) if epi == 2 else (torch.randn(M, N, device=dev).bfloat16() if epi == 3 else None)
-    auxo = torch.empty(M, N, device=dev, dtype=torch.bfloat16) if epi == 1 else None
-    t = timeit(lambda: _lib.call("climb_gemm_bf16_nt", A, K, W, K, C, N, cdt, M, N, K, bias, epi, aux, N, auxo, N, None, 0, st()))
-    f = 2.0 * M * N * K
-    tot_t += t; tot_f += f
-    print(f"NT {name:14s} N={N:5d} K={K:5d}: {t*1e6:8.1f} us  {f/t/1e12:7.1f} TF")
-print(f"NT total {tot_t*1e3:.3f} ms/layer  {tot_f/tot_t/1e12:.1f} TF")
-tt = tf = 0.0
-for name, N, K in [("dW2", 768, 3072), ("dW1", 3072, 768), ("dWo", 768, 768), ("dWqkv", 2304, 768)]:
-    dY = torch.randn(M, N, device=dev).bfloat16()
-    X = torch.randn(M, K, device=dev).bfloat16()
-    C = torch.zeros(N, K, device=dev)
-    t = timeit(lambda: _lib.call("climb_gemm_bf16_tn", dY, N, X, K, C, K, M, N, K, None, st()))
-    f = 2.0 * M * N * K
-    tt += t; tf += f
-    print(f"TN {name:14s} N={N:5d} K={K:5d}: {t*1e6:8.1f} us  {f/t/1e12:7.1f} TF")
-print(f"TN total {tt*1e3:.3f} ms/layer  {tf/tt/1e12:.1f} TF")
+if __name__ == "__main__":
+    if os.environ.get("NT_WAVES") is not None:
+        _lib.call("climb_set_option", 1, int(os.environ["NT_WAVES"]))
+    if os.environ.get("NT_STAGGER") is not None:
+        _lib.call("climb_set_option", 5, int(os.environ["NT_STAGGER"]))
+    if os.environ.get("NT96") is not None:
+        _lib.call("climb_set_option", 4, int(os.environ["NT96"]))
+    if os.environ.get("TN_TARGET") is not None:
+        _lib.call("climb_set_option", 3, int(os.environ["TN_TARGET"]))
+    if os.environ.get("NT_SMALL_M") is not None:
+        _lib.call("climb_set_option", 2, int(os.environ["NT_SMALL_M"]))
+    tot_t = tot_f = 0.0
+    for name, N, K, cdt, epi in [("qkv fwd", 2304, 768, 1, 0), ("out fwd +res", 768, 768, 0, 2), ("up fwd gelu", 3072, 768, 1, 1), ("down fwd +res", 768, 3072, 0, 2),
+                                 ("du dgelu", 3072, 768, 1, 3), ("dhn", 768, 3072, 1, 0), ("dctx", 768, 768, 1, 0), ("dxn", 768, 2304, 1, 0)]:
+        A = torch.randn(M, K, device=dev).bfloat16()
+        W = (torch.randn(N, K, device=dev) * 0.05).bfloat16()
+        C = torch.empty(M, N, device=dev, dtype=torch.bfloat16 if cdt else torch.float32)
+        bias = torch.randn(N, device=dev)
+        aux = torch.randn(M, N, device=dev) if epi == 2 else (torch.randn(M, N, device=dev).bfloat16() if epi == 3 else None)
+        auxo = torch.empty(M, N, device=dev, dtype=torch.bfloat16) if epi == 1 else None
+        t = timeit(lambda: _lib.call("climb_gemm_bf16_nt", A, K, W, K, C, N, cdt, M, N, K, bias, epi, aux, N, auxo, N, None, 0, st()))
+        f = 2.0 * M * N * K
+        tot_t += t; tot_f += f
+        print(f"NT {name:14s} N={N:5d} K={K:5d}: {t*1e6:8.1f} us  {f/t/1e12:7.1f} TF")
+    print(f"NT total {tot_t*1e3:.3f} ms/layer  {tot_f/tot_t/1e12:.1f} TF")
+    tt = tf = 0.0
+    for name, N, K in [("dW2", 768, 3072), ("dW1", 3072, 768), ("dWo", 768, 768), ("dWqkv", 2304, 768)]:
+        dY = torch.randn(M, N, device=dev).bfloat16()
+        X = torch.randn(M, K, device=dev).bfloat16()
+        C = torch.zeros(N, K, device=dev)
+        t = timeit(lambda: _lib.call("climb_gemm_bf16_tn", dY, N, X, K, C, K, M, N, K, None, st()))
+        f = 2.0 * M * N * K
+        tt += t; tf += f
+        print(f"TN {name:14s} N={N:5d} K={K:5d}: {t*1e6:8.1f} us  {f/t/1e12:7.1f} TF")
+    print(f"TN total {tt*1e3:.3f} ms/layer  {tf/tt/1e12:.1f} TF")
