@@ -3,11 +3,11 @@
 //   NT  C[M,N] = epi(A[M,K] . B[N,K]^T + bias)      forward (B = W) and input-gradient (B = W^T shadow) GEMMs
 //   TN  C[N,K] += A[M,N]^T . B[M,K]                 weight-gradient GEMM, reduction over the token dimension M
 //
-// Both: 256 threads = 4 waves (2x2), block tile 128x128, BK = 64, double-buffered LDS, global -> registers -> LDS
-// staging with the next tile's loads in flight under the current tile's MFMAs (one barrier per k-tile).
-// Operands are issued "swapped" (MFMA A = the weight-side tile, MFMA B = the token-side tile) so that in the 32x32
-// accumulator layout a lane owns ONE output row and 4 CONSECUTIVE output columns per register group: epilogues read
-// bias / residual / pre-activation and write C as 8- or 16-byte vectors.
+// Both: block tile 128x128 (NT also 64x128 and 96x192), BK = 64, double-buffered LDS filled by LDS-DMA with the next tile's
+// loads in flight under the current tile's MFMAs (one barrier per k-tile).
+// NT operands are issued "swapped" (MFMA A = the weight-side tile, MFMA B = the token-side tile): in the 32x32 accumulator
+// layout a lane then owns ONE output row and 4 CONSECUTIVE output columns per register group, which the epilogue turns
+// through LDS into whole-row (128-byte line) global accesses.
 //
 // LDS images:
 //   NT: [128 rows][64 k] bf16, 128-B rows, 16-B chunks XOR-swizzled by swz(row) so that the ds_read_b128 fragment reads
