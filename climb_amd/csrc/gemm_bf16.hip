@@ -367,14 +367,98 @@ __global__ __launch_bounds__(384) void gemm_bf16_nt96_kernel(const bf16_t* __res
   nt_epilogue<TO, EPI, 3, 1>(acc, ax, smem + wid * 12288, m0 + wm * 32, n0 + wn * 96, M, N, C, ldc, bias, aux_out, ldauxo);
 }
 
+// 192 x 192 tile, ONE workgroup of 12 waves per CU, three 48 KB LDS stages: the deep-prefetch variant.
+// The 128 x 128 kernels keep one k-tile in flight; measured, their k-loop sits at 28-36 % MFMA utilisation because an
+// LDS-DMA tile takes longer to land (~1-2 us under load) than the MFMAs of one k-tile last, and a second 64 KB workgroup per CU
+// is all the LDS there is.  Here two k-tiles are always in flight (raw s_barrier + counted vmcnt, never vmcnt(0) in the loop),
+// the tile reads 1.5x fewer operand bytes per flop, and 12288 x {768, 2304, 3072} outputs are exactly {1, 3, 4} rounds of 256 CUs.
+// Waves: 6 (M) x 2 (N), each 32 x 96 = three 32x32 blocks sharing one token fragment (3 waves per SIMD).
+#define N192_T 192
+#define N192_STAGE (2 * N192_T * GB_BK * 2)      // A + B image of one k-tile: 48 KB
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+template <typename TO, int EPI>
+__global__ __launch_bounds__(768) void gemm_bf16_nt192_kernel(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ B, long ldb,
+                                                              TO* __restrict__ C, long ldc, int M, int N, int K, const float* __restrict__ bias,
+                                                              const void* __restrict__ aux, long ldaux, bf16_t* __restrict__ aux_out, long ldauxo,
+                                                              const bf16_t* __restrict__ aux2, long ldaux2) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // 3 stages = 144 KB
+  constexpr int ABYTES = N192_T * GB_BK * 2;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, wm = wid >> 1, wn = wid & 1, half = lane >> 5, l31 = lane & 31;
+  int tm, tn;
+  nt_tile<8>((M + N192_T - 1) / N192_T, N / N192_T, tm, tn);
+  const int m0 = tm * N192_T, n0 = tn * N192_T;
+  f32x16 acc[3][1];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.f;
+  const int nk = K / GB_BK;
+  // prologue: k-tiles 0 and 1 in flight (4 DMA instructions per wave per stage)
+  nt_glds<12, N192_T>(A, lda, m0, 0, M, smem);
+  nt_glds<12, N192_T>(B, ldb, n0, 0, N, smem + ABYTES);
+  if (nk > 1) {
+    nt_glds<12, N192_T>(A, lda, m0, GB_BK, M, smem + N192_STAGE);
+    nt_glds<12, N192_T>(B, ldb, n0, GB_BK, N, smem + N192_STAGE + ABYTES);
+  }
+  AuxRegs<EPI, 12> ax;
+  nt_aux_prefetch<EPI, 3, 1>(ax, m0 + wm * 32, n0 + wn * 96, M, N, aux, ldaux, aux2, ldaux2);
+  for (int kt = 0; kt < nk; ++kt) {
+    // k-tile kt has landed for THIS wave once at most the 4 newest vector-memory operations are outstanding (returns are in
+    // order, and k-tile kt+1's 4 DMAs were issued after it); the barrier extends that to every wave's share, and also says
+    // every wave is done reading k-tile kt-1, whose stage is refilled next.
+    if (kt + 1 < nk) wait_vmcnt<4>(); else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (kt + 2 < nk) {
+      unsigned char* Sn = smem + ((kt + 2) % 3) * N192_STAGE;
+      nt_glds<12, N192_T>(A, lda, m0, (kt + 2) * GB_BK, M, Sn);
+      nt_glds<12, N192_T>(B, ldb, n0, (kt + 2) * GB_BK, N, Sn + ABYTES);
+    }
+    const unsigned char* As = smem + (kt % 3) * N192_STAGE;
+    const unsigned char* Bs = As + ABYTES;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int c = 2 * ks + half;
+      const int rowa = wm * 32 + l31;
+      const bf16x8 fa = as_bf16x8(*reinterpret_cast<const u32x4*>(As + rowa * 128 + ((c ^ swz(rowa)) << 4)));
+      bf16x8 fb[3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const int rowb = wn * 96 + i * 32 + l31;
+        fb[i] = as_bf16x8(*reinterpret_cast<const u32x4*>(Bs + rowb * 128 + ((c ^ swz(rowb)) << 4)));
+      }
+#pragma unroll
+      for (int i = 0; i < 3; ++i) acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[i], fa, acc[i][0], 0, 0, 0);
+    }
+  }
+  __syncthreads();      // every wave is past the last k-tile: the stages become 12 per-wave 12 KB staging regions
+  nt_epilogue<TO, EPI, 3, 1>(acc, ax, smem + wid * 12288, m0 + wm * 32, n0 + wn * 96, M, N, C, ldc, bias, aux_out, ldauxo);
+}
+
+template <typename TO, int EPI>
+static int nt192_launch(int nwg, hipStream_t st, const bf16_t* A, long lda, const bf16_t* B, long ldb, TO* C, long ldc, int M, int N, int K,
+                        const float* bias, const void* aux, long ldaux, bf16_t* aux_out, long ldauxo, const bf16_t* aux2, long ldaux2) {
+  static bool configured = false;      // per instantiation; the attribute is sticky for the process
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_nt192_kernel<TO, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * N192_STAGE);
+    if (e != hipSuccess) return (int)e;
+    configured = true;
+  }
+  hipLaunchKernelGGL((gemm_bf16_nt192_kernel<TO, EPI>), dim3(nwg), dim3(768), 3 * N192_STAGE, st, A, lda, B, ldb, C, ldc, M, N, K, bias, aux, ldaux,
+                     aux_out, ldauxo, aux2, ldaux2);
+  return CLIMB_OK;
+}
+
 static int g_tn_target = 512;
 static int g_nt_waves = 8;     // measured on MI355X (r01): 8 waves 537 TF vs 4 waves 514 TF average over the per-layer shapes
 static int g_nt_96 = 1;        // 96x192 tiles when they tile the problem into full rounds
+static int g_nt_192 = 1;       // 192x192 deep-prefetch tiles for large problems with N % 192 == 0
 static int g_nt_small_m = 1;   // 64x128 tiles for shapes whose 128x128 tiling quantises badly on 512 workgroup slots
 extern "C" int climb_set_option(int key, int value) {
   if (key == 1 && (value == 4 || value == 8)) { g_nt_waves = value; return CLIMB_OK; }
   if (key == 2) { g_nt_small_m = value; return CLIMB_OK; }
   if (key == 4) { g_nt_96 = value; return CLIMB_OK; }
+  if (key == 5) { g_nt_192 = value; return CLIMB_OK; }
   if (key == 3 && value > 0) { g_tn_target = value; return CLIMB_OK; }
   return CLIMB_EINVAL;
 }
@@ -393,9 +477,16 @@ static int nt_dispatch(const bf16_t* A, long lda, const bf16_t* B, long ldb, TO*
   const bool use96 = glds && g_nt_96 == 1 && (M % N96_BM) == 0 && (N % N96_BN) == 0 && nwg96 == 512;      // exactly one full round (measured: better than 64x128 there, worse than 128x128 on multi-round shapes)
   const bool use64 = glds && g_nt_small_m == 1 && waste(nwg64, 768) + 0.10 < waste(nwg, 512);
 #define NT_ARGS A, lda, B, ldb, C, ldc, M, N, K, bias, aux, ldaux, aux_out, ldauxo, aux2, ldaux2
+  const int nwg192 = ((M + N192_T - 1) / N192_T) * (N / N192_T);
+  // measured (r01, M = 12288): the single-round N = 768 GEMMs gain 15-25 % (K = 3072: 102 -> 79 us); on multi-round shapes the
+  // epilogue-heavy kernels lose the second resident workgroup that computes while the first one stores, and come out 5-12 % slower
+  const bool use192 = glds && g_nt_192 == 1 && (N % N192_T) == 0 && K >= 2 * GB_BK && nwg192 >= 160 && nwg192 <= 256;
 #define NT_LAUNCH(E)                                                                                                           \
   do {                                                                                                                         \
-    if (use96) hipLaunchKernelGGL((gemm_bf16_nt96_kernel<TO, E>), dim3(nwg96), dim3(384), 0, st, NT_ARGS); \
+    if (use192) {                                                                                                              \
+      int rc = nt192_launch<TO, E>(nwg192, st, NT_ARGS);                                                                       \
+      if (rc != CLIMB_OK) return rc;                                                                                           \
+    } else if (use96) hipLaunchKernelGGL((gemm_bf16_nt96_kernel<TO, E>), dim3(nwg96), dim3(384), 0, st, NT_ARGS); \
     else if (use64) hipLaunchKernelGGL((gemm_bf16_nt64_kernel<TO, E>), dim3(nwg64), dim3(256), 0, st, NT_ARGS); \
     else if (glds && g_nt_waves == 8) hipLaunchKernelGGL((gemm_bf16_nt_kernel<TO, E, true, 1>), grid, dim3(512), 0, st, NT_ARGS);   \
     else if (glds) hipLaunchKernelGGL((gemm_bf16_nt_kernel<TO, E, true, 2>), grid, dim3(256), 0, st, NT_ARGS);                 \

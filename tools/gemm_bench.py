@@ -26,6 +26,8 @@ def timeit(fn, iters=20):
 if __name__ == "__main__":
     if os.environ.get("NT_WAVES") is not None:
         _lib.call("climb_set_option", 1, int(os.environ["NT_WAVES"]))
+    if os.environ.get("NT192") is not None:
+        _lib.call("climb_set_option", 5, int(os.environ["NT192"]))
     if os.environ.get("NT96") is not None:
         _lib.call("climb_set_option", 4, int(os.environ["NT96"]))
     if os.environ.get("TN_TARGET") is not None:
