@@ -581,6 +581,9 @@ __device__ __forceinline__ bf16x8 tn_frag(const unsigned char* __restrict__ S, i
 }
 
 // grid: tiles * splits.  C[n][k] += sum_m A[m][n] * B[m][k]; ATOMIC = 1 when several splits accumulate into C.
+// Measured alternatives (r01, slower, removed): 192 x 192 tiles with three stages and 12 waves (329 vs 305 us per layer) and
+// 96 x 192 tiles filling 512 workgroups exactly (376 us): with two transpose reads per fragment the 64 x 64 wave tile's
+// read-per-MFMA ratio matters more here than tile quantisation.
 template <bool ATOMIC, bool GLDS>
 __global__ __launch_bounds__(256) void gemm_bf16_tn_kernel(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ B, long ldb,
                                                            float* __restrict__ C, long ldc, int M, int N, int K, int rows_per_split,
@@ -597,7 +600,11 @@ __global__ __launch_bounds__(256) void gemm_bf16_tn_kernel(const bf16_t* __restr
     bid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + idx;
   }
   const int split = bid / tiles, tile = bid - split * tiles;
-  const int n0 = (tile % nbn) * 128, k0 = (tile / nbn) * 128;
+  // tile order inside a split: the XCD's contiguous chunk should span the NARROWER operand completely and only a slice of the wider
+  // one (N = 3072, K = 768: a chunk of 6 k-tiles x 9 n-tiles re-reads X per XCD, not the 4x larger dY)
+  const int nkt = (K + 127) / 128;
+  const int ntile = nbn > nkt ? tile / nkt : tile % nbn, ktile = nbn > nkt ? tile % nkt : tile / nbn;
+  const int n0 = ntile * 128, k0 = ktile * 128;
   const int mbeg = split * rows_per_split;
   const int mend = min(M, mbeg + rows_per_split);
   f32x16 acc[2][2];   // [n block][k block]
@@ -610,7 +617,6 @@ __global__ __launch_bounds__(256) void gemm_bf16_tn_kernel(const bf16_t* __restr
   // bias gradient db[n] = sum_m dY[m][n] rides along as dY^T . 1: one extra MFMA per dY fragment against an all-ones operand
   // (every column of the result holds the column sum).  The reduction steps are dealt round-robin to the k-tiles that share
   // this n-tile, so every workgroup carries the same small share of the extra work (no slow tail).
-  const int nkt = (K + 127) / 128, ktile = tile / nbn;
   const bool do_bias = dbias != nullptr && wk == 0;
   f32x16 accb[2];
 #pragma unroll
@@ -704,6 +710,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_tn_kernel(const bf16_t* __restr
 extern "C" int climb_gemm_bf16_tn(const void* A, long lda, const void* B, long ldb, float* C, long ldc, int M, int N, int K, float* dbias,
                                   void* stream) {
   if (M <= 0 || N <= 0 || K <= 0 || (N % 8) || (K % 8) || (lda % 8) || (ldb % 8) || !al16p(A) || !al16p(B)) return CLIMB_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
   const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
   int splits = g_tn_target / tiles;                               // as many token-range splits as fit ONE round of 2 workgroups per CU
                                                                   // (measured: 432 workgroups 579 TF vs 576 workgroups 436 TF)
@@ -714,7 +721,6 @@ extern "C" int climb_gemm_bf16_tn(const void* A, long lda, const void* B, long l
   rows = (rows + TN_BR - 1) / TN_BR * TN_BR;
   splits = (M + rows - 1) / rows;
   dim3 grid(tiles * splits), blk(256);
-  hipStream_t st = (hipStream_t)stream;
   const bool glds = (M % TN_BR) == 0 && N >= 8 && K >= 8;      // the DMA path cannot zero-fill a ragged reduction tail
 #define TN_LAUNCH(AT, GL) hipLaunchKernelGGL((gemm_bf16_tn_kernel<AT, GL>), grid, blk, 0, st, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc, M, N, K, rows, dbias)
   if (splits > 1) { if (glds) TN_LAUNCH(true, true); else TN_LAUNCH(true, false); }
