@@ -169,26 +169,52 @@ extern "C" int climb_transpose_bf16(const void* in, void* out, int R, int C, voi
   return CLIMB_OK;
 }
 
-// many [R,C] -> [C,R] transposes in one launch: table[i] = {src_off, dst_off, R, C} (elements), grid.y = matrix
+// many [R,C] -> [C,R] transposes in one launch: table[i] = {src_off, dst_off, R, C} (elements), grid.y = matrix.
+// 64x64 tiles; when R and C are multiples of 8 (every weight matrix of the model) both global sides move 16 bytes per thread:
+// a wave reads 8 rows x 128 B and writes 8 transposed rows x 128 B, the 2-byte element shuffle happens in LDS only.
 __global__ __launch_bounds__(256) void transpose_bf16_batched_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst,
                                                                      const long* __restrict__ table) {
-  __shared__ bf16_t tile[64][66];
+  __shared__ __attribute__((aligned(16))) bf16_t tile[64][72];
   const long* t = table + 4 * blockIdx.y;
   const int R = (int)t[2], C = (int)t[3];
   const int tc = (C + 63) / 64, tr = (R + 63) / 64;
   const bf16_t* in = src + t[0];
   bf16_t* out = dst + t[1];
+  const bool vec = ((R | C) & 7) == 0 && ((t[0] | t[1]) & 7) == 0;
   for (int tileid = blockIdx.x; tileid < tc * tr; tileid += gridDim.x) {
     const int r0 = (tileid / tc) * 64, c0 = (tileid % tc) * 64;
     __syncthreads();
-    for (int e = threadIdx.x; e < 64 * 64; e += 256) {
-      int r = e >> 6, c = e & 63;
-      tile[r][c] = (r0 + r < R && c0 + c < C) ? in[(long)(r0 + r) * C + c0 + c] : (bf16_t)0;
-    }
-    __syncthreads();
-    for (int e = threadIdx.x; e < 64 * 64; e += 256) {
-      int c = e >> 6, r = e & 63;
-      if (r0 + r < R && c0 + c < C) out[(long)(c0 + c) * R + r0 + r] = tile[r][c];
+    if (vec) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int q = threadIdx.x + 256 * i, r = q >> 3, c = (q & 7) * 8;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (r0 + r < R && c0 + c < C) v = *reinterpret_cast<const uint4*>(in + (long)(r0 + r) * C + c0 + c);
+        *reinterpret_cast<uint4*>(&tile[r][c]) = v;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int q = threadIdx.x + 256 * i, c = q >> 3, r = (q & 7) * 8;
+        if (r0 + r < R && c0 + c < C) {
+          uint4 v;
+          v.x = tile[r][c] | ((unsigned)tile[r + 1][c] << 16);
+          v.y = tile[r + 2][c] | ((unsigned)tile[r + 3][c] << 16);
+          v.z = tile[r + 4][c] | ((unsigned)tile[r + 5][c] << 16);
+          v.w = tile[r + 6][c] | ((unsigned)tile[r + 7][c] << 16);
+          *reinterpret_cast<uint4*>(out + (long)(c0 + c) * R + r0 + r) = v;
+        }
+      }
+    } else {
+      for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+        int r = e >> 6, c = e & 63;
+        tile[r][c] = (r0 + r < R && c0 + c < C) ? in[(long)(r0 + r) * C + c0 + c] : (bf16_t)0;
+      }
+      __syncthreads();
+      for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+        int c = e >> 6, r = e & 63;
+        if (r0 + r < R && c0 + c < C) out[(long)(c0 + c) * R + r0 + r] = tile[r][c];
+      }
     }
   }
 }

@@ -184,16 +184,19 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict_
   float* out = o.out[blockIdx.y];
   if (!out) return;
   const float* src = part + o.col_off[blockIdx.y];
-  float s0 = 0.f, s1 = 0.f;
+  // 8 independent loads in flight per thread: the reduction is latency-bound (few hundred partial rows, tiny grid)
+  float s[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) s[u] = 0.f;
   if (c < ncols) {
     int b = ry;
-    for (; b + 8 < nblk; b += 16) {
-      s0 += src[(long)b * stride + c];
-      s1 += src[(long)(b + 8) * stride + c];
+    for (; b + 56 < nblk; b += 64) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s[u] += src[(long)(b + 8 * u) * stride + c];
     }
-    if (b < nblk) s0 += src[(long)b * stride + c];
+    for (; b < nblk; b += 8) s[0] += src[(long)b * stride + c];
   }
-  red[ry][cx] = s0 + s1;
+  red[ry][cx] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
   __syncthreads();
   if (ry == 0 && c < ncols) {
     float s = ((red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx])) + ((red[4][cx] + red[5][cx]) + (red[6][cx] + red[7][cx]));
