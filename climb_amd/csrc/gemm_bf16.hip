@@ -373,6 +373,10 @@ __global__ __launch_bounds__(384) void gemm_bf16_nt96_kernel(const bf16_t* __res
 // is all the LDS there is.  Here two k-tiles are always in flight (raw s_barrier + counted vmcnt, never vmcnt(0) in the loop),
 // the tile reads 1.5x fewer operand bytes per flop, and 12288 x {768, 2304, 3072} outputs are exactly {1, 3, 4} rounds of 256 CUs.
 // Waves: 6 (M) x 2 (N), each 32 x 96 = three 32x32 blocks sharing one token fragment (3 waves per SIMD).
+// Measured alternative (r01, slower, removed): the same tile as a persistent kernel with two producer waves issuing all
+// LDS-DMAs and 12 consumer waves whose epilogue stores drain under the next tile's k-loop -- qkv 66 / GELU 162 / xGELU' 118 us
+// against 62 / 114 / 111 for two independent 128 x 128 workgroups per CU: with one workgroup per CU nothing computes while the
+// consumers run the (VALU-heavy) epilogue.
 #define N192_T 192
 #define N192_STAGE (2 * N192_T * GB_BK * 2)      // A + B image of one k-tile: 48 KB
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
