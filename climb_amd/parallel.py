@@ -11,9 +11,15 @@ Why it is shaped like this on MI355X
   * `finish()` makes the compute stream wait for every outstanding collective; only then are the EWC penalty gradient
     (identical on every rank, so it must NOT be summed) and the fused AdamW enqueued.
   * ReduceOp.AVG on RCCL; SUM followed by a scale on backends without AVG (gloo, used by the CPU tests).
+  * Payload: fp32 (bit-faithful averaging, the parity default) or bf16 (`compress="bf16"`, the default of the bf16 throughput
+    mode; SURVEY.md §8(e) "prefer bf16 payload"): the range is cast into a persistent bf16 staging buffer laid out like the
+    gradient buffer, reduced there, and cast back in `finish()`.  Halves the bytes every xGMI link carries (480 -> 240 MB per
+    step) for two extra streaming passes over the gradients; the rounding (2^-9 relative per element, once) is below the bf16
+    GEMM noise already in those gradients.  `CLIMB_AMD_DP_COMPRESS=none|bf16` overrides.
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional, Tuple
 
 import torch
@@ -21,8 +27,11 @@ import torch.distributed as dist
 
 
 class GradientAllReducer:
-    def __init__(self, model=None, process_group=None, min_bucket_elems: int = 4 * 1024 * 1024, broadcast: bool = True):
+    def __init__(self, model=None, process_group=None, min_bucket_elems: int = 4 * 1024 * 1024, broadcast: bool = True,
+                 compress: Optional[str] = None):
         self.pg = process_group
+        self.compress = compress            # None = decide at attach() from the engine's precision
+        self._stage = None
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.min_bucket = min_bucket_elems
         self.eng = None
@@ -42,6 +51,13 @@ class GradientAllReducer:
         """(Re)bind to an engine: its `grad_ready_hook` fires with a flat range whose gradients are final."""
         self.eng = eng
         eng.grad_ready_hook = self.on_ready
+        mode = os.environ.get("CLIMB_AMD_DP_COMPRESS") or self.compress
+        if mode is None:
+            mode = "bf16" if getattr(eng, "precision", "fp32") == "bf16" else "none"
+        if mode not in ("none", "bf16"):
+            raise ValueError(f"unknown gradient compression {mode!r}")
+        self.compress = mode
+        self._stage = None
 
     def begin(self):
         self._works.clear()
@@ -51,10 +67,16 @@ class GradientAllReducer:
         if self.world == 1:
             return
         chunk = self.eng.grad[lo:hi]
+        if self.compress == "bf16":
+            if self._stage is None:
+                self._stage = torch.empty(self.eng.grad.numel(), dtype=torch.bfloat16, device=self.eng.grad.device)
+            stage = self._stage[lo:hi]
+            stage.copy_(chunk)                 # fp32 -> bf16 (round to nearest even) on the compute stream
+            chunk = stage
         op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
         work = dist.all_reduce(chunk, op=op, group=self.pg, async_op=True)
         self._works.append((work, lo, hi))
-        self.bytes_reduced += (hi - lo) * 4
+        self.bytes_reduced += (hi - lo) * chunk.element_size()
 
     def on_ready(self, lo: int, hi: int):
         """Ranges arrive in backward order (head, final norm + pooler, layer 11 ... layer 0, embeddings).  Adjacent small
@@ -80,6 +102,8 @@ class GradientAllReducer:
             self._pending = None
         for work, lo, hi in self._works:
             work.wait()
+            if self.compress == "bf16":
+                self.eng.grad[lo:hi].copy_(self._stage[lo:hi])
             if not self._avg and self.world > 1:
                 self.eng.grad[lo:hi].div_(self.world)
         self._works.clear()
