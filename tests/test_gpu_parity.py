@@ -533,6 +533,34 @@ def test_variable_resolution_batch_vs_reference(golden_dir, precision, tol):
     _close(out[1], z["logits"], tol, "eval logits")
 
 
+def test_maximum_sequence_384x640_vs_oracle():
+    """The largest input the reference's processor can emit (shortest edge 384, longest capped at 640: 12 x 20 patches, 40 + 1 + 240
+    = 281 tokens, S_pad 288) next to a small 32-pixel-high strip and 3-token texts: step output and gradients against the oracle."""
+    sizes = [(384, 640), (32, 608)]
+    model, P = make_model(["vqa"], 7, precision="fp32")
+    enc = vo.synthetic_varres_encodings(sizes, seed=5)
+    target = vo.synthetic_vqa_targets(len(sizes), seed=5)
+    texts = dict(input_ids=enc["input_ids"], token_type_ids=enc["token_type_ids"], attention_mask=enc["attention_mask"])
+    images = dict(pixel_values=enc["pixel_values"], pixel_mask=enc["pixel_mask"])
+    model.train()
+    loss, (pooled, logits), _, _ = model.fused_forward_backward("vqa", images, texts, target)
+    oloss, (opooled, ologits), _, oG = vo.train_step(P, "vqa", enc, target)
+    _close(pooled, opooled, TOL, "pooled")
+    _close(logits, ologits, TOL, "logits")
+    _close(loss, oloss, TOL, "loss")
+    assert torch.equal(logits.argmax(-1).cpu(), ologits.argmax(-1))
+    G = grads_of(model)
+    for n, g in oG.items():
+        if n in G and not n.endswith("attention.key.bias"):
+            _close(G[n], g, TOL, n)
+    # one patch more than the attention tiles are sized for is refused loudly, not truncated
+    with pytest.raises(NotImplementedError):
+        big = vo.synthetic_varres_encodings([(384, 672)], seed=5)
+        model.fused_forward_backward("vqa", dict(pixel_values=big["pixel_values"], pixel_mask=big["pixel_mask"]),
+                                     dict(input_ids=big["input_ids"], token_type_ids=big["token_type_ids"], attention_mask=big["attention_mask"]),
+                                     vo.synthetic_vqa_targets(1, seed=5))
+
+
 def test_hipgraph_replay_matches_eager():
     """The captured step (one hipGraph launch) must reproduce the eager launches bit for bit, across optimizer steps and new inputs."""
     dev = _dev()
