@@ -178,14 +178,16 @@ extern "C" int climb_attn_fwd_bf16(const void* qkv, const float* key_bias, void*
 //     S^T = K Q^T, dP^T = V dO^T, P^T = exp(S^T*scale + bias - lse), dS^T = P^T (dP^T - delta) scale, dQ^T += K^T dS^T
 // PHASE 1 (dK, dV):  outer = key block (K, V rows in registers), inner = queries (Q, dO images in LDS)
 //     S = Q K^T, dP = dO V^T, P, dS;  dV^T += dO^T P,  dK^T += Q^T dS
+// delta[q] = sum_d dO[q][d] O[q][d] (the softmax-backward row term) is computed by PHASE 0 itself, whose waves already hold
+// their dO rows in registers, and written out for PHASE 1, which needs it for every query.
 // dynamic LDS: Xs[S_pad][128 B] | Ys[S_pad][128 B] | bias_s | lse_s | delta_s
 // launch bound 576 (= 9 waves, 3 per SIMD) caps the kernel at 168 VGPRs: three workgroups stay resident per CU, which is worth
 // more than the 17 spilled dwords of phase 1 (measured: 63 us vs 80 us per layer with a 256-thread bound)
 template <int PHASE>
 __global__ __launch_bounds__(576) void attn_bwd_bf16_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ key_bias,
-                                                            const bf16_t* __restrict__ dctx, const float* __restrict__ lse,
-                                                            const float* __restrict__ delta, bf16_t* __restrict__ dqkv, int S_pad, int heads,
-                                                            float scale) {
+                                                            const bf16_t* __restrict__ dctx, const bf16_t* __restrict__ ctx,
+                                                            const float* __restrict__ lse, float* __restrict__ delta,
+                                                            bf16_t* __restrict__ dqkv, int S_pad, int heads, float scale) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* Xs = smem;
   unsigned char* Ys = Xs + S_pad * 128;
@@ -210,7 +212,7 @@ __global__ __launch_bounds__(576) void attn_bwd_bf16_kernel(const bf16_t* __rest
   for (int i = tid; i < S_pad; i += blockDim.x) {
     bias_s[i] = key_bias[(long)b * S_pad + i];
     lse_s[i] = lse[((long)b * heads + h) * S_pad + i];
-    delta_s[i] = delta[((long)b * heads + h) * S_pad + i];
+    if (PHASE == 1) delta_s[i] = delta[((long)b * heads + h) * S_pad + i];
   }
   __syncthreads();
   const int NB = S_pad / 32;
@@ -224,7 +226,18 @@ __global__ __launch_bounds__(576) void attn_bwd_bf16_kernel(const bf16_t* __rest
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc1[d][r] = acc2[d][r] = 0.f;
     const int my = ob * 32 + l31;
-    const float my_lse = lse_s[my], my_delta = delta_s[my], my_bias = bias_s[my];
+    float my_delta = 0.f;
+    if (PHASE == 0) {
+      bf16x8 fo[4];
+      load_rows(fo, ctx + (long)b * S_pad * H + h * AB_D, H, ob * 32, lane);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) my_delta += (float)fo[ks][e] * (float)f2[ks][e];
+      my_delta += __shfl_xor(my_delta, 32, 64);
+      if (half == 0) delta[((long)b * heads + h) * S_pad + my] = my_delta;
+    }
+    const float my_lse = lse_s[my], my_bias = bias_s[my];
     for (int ib = 0; ib < NB; ++ib) {
       f32x16 s, dp;
 #pragma unroll
@@ -267,8 +280,8 @@ __global__ __launch_bounds__(576) void attn_bwd_bf16_kernel(const bf16_t* __rest
   }
 }
 
-extern "C" int climb_attn_bwd_bf16(const void* qkv, const float* key_bias, const void* dctx, const float* lse, const float* delta, void* dqkv, int B,
-                                   int S_pad, int heads, int head_dim, void* stream) {
+extern "C" int climb_attn_bwd_bf16(const void* qkv, const float* key_bias, const void* dctx, const void* ctx, const float* lse, float* delta,
+                                   void* dqkv, int B, int S_pad, int heads, int head_dim, void* stream) {
   if (head_dim != AB_D || S_pad % 32 || S_pad <= 0 || S_pad > 512) return CLIMB_EUNSUPPORTED;
   size_t lds = (size_t)S_pad * 256 + (size_t)S_pad * 12;
   static size_t lds_set = 0;
@@ -282,10 +295,10 @@ extern "C" int climb_attn_bwd_bf16(const void* qkv, const float* key_bias, const
   const float scale = 1.0f / sqrtf((float)head_dim);
   const int nthreads = 64 * ((S_pad / 32) % 3 == 0 ? 3 : 4);     // measured at S_pad = 192: 3-4 waves 63 us, 6 waves 78 us (register pressure)
   hipLaunchKernelGGL((attn_bwd_bf16_kernel<0>), dim3(B * heads), dim3(nthreads), lds, (hipStream_t)stream, (const bf16_t*)qkv, key_bias,
-                     (const bf16_t*)dctx, lse, delta, (bf16_t*)dqkv, S_pad, heads, scale);
+                     (const bf16_t*)dctx, (const bf16_t*)ctx, lse, delta, (bf16_t*)dqkv, S_pad, heads, scale);
   LAUNCH_CHECK();
   hipLaunchKernelGGL((attn_bwd_bf16_kernel<1>), dim3(B * heads), dim3(nthreads), lds, (hipStream_t)stream, (const bf16_t*)qkv, key_bias,
-                     (const bf16_t*)dctx, lse, delta, (bf16_t*)dqkv, S_pad, heads, scale);
+                     (const bf16_t*)dctx, (const bf16_t*)ctx, lse, delta, (bf16_t*)dqkv, S_pad, heads, scale);
   LAUNCH_CHECK();
   return CLIMB_OK;
 }

@@ -452,11 +452,11 @@ class ViltEngine:
     def attn_bwd(self, qkv, key_bias, dctx, ctx, lse, delta, dqkv, B, S_pad):
         cfg = self.cfg
         st = _stream()
-        _lib.call("climb_attn_delta", dctx, ctx, self.adt, delta, B, S_pad, cfg["heads"], st)
         if self.precision == "fp32":
+            _lib.call("climb_attn_delta", dctx, ctx, self.adt, delta, B, S_pad, cfg["heads"], st)
             _lib.call("climb_attn_bwd_f32", qkv, key_bias, dctx, lse, delta, dqkv, B, S_pad, cfg["heads"], cfg["head_dim"], st)
-        else:
-            _lib.call("climb_attn_bwd_bf16", qkv, key_bias, dctx, lse, delta, dqkv, B, S_pad, cfg["heads"], cfg["head_dim"], st)
+        else:   # the bf16 kernel computes delta in its first phase (`delta` is its scratch)
+            _lib.call("climb_attn_bwd_bf16", qkv, key_bias, dctx, ctx, lse, delta, dqkv, B, S_pad, cfg["heads"], cfg["head_dim"], st)
 
     # ------------------------------------------------------------------ encoder backward
     def _ready(self, lo, hi):
