@@ -352,12 +352,62 @@ def case_replay(fname, B=2, tasks=("vqa", "nlvr2"), wseed=42, dseed=6):
                         meta=np.array([f"task=vqa;tasks={','.join(tasks)};B={B};wseed={wseed};dseed={dseed};lr=1e-4;fresh_adamw=1"]))
 
 
+def case_cl_eval(fname="cl_eval.json"):
+    """Row F3: the reference's own upstream_knowledge_transfer_eval / catastrophic_forgetting_eval
+    (REF/cl_evaluation/evaluate_cl_algorithm.py:32-140) on a synthetic 4-task run: the inputs (results.json contents, single-task
+    scores, the scores `eval_forgetting` returns) and the dictionaries the reference computes from them."""
+    import argparse
+    import importlib
+    import json
+    import shutil
+    import tempfile
+    print(f"[{fname}] CL metrics from the reference's evaluate_cl_algorithm")
+    ri.import_reference()
+    ref_eval = importlib.import_module("cl_evaluation.evaluate_cl_algorithm")
+    tasks = ["vqa", "nlvr2", "snli-ve", "vcr"]
+    cl_scores = {"vqa": 67.31, "nlvr2": 73.07, "snli-ve": 76.28, "vcr": 61.02}
+    single = {"vqa": 67.70, "nlvr2": 73.07 + 0.44, "snli-ve": 76.31, "vcr": 61.31}
+    forget = {("nlvr2", "vqa"): 41.2, ("snli-ve", "vqa"): 30.5, ("snli-ve", "nlvr2"): 51.9, ("vcr", "vqa"): 12.25, ("vcr", "nlvr2"): 50.0,
+              ("vcr", "snli-ve"): 70.125}
+    root = tempfile.mkdtemp(prefix="climb_cl_eval_")
+    try:
+        args = argparse.Namespace(ordered_cl_tasks=tasks, output_dir=root, encoder_name="vilt")
+        run_dir = os.path.join(root, "vilt-sequential_ft-task0_vqa-task1_nlvr2-task2_snli-ve-task3_vcr")
+        os.makedirs(run_dir)
+        results = [{"task_num": i, "task_key": t, "best_score": cl_scores[t], "best_epoch": 3 + i} for i, t in enumerate(tasks)]
+        results_file = os.path.join(run_dir, "results.json")
+        json.dump(results, open(results_file, "w"))
+        for t in tasks:
+            d = os.path.join(root, "vilt-singletask_ft-task0_{}".format(t))
+            os.makedirs(d)
+            json.dump([{"task_num": 0, "task_key": t, "best_score": single[t], "best_epoch": 5}], open(os.path.join(d, "results.json"), "w"))
+
+        class _Trainer:
+            def __init__(self, key):
+                self.key = key
+
+            def eval_forgetting(self, model, model_path):
+                cur = os.path.basename(os.path.dirname(model_path)).split("_", 1)[1]
+                return forget[(cur, self.key)]
+
+        kt = ref_eval.upstream_knowledge_transfer_eval(args, results_file)
+        cf = ref_eval.catastrophic_forgetting_eval(args, results_file, model=None, task_trainers={t: _Trainer(t) for t in tasks}, adapter_handler=None)
+    finally:
+        shutil.rmtree(root)
+    out = {"tasks": tasks, "cl_scores": cl_scores, "singletask_scores": single, "forgetting_scores": {f"{a}|{b}": v for (a, b), v in forget.items()},
+           "results": results, "knowledge_transfer": kt, "catastrophic_forgetting": {k: dict(v) for k, v in cf.items()}}
+    json.dump(out, open(os.path.join(OUT, fname), "w"), indent=1)
+
+
 def main():
     assert ri.reference_available(), "needs /root/reference (build container only)"
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(os.cpu_count() or 8)
     if len(sys.argv) > 1 and sys.argv[1] == "varres":
         case_varres("vqa_b4_varres.npz")
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "cl_eval":
+        case_cl_eval()
         return
     case_single_image("vqa", ["vqa", "nlvr2"], 2, "vqa_b2.npz")
     case_single_image("vqa", ["vqa", "nlvr2"], 3, "vqa_b3_ragged.npz", ragged=True, dseed=2)
@@ -369,6 +419,7 @@ def main():
     case_replay("replay_b2.npz")
     case_steps("vqa_b2_10steps.npz")
     case_varres("vqa_b4_varres.npz")
+    case_cl_eval()
     print("golden fixtures written to", OUT)
 
 
