@@ -303,15 +303,16 @@ class ViltEncoderWrapper(EncoderWrapper):
         self.encoder_dim = self.vilt.config.hidden_size
         self.precision = precision or default_precision()
         self._host: Optional[_EngineHost] = None
+        self._image_pipeline = None           # climb_amd.data.DeviceImagePipeline, built on first use
 
     def __deepcopy__(self, memo):
         new = self.__class__.__new__(self.__class__)
         memo[id(self)] = new
         for k, v in self.__dict__.items():
-            new.__dict__[k] = v if k == "processor" else copy.deepcopy(v, memo)
+            new.__dict__[k] = v if k in ("processor", "_image_pipeline") else copy.deepcopy(v, memo)
         return new
 
-    # --- inputs (REF:83-96).  Host work; the GPU-side input pipeline is SURVEY.md row F1 (next).
+    # --- inputs (REF:83-96)
     def process_inputs(self, images, texts) -> Dict[str, torch.Tensor]:
         dev = self.device
         if isinstance(texts, dict):                               # pre-tokenised text + pre-processed pixel tensor(s)
@@ -329,6 +330,16 @@ class ViltEncoderWrapper(EncoderWrapper):
         if self.processor is None:
             raise RuntimeError("no ViltProcessor attached: pass tensor encodings (texts=dict(input_ids=...), images=pixel tensor) "
                                "or construct the encoder with a processor")
+        if dev.type == "cuda" and os.environ.get("CLIMB_AMD_HOST_IMAGES") != "1":
+            # row F1: tokenise on the host, but resize / rescale / normalise / pad the images on the device from their raw bytes
+            # (bit-identical to ViltProcessor's tensors, a quarter of its host->device traffic, none of its host arithmetic)
+            enc = self.processor.tokenizer(texts, max_length=self.max_text_length, padding=True, truncation=True, return_tensors="pt")
+            enc = {k: v.to(dev, non_blocking=True) for k, v in enc.items()}
+            if self._image_pipeline is None:
+                from ..data import DeviceImagePipeline
+                self._image_pipeline = DeviceImagePipeline(dev)
+            enc.update(self._image_pipeline(images))
+            return enc
         enc = self.processor(images=images, text=texts, max_length=self.max_text_length, padding=True, truncation=True, return_tensors="pt")
         return {k: v.to(dev, non_blocking=True) for k, v in enc.items()}
 

@@ -121,6 +121,15 @@ int climb_gemm_bf16_tn(const void* A, long lda, const void* B, long ldb, float* 
 int climb_attn_fwd_bf16(const void* qkv, const float* key_bias, void* ctx, float* lse, int B, int S_pad, int heads, int head_dim, void* stream);
 int climb_attn_bwd_bf16(const void* qkv, const float* key_bias, const void* dctx, const void* ctx, const float* lse, float* delta, void* dqkv, int B, int S_pad, int heads, int head_dim, void* stream);
 
+/* ---- image pre-processing on the device (replaces the host call REF/modeling/vilt.py:86-96 -> ViltProcessor ->
+ * transformers image_processing_pil_vilt.py:127-242 -> Pillow Resample.c).  All images of a batch live in byte arenas; `table` holds
+ * 16 longs per image: byte offsets of its raw [sh][sw][3] pixels, its [sh][dw][3] intermediate and its [dh][dw][3] result, then
+ * sh sw dh dw, then int offsets into `coef` of the horizontal coefficients / bounds and their row length, the same for vertical.
+ * Coefficients are Pillow's 22-bit fixed point (computed by the host: climb_amd/data/image_pipeline.py). */
+int climb_image_resample(const void* src, void* tmp, void* dst, const int* coef, const long* table, int n_images, long max_elems, void* stream);
+/* rescale + normalise (256-entry table) + zero pad to [B,3,Hc,Wc] + pixel_mask [B,Hc,Wc] (int64, 1 = real pixel) */
+int climb_image_normalize_pad(const void* img, const long* table, const float* lut, float* pixel_values, long* pixel_mask, int n_images, int Hc, int Wc, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
