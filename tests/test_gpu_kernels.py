@@ -256,7 +256,9 @@ def _bf(x):
     return x.to(torch.bfloat16)
 
 
-@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (384, 768, 768), (200, 2304, 768), (390, 48, 768), (384, 768, 3072)])
+# the last two shapes select the 192x192 three-stage kernel (160..256 tiles), with a ragged last row tile
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (384, 768, 768), (200, 2304, 768), (390, 48, 768), (384, 768, 3072), (9184, 768, 768),
+                                   (7712, 768, 1536)])
 def test_gemm_bf16_nt(M, N, K):
     """bf16 operands, fp32 accumulate: compared with a float64 product of the SAME bf16-rounded operands, so the only
     error left is accumulation order + the bf16 rounding of the output (<= 2^-8 relative)."""
