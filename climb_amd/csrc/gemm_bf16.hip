@@ -454,6 +454,7 @@ static int nt192_launch(int nwg, hipStream_t st, const bf16_t* A, long lda, cons
 }
 
 static int g_tn_target = 512;
+static int g_tn_waves = 8;     // measured (r01): 8 waves of 32 x 64 282 us per layer vs 4 waves of 64 x 64 318 us
 static int g_nt_waves = 8;     // measured on MI355X (r01): 8 waves 537 TF vs 4 waves 514 TF average over the per-layer shapes
 static int g_nt_96 = 1;        // 96x192 tiles when they tile the problem into full rounds
 static int g_nt_192 = 1;       // 192x192 deep-prefetch tiles for large problems with N % 192 == 0
@@ -463,6 +464,7 @@ extern "C" int climb_set_option(int key, int value) {
   if (key == 2) { g_nt_small_m = value; return CLIMB_OK; }
   if (key == 4) { g_nt_96 = value; return CLIMB_OK; }
   if (key == 5) { g_nt_192 = value; return CLIMB_OK; }
+  if (key == 6 && (value == 4 || value == 8)) { g_tn_waves = value; return CLIMB_OK; }
   if (key == 3 && value > 0) { g_tn_target = value; return CLIMB_OK; }
   return CLIMB_EINVAL;
 }
@@ -557,11 +559,12 @@ __device__ __forceinline__ void tn_store(const u32x4 (&r)[4], unsigned char* __r
   }
 }
 // LDS-DMA staging of a FULL [64][128] tile (rows must all be inside the reduction range; columns are clamped)
+template <int NW = 4>
 __device__ __forceinline__ void tn_glds(const bf16_t* __restrict__ P, long ld, int m0, int c0, int Ccols, unsigned char* __restrict__ S) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int j = wave * 4 + i;
+  for (int i = 0; i < 16 / NW; ++i) {
+    const int j = wave * (16 / NW) + i;
     const int slot = j * 64 + lane, row = slot >> 4, c = (slot & 15) ^ tswz(row);
     int col = c0 + c * 8;
     col = col < Ccols ? col : Ccols - 8;
@@ -588,12 +591,14 @@ __device__ __forceinline__ bf16x8 tn_frag(const unsigned char* __restrict__ S, i
 // Measured alternatives (r01, slower, removed): 192 x 192 tiles with three stages and 12 waves (329 vs 305 us per layer) and
 // 96 x 192 tiles filling 512 workgroups exactly (376 us): with two transpose reads per fragment the 64 x 64 wave tile's
 // read-per-MFMA ratio matters more here than tile quantisation.
-template <bool ATOMIC, bool GLDS>
-__global__ __launch_bounds__(256) void gemm_bf16_tn_kernel(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ B, long ldb,
+template <bool ATOMIC, bool GLDS, int NI = 2>
+__global__ __launch_bounds__(512 / NI) void gemm_bf16_tn_kernel(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ B, long ldb,
                                                            float* __restrict__ C, long ldc, int M, int N, int K, int rows_per_split,
                                                            float* __restrict__ dbias) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * TN_BR * TN_PITCH];   // [buf][A|B][64][256 B] = 64 KB
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  static_assert(GLDS || NI == 2, "register-staged fallback is written for 256 threads");
+  constexpr int NW = 8 / NI;                     // NI = 2: 4 waves of 64 x 64; NI = 1: 8 waves of 32 x 64
   const int wn = wid >> 1, wk = wid & 1, half = lane >> 5, l31 = lane & 31;
   // 1-D grid, XCD-contiguous chunks: the workgroups one XCD runs together belong to the same token range (split), so its
   // L2 holds each dY / X panel once while all (n, k) tiles of that split consume them
@@ -611,9 +616,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_tn_kernel(const bf16_t* __restr
   const int n0 = ntile * 128, k0 = ktile * 128;
   const int mbeg = split * rows_per_split;
   const int mend = min(M, mbeg + rows_per_split);
-  f32x16 acc[2][2];   // [n block][k block]
+  f32x16 acc[NI][2];   // [n block][k block]
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < NI; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -622,9 +627,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_tn_kernel(const bf16_t* __restr
   // (every column of the result holds the column sum).  The reduction steps are dealt round-robin to the k-tiles that share
   // this n-tile, so every workgroup carries the same small share of the extra work (no slow tail).
   const bool do_bias = dbias != nullptr && wk == 0;
-  f32x16 accb[2];
+  f32x16 accb[NI];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < NI; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) accb[i][r] = 0.f;
   bf16x8 ones;
@@ -634,9 +639,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_tn_kernel(const bf16_t* __restr
     ones = c.b;
   }
   u32x4 ra[4], rb[4];
-  if (GLDS) {
-    tn_glds(A, lda, mbeg, n0, N, smem);
-    tn_glds(B, ldb, mbeg, k0, K, smem + TN_BR * TN_PITCH);
+  if constexpr (GLDS) {
+    tn_glds<NW>(A, lda, mbeg, n0, N, smem);
+    tn_glds<NW>(B, ldb, mbeg, k0, K, smem + TN_BR * TN_PITCH);
   } else {
     tn_load(ra, A, lda, mbeg, n0, mend, N);
     tn_load(rb, B, ldb, mbeg, k0, mend, K);
@@ -649,10 +654,10 @@ __global__ __launch_bounds__(256) void gemm_bf16_tn_kernel(const bf16_t* __restr
     const unsigned char* As = smem + (t & 1) * (2 * TN_BR * TN_PITCH);
     const unsigned char* Bs = As + TN_BR * TN_PITCH;
     if (t + 1 < nt) {
-      if (GLDS) {
+      if constexpr (GLDS) {
         unsigned char* An = smem + ((t + 1) & 1) * (2 * TN_BR * TN_PITCH);
-        tn_glds(A, lda, mbeg + (t + 1) * TN_BR, n0, N, An);
-        tn_glds(B, ldb, mbeg + (t + 1) * TN_BR, k0, K, An + TN_BR * TN_PITCH);
+        tn_glds<NW>(A, lda, mbeg + (t + 1) * TN_BR, n0, N, An);
+        tn_glds<NW>(B, ldb, mbeg + (t + 1) * TN_BR, k0, K, An + TN_BR * TN_PITCH);
       } else {
         tn_load(ra, A, lda, mbeg + (t + 1) * TN_BR, n0, mend, N);
         tn_load(rb, B, ldb, mbeg + (t + 1) * TN_BR, k0, mend, K);
@@ -660,21 +665,21 @@ __global__ __launch_bounds__(256) void gemm_bf16_tn_kernel(const bf16_t* __restr
     }
 #pragma unroll
     for (int ms = 0; ms < TN_BR / 16; ++ms) {
-      bf16x8 fa[2], fb[2];
+      bf16x8 fa[NI], fb[2];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) fa[i] = tn_frag(As, ms * 16, wn * 64 + i * 32, lane);
+      for (int i = 0; i < NI; ++i) fa[i] = tn_frag(As, ms * 16, wn * (32 * NI) + i * 32, lane);
 #pragma unroll
       for (int j = 0; j < 2; ++j) fb[j] = tn_frag(Bs, ms * 16, wk * 64 + j * 32, lane);
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < NI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
       if (do_bias && (t % nkt) == ktile) {
-        accb[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], ones, accb[0], 0, 0, 0);
-        accb[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1], ones, accb[1], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) accb[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], ones, accb[i], 0, 0, 0);
       }
     }
-    if (!GLDS && t + 1 < nt) {
+    if constexpr (!GLDS) if (t + 1 < nt) {
       unsigned char* An = smem + ((t + 1) & 1) * (2 * TN_BR * TN_PITCH);
       tn_store(ra, An);
       tn_store(rb, An + TN_BR * TN_PITCH);
@@ -683,14 +688,14 @@ __global__ __launch_bounds__(256) void gemm_bf16_tn_kernel(const bf16_t* __restr
   }
   // D layout: col = lane&31 -> k, row = (r&3) + 8*(r>>2) + 4*half -> n ; a wave-instruction writes 2 rows x 32 consecutive floats
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < NI; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int k = k0 + wk * 64 + j * 32 + l31;
       if (k >= K) continue;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int n = n0 + wn * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int n = n0 + wn * (32 * NI) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
         if (n >= N) continue;
         float* cp = C + (long)n * ldc + k;
         if (ATOMIC) atomicAdd(cp, acc[i][j][r]);
@@ -699,10 +704,10 @@ __global__ __launch_bounds__(256) void gemm_bf16_tn_kernel(const bf16_t* __restr
     }
   if (do_bias && l31 == 0) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int n = n0 + wn * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int n = n0 + wn * (32 * NI) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
         if (n < N) atomicAdd(dbias + n, accb[i][r]);       // several k-tiles (and splits) contribute
       }
   }
@@ -727,7 +732,10 @@ extern "C" int climb_gemm_bf16_tn(const void* A, long lda, const void* B, long l
   dim3 grid(tiles * splits), blk(256);
   const bool glds = (M % TN_BR) == 0 && N >= 8 && K >= 8;      // the DMA path cannot zero-fill a ragged reduction tail
 #define TN_LAUNCH(AT, GL) hipLaunchKernelGGL((gemm_bf16_tn_kernel<AT, GL>), grid, blk, 0, st, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc, M, N, K, rows, dbias)
-  if (splits > 1) { if (glds) TN_LAUNCH(true, true); else TN_LAUNCH(true, false); }
+  if (glds && g_tn_waves == 8) {
+    if (splits > 1) hipLaunchKernelGGL((gemm_bf16_tn_kernel<true, true, 1>), grid, dim3(512), 0, st, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc, M, N, K, rows, dbias);
+    else hipLaunchKernelGGL((gemm_bf16_tn_kernel<false, true, 1>), grid, dim3(512), 0, st, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc, M, N, K, rows, dbias);
+  } else if (splits > 1) { if (glds) TN_LAUNCH(true, true); else TN_LAUNCH(true, false); }
   else { if (glds) TN_LAUNCH(false, true); else TN_LAUNCH(false, false); }
 #undef TN_LAUNCH
   LAUNCH_CHECK();

@@ -27,7 +27,7 @@ const char* climb_arch(void);
 const char* climb_error_string(int code);
 int climb_device_sync(void);
 /* tuning switches for A/B measurements: key 1 = waves per workgroup of the 128x128 bf16 NT GEMM (4 or 8); key 2 / 4 / 5 = allow the
- * 64x128 / 96x192 / 192x192 NT tile variants (0/1); key 3 = workgroup target of the 128x128 TN split */
+ * 64x128 / 96x192 / 192x192 NT tile variants (0/1); key 3 = workgroup target of the 128x128 TN split; key 6 = waves per workgroup of the TN GEMM (4 or 8) */
 int climb_set_option(int key, int value);
 
 /* ---- embeddings -------------------------------------------------------------------------------------------------- */

@@ -28,6 +28,8 @@ if __name__ == "__main__":
         _lib.call("climb_set_option", 1, int(os.environ["NT_WAVES"]))
     if os.environ.get("NT192") is not None:
         _lib.call("climb_set_option", 5, int(os.environ["NT192"]))
+    if os.environ.get("TN_WAVES") is not None:
+        _lib.call("climb_set_option", 6, int(os.environ["TN_WAVES"]))
     if os.environ.get("NT96") is not None:
         _lib.call("climb_set_option", 4, int(os.environ["NT96"]))
     if os.environ.get("TN_TARGET") is not None:
