@@ -99,8 +99,15 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TI* __restrict
     const int row = blockIdx.x * LNB_ROWS + rr * 4 + wid;
     if (row >= M) break;
     const float mu = mean[row], rs = rstd[row];
-    float4 xh[NV], g[NV], d[NV];
+    float4 xh[NV], g[NV], d[NV], rin[NV];
     float s1 = 0.f, s2 = 0.f;
+    // all three input streams of the row are requested before the first reduction (the residual gradient is only needed after
+    // it, but its latency then hides under the row statistics instead of following them)
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      int c = (i * 64 + lane) * 4;
+      rin[i] = (dres_in && c < C) ? ld4(dres_in + (long)row * ldr + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       int c = (i * 64 + lane) * 4;
@@ -120,7 +127,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TI* __restrict
     for (int i = 0; i < NV; ++i) {
       int c = (i * 64 + lane) * 4;
       if (c < C) {
-        float4 r = dres_in ? ld4(dres_in + (long)row * ldr + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 r = rin[i];
         float4 o = make_float4(r.x + rs * (g[i].x - m1 - xh[i].x * m2), r.y + rs * (g[i].y - m1 - xh[i].y * m2),
                                r.z + rs * (g[i].z - m1 - xh[i].z * m2), r.w + rs * (g[i].w - m1 - xh[i].w * m2));
         st4(dxo + (long)row * ldo + c, o);
