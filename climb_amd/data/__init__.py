@@ -1,3 +1,4 @@
 from .image_pipeline import DeviceImagePipeline, vilt_output_size, resample_coefficients
+from .prefetch import PrefetchLoader
 
-__all__ = ["DeviceImagePipeline", "vilt_output_size", "resample_coefficients"]
+__all__ = ["DeviceImagePipeline", "PrefetchLoader", "vilt_output_size", "resample_coefficients"]
