@@ -722,7 +722,9 @@ extern "C" int climb_gemm_bf16_tn(const void* A, long lda, const void* B, long l
   hipStream_t st = (hipStream_t)stream;
   const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
   // small outputs (768 x 768: 36 tiles) are atomics-bound: fewer, longer splits (measured 37 vs 44 us at 360 vs 504 workgroups)
-  int splits = (tiles <= 48 ? g_tn_target * 3 / 4 : g_tn_target) / tiles;   // as many token-range splits as fit ONE round of 2 workgroups per CU
+  // ... and sliver outputs (the adapters' 48 x 768 / 768 x 48: 6 tiles) want ~96 workgroups (measured 29 / 16 us against 58 / 22 at 384)
+  const int target = tiles <= 8 ? g_tn_target * 3 / 16 : (tiles <= 48 ? g_tn_target * 3 / 4 : g_tn_target);
+  int splits = target / tiles;                                    // as many token-range splits as fit ONE round of 2 workgroups per CU
                                                                   // (measured: 432 workgroups 579 TF vs 576 workgroups 436 TF)
   const int max_splits = (M + 4 * TN_BR - 1) / (4 * TN_BR);       // at least 4 LDS tiles of work per split
   if (splits > max_splits) splits = max_splits;
