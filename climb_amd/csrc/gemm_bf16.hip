@@ -377,6 +377,9 @@ __global__ __launch_bounds__(384) void gemm_bf16_nt96_kernel(const bf16_t* __res
 // LDS-DMAs and 12 consumer waves whose epilogue stores drain under the next tile's k-loop -- qkv 66 / GELU 162 / xGELU' 118 us
 // against 62 / 114 / 111 for two independent 128 x 128 workgroups per CU: with one workgroup per CU nothing computes while the
 // consumers run the (VALU-heavy) epilogue.
+// Also measured and removed: 128 x 128 tiles with BK = 32, three 16 KB stages and THREE workgroups per CU (24 waves, direct
+// epilogue): 75 / 154 / 142 us on the same three shapes -- twice the barriers per k and a 64-byte-row LDS image cost more than the
+// extra occupancy and prefetch depth return.
 #define N192_T 192
 #define N192_STAGE (2 * N192_T * GB_BK * 2)      // A + B image of one k-tile: 48 KB
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
