@@ -1,8 +1,7 @@
 """Import recipe for the CLiMB reference.  BUILD-CONTAINER ONLY, TEST INFRASTRUCTURE.
 
 `/root/reference` does not exist on the GPU box; nothing that runs there imports this file.
-It is used by `oracle/gen_golden.py` (to write fixtures under tests/golden/) and by
-`tests/test_oracle_vs_reference.py` (skipped when the reference tree is absent).
+It is used only by `oracle/gen_golden.py` (to write the fixtures under tests/golden/); the tests read the committed fixtures.
 
 The reference needs three throw-away stubs (wandb, torchvision, jsonlines-free imports) and a
 stub `transformers.adapters`; they are created in a temporary directory at run time and never
