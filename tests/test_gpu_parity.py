@@ -591,3 +591,76 @@ def test_hipgraph_replay_matches_eager():
         dg = (res["graph"][1][n] - P0[n]).double().norm()
         de = (res["eager"][1][n] - P0[n]).double().norm()
         assert abs(float(dg - de)) <= 2e-2 * float(de), (n, float(dg), float(de))
+
+
+# ------------------------------------------------------------------------------------------------ data parallel, end to end
+def _dp_worker(rank, world, port, q):
+    import os as _os
+    _os.environ["MASTER_ADDR"], _os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)          # both ranks share the one GPU of the test box
+    try:
+        from climb_amd.parallel import GradientAllReducer
+        torch.manual_seed(1000 + rank)                                     # replicas start DIFFERENT: the broadcast must fix that
+        model, _ = make_model(["vqa"], 42 + rank, precision="fp32")
+        ddp = GradientAllReducer(model)
+        enc = vo.synthetic_encodings(4, seed=21)
+        tgt = vo.synthetic_vqa_targets(4, seed=21)
+        sl = slice(2 * rank, 2 * rank + 2)                                 # this rank's shard of the global batch of 4
+        images, texts = enc_to_inputs({k: v[sl] for k, v in enc.items()})
+        opt = model.create_optimizer({"lr": 1e-3, "weight_decay": 1e-2, "adam_epsilon": 1e-8})
+        model.train()
+        losses, grads = [], None
+        for it in range(2):
+            loss, _, _, _ = model.fused_forward_backward("vqa", images, texts, tgt[sl])
+            if it == 0 and rank == 0:          # the averaged gradients the optimizer is about to consume (numpy: pickled by value)
+                grads = {n: p.grad.detach().cpu().numpy() for n, p in model.named_parameters() if p.grad is not None}
+            opt.step()
+            opt.zero_grad()
+            losses.append(float(loss))
+        ok = ddp.replicas_in_sync()
+        q.put((rank, ok, losses, grads, ddp.bytes_reduced))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_data_parallel_two_ranks_equals_single_process_on_the_global_batch():
+    """Two processes (gloo collectives on device tensors, both on the test box's single GPU) train on halves of a batch of 4 through the
+    real engine hooks: weights broadcast from rank 0, per-range gradient all-reduce during the backward, finish() before AdamW.
+    The averaged gradients equal (fp32 summation order aside) those of ONE process on the whole batch -- the loss is a batch mean,
+    so the average of the shard gradients is the global gradient -- and after two optimizer steps the replicas are bit-identical."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    res.sort(key=lambda r: r[0])
+    assert all(r[1] for r in res), "replicas diverged"
+    assert res[0][4] > 0 and res[0][4] == res[1][4]
+    # single process, global batch: its gradient is what the ranks' averaged gradient must be
+    model, _ = make_model(["vqa"], 42, precision="fp32")
+    enc = vo.synthetic_encodings(4, seed=21)
+    tgt = vo.synthetic_vqa_targets(4, seed=21)
+    images, texts = enc_to_inputs(enc)
+    model.train()
+    loss, _, _, _ = model.fused_forward_backward("vqa", images, texts, tgt)
+    dp = res[0][3]
+    G = grads_of(model)
+    assert set(G) == set(dp)
+    worst = 0.0
+    for n, g in G.items():
+        if n.endswith("attention.key.bias"):
+            continue             # mathematically zero (softmax shift invariance): only rounding noise on both sides
+        worst = max(worst, _close(torch.from_numpy(dp[n]), g.cpu(), 1e-4, f"averaged gradient {n}"))
+    print(f"data parallel (2 ranks) vs single process on the global batch: worst gradient error {worst:.2e}")
+    assert abs(0.5 * (res[0][2][0] + res[1][2][0]) - float(loss)) < 1e-4 * abs(float(loss))      # mean of the shard losses = global loss
