@@ -218,7 +218,9 @@ extern "C" int climb_gemm_f32(const float* A, long sam, long sak, const float* B
     }
   }
   const long tiles128 = (long)((M + 127) / 128) * ((N + 127) / 128);
-  if (tiles128 >= 192) {
+  // rank-K updates with a short K (the heads' weight gradients: K = batch) are all epilogue (read-modify-write of C): the smaller
+  // tile quadruples the workgroups that share that memory work
+  if (tiles128 >= 192 && K > 128) {
     dim3 grid((N + 127) / 128, (M + 127) / 128);
     hipLaunchKernelGGL((gemm_f32_kernel<128, 128>), grid, dim3(256), 0, st, A, sam, sak, modeA, B, sbn, sbk, modeB, C, ldc, M, N, K, bias, epi, aux,
                        ldaux, aux_out, ldauxo, beta, aux2, ldaux2, 0);

@@ -659,6 +659,7 @@ __global__ void ew_kernel(int op, const float* __restrict__ a, const float* __re
       case 3: r = x * b[i] * s; break;               // dropout: a=x, b=keep mask, s=1/(1-p)
       case 4: r = x * s; break;                      // scale
       case 5: r = x + b[i]; break;                   // add
+      case 6: r = tanhf(x); break;                   // tanh fwd (pooler, after a split-K GEMM)
       default: r = x;
     }
     out[i] = r;

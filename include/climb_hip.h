@@ -83,7 +83,7 @@ int climb_attn_delta(const void* dctx, const void* ctx, int dtype, float* delta,
 int climb_attn_bwd_f32(const float* qkv, const float* key_bias, const float* dctx, const float* lse, const float* delta, float* dqkv, int B, int S_pad, int heads, int head_dim, void* stream);
 
 /* ---- heads / losses -------------------------------------------------------------------------------------------- */
-/* op: 0 gelu(a) | 1 a*gelu'(b) | 2 a*(1-b^2) (tanh bwd) | 3 a*b*s (dropout) | 4 a*s | 5 a+b */
+/* op: 0 gelu(a) | 1 a*gelu'(b) | 2 a*(1-b^2) (tanh bwd) | 3 a*b*s (dropout) | 4 a*s | 5 a+b | 6 tanh(a) */
 int climb_elementwise(int op, const float* a, const float* b, float* out, long n, float s, void* stream);
 /* REF/train/visionlanguage_tasks/train_vqa.py:95,:157: loss = BCEWithLogits(mean)*N; dlogits = gscale*(sigmoid(x)-t)/B */
 int climb_bce_logits(const float* logits, long ldl, const float* target, long ldt, float* dlogits, long ldd, float* loss, float* partials, int B, int N, float gscale, void* stream);

@@ -434,8 +434,11 @@ def test_houlsby_adapters_vs_oracle_restatement(precision, tol):
         l_other = model(task_key="vqa", images=images, texts=texts)[1].clone()
         handler.activate_adapter_for_eval("vqa", model)
         p_back, l_back = (t.clone() for t in model(task_key="vqa", images=images, texts=texts))
-    # the encoder is bit-reproducible; the bf16 mode's head GEMMs use split-K atomics (sum order varies in the last bits)
-    assert torch.equal(p_vqa, p_back) and torch.allclose(l_vqa, l_back, rtol=1e-5, atol=1e-5) and not torch.allclose(l_vqa, l_other)
+    # fp32 mode: bit-reproducible; bf16 mode: the pooler / head GEMMs use split-K atomics (sum order varies in the last bits)
+    if precision == "fp32":
+        assert torch.equal(p_vqa, p_back) and torch.equal(l_vqa, l_back)
+    assert torch.allclose(p_vqa, p_back, rtol=1e-5, atol=1e-6) and torch.allclose(l_vqa, l_back, rtol=1e-5, atol=1e-5)
+    assert not torch.allclose(l_vqa, l_other)
 
 
 # ------------------------------------------------------------------------------------------------ full size (bs = 64) properties
