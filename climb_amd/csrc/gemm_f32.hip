@@ -97,7 +97,9 @@ __device__ __forceinline__ void tile_store(const TileRegs<BR>& t, float* __restr
   }
 }
 
-template <int BM, int BN>
+// XEPI: the adapter epilogues (SiLU, SiLU', dual residual) are compiled only into their own instantiation -- with all seven cases in one
+// kernel the 128 x 128 variant spilled 320 B per lane and the parity mode's GEMMs ran at 37 instead of 66 TF
+template <int BM, int BN, bool XEPI = false>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, long sam, long sak, int modeA, const float* __restrict__ B,
                                                        long sbn, long sbk, int modeB, float* C, long ldc, int M, int N, int K,
                                                        const float* __restrict__ bias, int epi, const float* aux, long ldaux, float* aux_out,
@@ -166,9 +168,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
         else if (epi == EPI_RESID) v += aux[(long)m * ldaux + n];
         else if (epi == EPI_DGELU) v *= dgelu_f(aux[(long)m * ldaux + n]);
         else if (epi == EPI_TANH) v = tanhf(v);
-        else if (epi == EPI_SILU) { aux_out[(long)m * ldauxo + n] = v; v = silu_f(v); }
-        else if (epi == EPI_DSILU) v *= dsilu_f(aux[(long)m * ldaux + n]);
-        else if (epi == EPI_RESID2) v += aux[(long)m * ldaux + n] + aux2[(long)m * ldaux2 + n];
+        if constexpr (XEPI) {
+          if (epi == EPI_SILU) { aux_out[(long)m * ldauxo + n] = v; v = silu_f(v); }
+          else if (epi == EPI_DSILU) v *= dsilu_f(aux[(long)m * ldaux + n]);
+          else if (epi == EPI_RESID2) v += aux[(long)m * ldaux + n] + aux2[(long)m * ldaux2 + n];
+        }
         float* cp = C + (long)m * ldc + n;
         if (kper) { atomicAdd(cp, v); continue; }
         if (beta != 0.f) v += beta * (*cp);
@@ -220,15 +224,18 @@ extern "C" int climb_gemm_f32(const float* A, long sam, long sak, const float* B
   const long tiles128 = (long)((M + 127) / 128) * ((N + 127) / 128);
   // rank-K updates with a short K (the heads' weight gradients: K = batch) are all epilogue (read-modify-write of C): the smaller
   // tile quadruples the workgroups that share that memory work
+  const bool xepi = epi == EPI_SILU || epi == EPI_DSILU || epi == EPI_RESID2;
+#define F32_LAUNCH(BM_, BN_, X_, grid_)                                                                                                      \
+  hipLaunchKernelGGL((gemm_f32_kernel<BM_, BN_, X_>), grid_, dim3(256), 0, st, A, sam, sak, modeA, B, sbn, sbk, modeB, C, ldc, M, N, K, bias, epi, aux, \
+                     ldaux, aux_out, ldauxo, beta, aux2, ldaux2, 0)
   if (tiles128 >= 192 && K > 128) {
     dim3 grid((N + 127) / 128, (M + 127) / 128);
-    hipLaunchKernelGGL((gemm_f32_kernel<128, 128>), grid, dim3(256), 0, st, A, sam, sak, modeA, B, sbn, sbk, modeB, C, ldc, M, N, K, bias, epi, aux,
-                       ldaux, aux_out, ldauxo, beta, aux2, ldaux2, 0);
+    if (xepi) F32_LAUNCH(128, 128, true, grid); else F32_LAUNCH(128, 128, false, grid);
   } else {
     dim3 grid((N + 63) / 64, (M + 63) / 64);
-    hipLaunchKernelGGL((gemm_f32_kernel<64, 64>), grid, dim3(256), 0, st, A, sam, sak, modeA, B, sbn, sbk, modeB, C, ldc, M, N, K, bias, epi, aux,
-                       ldaux, aux_out, ldauxo, beta, aux2, ldaux2, 0);
+    if (xepi) F32_LAUNCH(64, 64, true, grid); else F32_LAUNCH(64, 64, false, grid);
   }
+#undef F32_LAUNCH
   LAUNCH_CHECK();
   return CLIMB_OK;
 }
