@@ -185,3 +185,20 @@ def test_task_configs_carry_reference_hyperparameters():
         c = task_configs[k]
         assert (c["lr"], c["num_epochs"], c["weight_decay"], c["adam_epsilon"]) == (lr, ep, 1e-2, 1e-8)
         assert c["num_labels"] == vo.TASKS[k]["num_labels"] and c["model_type"] == vo.TASKS[k]["model_type"]
+
+
+def test_fp32_gemm_does_not_spill():
+    """Compile-time guard (hipcc resource report, no GPU): the parity mode's GEMM must keep its accumulators in registers.  Adding
+    epilogue cases to its runtime switch once pushed the 128x128 instantiation into scratch and halved its rate unnoticed."""
+    import importlib.util
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("check_spills", os.path.join(ROOT, "tools", "check_spills.py"))
+    cs = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cs)
+    if not os.path.exists(cs.HIPCC):
+        pytest.skip("hipcc not available")
+    rows = cs.report(os.path.join(ROOT, "climb_amd", "csrc", "gemm_f32.hip"))
+    assert rows, "no resource report parsed"
+    for name, vgpr, scratch in rows:
+        if not any(k in name for k in cs.KNOWN):
+            assert scratch == 0, (name, vgpr, scratch)
