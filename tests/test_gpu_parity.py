@@ -668,3 +668,27 @@ def test_data_parallel_two_ranks_equals_single_process_on_the_global_batch(preci
         worst = max(worst, _close(torch.from_numpy(dp[n]), g.cpu(), tol, f"averaged gradient {n}"))
     print(f"data parallel[{precision}] (2 ranks) vs single process on the global batch: worst gradient error {worst:.2e}")
     assert abs(0.5 * (res[0][2][0] + res[1][2][0]) - float(loss)) < tol * abs(float(loss))      # mean of the shard losses = global loss
+
+
+@pytest.mark.parametrize("B", [1, 7, 33, 48])
+def test_odd_batch_sizes_select_other_kernel_variants(B):
+    """The GEMM launchers pick tiles / split counts from the problem size (64x128, 96x192, 128x128, 192x192, ragged last tiles,
+    split targets).  Batch sizes other than the benchmark's walk those branches: the bf16 mode must agree with the fp32 mode
+    (itself pinned to the oracle) on logits, loss and every gradient norm."""
+    dev = _dev()
+    pixels, texts, target = _rand_batch(B, 100 + B, dev)
+    out = {}
+    for precision in ("fp32", "bf16"):
+        model, _ = make_model(["vqa"], 42, precision=precision)
+        model.train()
+        loss, (pooled, logits), _, _ = model.fused_forward_backward("vqa", pixels, texts, target)
+        out[precision] = (float(loss), logits.detach().float().cpu(), {n: float(g.double().norm()) for n, g in grads_of(model).items()})
+        assert bool(torch.isfinite(logits).all())
+    l32, lg32, g32 = out["fp32"]
+    l16, lg16, g16 = out["bf16"]
+    assert abs(l16 - l32) <= 2e-3 * abs(l32)
+    _close(lg16, lg32, BF16_TOL, f"logits bf16 vs fp32 at B={B}")
+    top = max(g32.values())
+    for n, v in g32.items():
+        if v > 1e-3 * top:
+            assert abs(g16[n] - v) <= 6e-2 * v, (n, v, g16[n])
