@@ -178,6 +178,7 @@ __device__ __forceinline__ void nt_tile(int nbm, int nbn, int& tm, int& tn) {
 
 // 128 x 128 tile; waves arranged (8/MJ/2) x 2, each owning MJ*32 rows x 64 columns: MJ = 1 -> 8 waves (twice the waves per CU
 // hiding LDS-DMA / L2 latency for the same LDS footprint, at 1.5x the fragment reads per MFMA); MJ = 2 -> 4 waves.
+// (16 waves of 32 x 32 measured the same as 8 within noise on the multi-round shapes: 60 / 105 / 100 us against 62 / 103 / 102.)
 template <typename TO, int EPI, bool GLDS, int MJ>
 __global__ __launch_bounds__(512 / MJ)
 void gemm_bf16_nt_kernel(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ B, long ldb, TO* __restrict__ C, long ldc, int M, int N,
