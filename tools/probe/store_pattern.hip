@@ -1,3 +1,4 @@
+// build + run on the GPU box: hipcc --offload-arch=gfx950 -O2 tools/probe/store_pattern.hip -o /tmp/store_pattern && /tmp/store_pattern
 // Diagnostic: how fast can 256 CUs write a [12288 x 3072] bf16 matrix in the GEMM-epilogue pattern vs linearly?
 #include <hip/hip_runtime.h>
 #include <stdio.h>
