@@ -330,7 +330,7 @@ class ViltEncoderWrapper(EncoderWrapper):
         if self.processor is None:
             raise RuntimeError("no ViltProcessor attached: pass tensor encodings (texts=dict(input_ids=...), images=pixel tensor) "
                                "or construct the encoder with a processor")
-        if dev.type == "cuda" and os.environ.get("CLIMB_AMD_HOST_IMAGES") != "1":
+        if dev.type == "cuda":
             # row F1: tokenise on the host, but resize / rescale / normalise / pad the images on the device from their raw bytes
             # (bit-identical to ViltProcessor's tensors, a quarter of its host->device traffic, none of its host arithmetic)
             enc = self.processor.tokenizer(texts, max_length=self.max_text_length, padding=True, truncation=True, return_tensors="pt")
@@ -340,6 +340,7 @@ class ViltEncoderWrapper(EncoderWrapper):
                 self._image_pipeline = DeviceImagePipeline(dev)
             enc.update(self._image_pipeline(images))
             return enc
+        # module left on a CPU device (host-side inspection only: the engine refuses to run there): the reference's own host call
         enc = self.processor(images=images, text=texts, max_length=self.max_text_length, padding=True, truncation=True, return_tensors="pt")
         return {k: v.to(dev, non_blocking=True) for k, v in enc.items()}
 
