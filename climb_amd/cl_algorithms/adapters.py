@@ -37,22 +37,30 @@ SUPPORTED_ADAPTER_METHODS = ["vanilla"]
 
 
 class AdapterHandler:
+    """Driver-facing switchboard (same constructor keywords and method names as the reference's handler): one adapter per task is
+    inserted up front, then exactly one of them is trained / active at a time while the base encoder stays frozen."""
+
     def __init__(self, adapter_method, args):
-        self.args = args
-        self.adapter_method = adapter_method
-        config_dict = AdapterConfig.load(args.adapter_config).to_dict()
-        if args.adapter_reduction_factor > 0:
-            config_dict["reduction_factor"] = args.adapter_reduction_factor
-        self.adapter_config = AdapterConfig.from_dict(config_dict)
-        logger.info("Adding Adapter layers with configuration: %s", self.adapter_config)
+        if adapter_method not in SUPPORTED_ADAPTER_METHODS:
+            raise NotImplementedError(f"adapter method {adapter_method!r}; supported: {SUPPORTED_ADAPTER_METHODS}")
+        self.adapter_method, self.args = adapter_method, args
+        preset = AdapterConfig.load(args.adapter_config)
+        override = getattr(args, "adapter_reduction_factor", 0)
+        if override and override > 0:                      # the published runs use bottleneck = hidden / 16
+            preset = AdapterConfig.from_dict({**preset.to_dict(), "reduction_factor": override})
+        self.adapter_config = preset
+        logger.info("adapter configuration: %s", dict(self.adapter_config))
 
     def add_adapters_to_model(self, model):
-        for task_key in self.args.ordered_cl_tasks:
-            model.add_adapter(task_key, config=self.adapter_config)
+        """Every task of the CL sequence gets its adapter before training starts (parameter layout is fixed once)."""
+        for key in self.args.ordered_cl_tasks:
+            model.add_adapter(key, config=self.adapter_config)
 
     def activate_adapter_for_training(self, task_key: str, model):
+        """Freeze everything but `task_key`'s adapter (and the task heads) and route the forward pass through it."""
         model.train_adapter(task_key)
         model.set_active_adapters(task_key)
 
     def activate_adapter_for_eval(self, task_key: str, model):
+        """Route the forward pass through `task_key`'s adapter; trainability is left as it is."""
         model.set_active_adapters(task_key)

@@ -1,5 +1,13 @@
-"""Registration point with the reference's names (REF/modeling/__init__.py:4-12)."""
-from .vilt import load_vilt_encoder, create_vilt_continual_learner_model
+"""Encoder registry under the reference's names (REF/modeling/__init__.py:4-12): the upstream driver looks the encoder up by
+`args.encoder_name` in these two maps.  Only ViLT is built (ViLT-BERT is SURVEY.md row F4)."""
+from .vilt import (ViltContinualLearner, ViltEncoderWrapper, convert_batch_to_vilt_input_dict, create_vilt_continual_learner_model,
+                   load_vilt_encoder)
 
-load_encoder_map = {"vilt": load_vilt_encoder}
-create_continual_learner_map = {"vilt": create_vilt_continual_learner_model}
+_ENCODERS = {
+    "vilt": (load_vilt_encoder, create_vilt_continual_learner_model),
+}
+load_encoder_map = {name: fns[0] for name, fns in _ENCODERS.items()}
+create_continual_learner_map = {name: fns[1] for name, fns in _ENCODERS.items()}
+
+__all__ = ["load_encoder_map", "create_continual_learner_map", "ViltContinualLearner", "ViltEncoderWrapper",
+           "convert_batch_to_vilt_input_dict", "create_vilt_continual_learner_model", "load_vilt_encoder"]

@@ -11,20 +11,27 @@ class _CheckpointCompat:
         return super().load_state_dict(state_dict, strict=strict, **kw)
 
 
-class EncoderWrapper(_CheckpointCompat, nn.Module):
-    def __init__(self, **kwargs):
-        super().__init__()
+def _abstract(what: str):
+    def method(self, *args, **kwargs):
+        raise NotImplementedError(f"{type(self).__name__} must implement {what}")
+    method.__name__ = what
+    return method
 
-    def forward(self, **kwargs):
-        raise NotImplementedError
+
+class EncoderWrapper(_CheckpointCompat, nn.Module):
+    """Base of a vision-language encoder: `forward(**encodings) -> pooled features [B, encoder_dim]`."""
+
+    def __init__(self, **_unused):
+        nn.Module.__init__(self)
+
+    forward = _abstract("forward")
 
 
 class ContinualLearner(_CheckpointCompat, nn.Module):
-    def __init__(self, **kwargs):
-        super().__init__()
+    """Base of encoder + per-task heads: `forward(task_key=, images=, texts=) -> (pooled, logits)`, `get_encoder()`."""
 
-    def forward(self, **kwargs):
-        raise NotImplementedError
+    def __init__(self, **_unused):
+        nn.Module.__init__(self)
 
-    def get_encoder(self):
-        raise NotImplementedError
+    forward = _abstract("forward")
+    get_encoder = _abstract("get_encoder")
