@@ -19,6 +19,14 @@ from .. import _lib
 logger = logging.getLogger(__name__)
 
 
+def _num_examples(raw_texts) -> int:
+    """Examples in a collated batch: a list of strings in the reference's loaders (REF ewc.py:65 uses len()), or pre-tokenised
+    tensors (dict of [B, T]) when the input pipeline already ran."""
+    if isinstance(raw_texts, dict):
+        return int(next(iter(raw_texts.values())).shape[0])
+    return len(raw_texts)
+
+
 def _views(flat: torch.Tensor, eng) -> Dict[str, torch.Tensor]:
     lay = eng.layout
     out = {}
@@ -82,7 +90,7 @@ class EWC:
             task_trainer.train_step(model, batch)
             eng = host.engine()
             eng.fisher_accumulate(fisher)
-            num_samples_completed += len(batch["raw_texts"])
+            num_samples_completed += _num_examples(batch["raw_texts"])
             if num_samples_completed >= fisher_sample_size:
                 break
         _lib.call("climb_scale", fisher, n, 1.0 / max(1, num_samples_completed), torch.cuda.current_stream().cuda_stream)
