@@ -349,3 +349,33 @@ def test_weight_shadow_cast_and_batched_transpose():
     a = sh[:96 * 160].view(96, 160).t().contiguous().view(-1)
     b = sh[96 * 160:].view(160, 96).t().contiguous().view(-1)
     assert torch.equal(out.cpu(), torch.cat([a, b]).cpu())
+
+
+# ------------------------------------------------------------------------------------------------ error behaviour of the C ABI
+def test_abi_rejects_bad_arguments_with_codes_not_crashes():
+    """SURVEY.md §8(b) "Errors": every entry returns an int; invalid shapes / missing operands come back as a library code (turned into
+    RuntimeError by the binding) instead of launching, throwing across the ABI or exiting."""
+    from climb_amd import _lib
+    dev = _dev()
+    a = torch.zeros(64, 64, device=dev, dtype=torch.bfloat16)
+    c = torch.zeros(64, 64, device=dev)
+    bad = [
+        ("climb_gemm_bf16_nt", (a, 64, a, 64, c, 64, 0, 0, 64, 64, None, 0, None, 0, None, 0, None, 0, _st())),       # M = 0
+        ("climb_gemm_bf16_nt", (a, 64, a, 64, c, 64, 0, 64, 64, 60, None, 0, None, 0, None, 0, None, 0, _st())),      # K % 8 != 0
+        ("climb_gemm_bf16_nt", (a, 64, a, 64, c, 64, 0, 64, 64, 64, None, 2, None, 0, None, 0, None, 0, _st())),      # residual epilogue, no residual
+        ("climb_gemm_bf16_nt", (a, 64, a, 64, c, 64, 5, 64, 64, 64, None, 0, None, 0, None, 0, None, 0, _st())),      # unknown output dtype
+        ("climb_gemm_bf16_tn", (a, 64, a, 64, c, 64, 64, 60, 64, None, _st())),                                         # N % 8 != 0
+        ("climb_gemm_f32", (c, 64, 1, c, 64, 1, c, 64, 64, 64, 64, None, 1, None, 0, None, 0, 0.0, None, 0, 0, _st())),  # GELU without aux_out
+        ("climb_attn_fwd_bf16", (a, c, a, c, 1, 48, 1, 64, _st())),                                                      # S_pad % 32 != 0
+        ("climb_attn_fwd_bf16", (a, c, a, c, 1, 64, 1, 32, _st())),                                                      # head_dim != 64
+        ("climb_layernorm_fwd", (c, 64, c, c, 1e-5, c, 64, 0, c, c, 64, 66, _st())),                                     # C % 4 != 0
+        ("climb_image_resample", (a, a, a, c, c, 0, 1, _st())),                                                          # no images
+        ("climb_cast_bf16", (c, a, 6, _st())),                                                                           # n % 4 != 0
+    ]
+    for name, args in bad:
+        with pytest.raises(RuntimeError, match=name):
+            _lib.call(name, *args)
+    torch.cuda.synchronize()          # nothing was launched, the context is healthy
+    assert _lib.load().climb_error_string(-1).decode().startswith("climb:")
+    assert _lib.load().climb_error_string(0).decode() == "ok"
+    assert _lib.load().climb_arch().decode() == "gfx950" and _lib.load().climb_version() >= 100
