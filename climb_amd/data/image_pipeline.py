@@ -93,7 +93,11 @@ class DeviceImagePipeline:
         _lib.load()
         self.shorter, self.size_divisor = shorter, size_divisor
         self.lut = torch.from_numpy(normalize_table()).to(self.device)
-        self._pinned = None
+        # pinned staging ring: a buffer is rewritten only after the event recorded behind its last host->device copy has
+        # completed, so a prefetching caller (PrefetchLoader: worker thread, side stream, no host syncs) can never overwrite
+        # raw bytes a DMA is still reading
+        self._ring = [None] * 3          # [pinned uint8 tensor, torch.cuda.Event]
+        self._ring_at = 0
 
     def plan(self, shapes: Sequence[Tuple[int, int]]):
         """Host-side layout of one batch: descriptor table, coefficient arena, arena sizes, canvas size."""
@@ -131,16 +135,22 @@ class DeviceImagePipeline:
     def __call__(self, images) -> Dict[str, torch.Tensor]:
         arrs = [_as_rgb_u8(im) for im in images]
         table, coef, (nsrc, ntmp, ndst), max_elems, (Hc, Wc) = self.plan([a.shape[:2] for a in arrs])
-        if self._pinned is None or self._pinned.numel() < nsrc:
-            self._pinned = torch.empty(max(nsrc, 1 << 20), dtype=torch.uint8).pin_memory()
-        stage = self._pinned.numpy()
+        slot = self._ring_at
+        self._ring_at = (slot + 1) % len(self._ring)
+        if self._ring[slot] is not None:
+            self._ring[slot][1].synchronize()                 # the copy that last read this buffer has finished
+        if self._ring[slot] is None or self._ring[slot][0].numel() < nsrc:
+            self._ring[slot] = [torch.empty(max(nsrc, 1 << 20), dtype=torch.uint8).pin_memory(), torch.cuda.Event()]
+        pinned, copied = self._ring[slot]
+        stage = pinned.numpy()
         o = 0
         for a in arrs:
             stage[o:o + a.size] = a.reshape(-1)
             o += a.size
         dev = self.device
         src = torch.empty(nsrc, dtype=torch.uint8, device=dev)
-        src.copy_(self._pinned[:nsrc], non_blocking=True)
+        src.copy_(pinned[:nsrc], non_blocking=True)
+        copied.record(torch.cuda.current_stream())
         tmp = torch.empty(ntmp, dtype=torch.uint8, device=dev)
         dst = torch.empty(ndst, dtype=torch.uint8, device=dev)
         table_d = torch.from_numpy(table.reshape(-1)).to(dev, non_blocking=True)

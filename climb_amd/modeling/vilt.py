@@ -127,6 +127,7 @@ class _EngineHost:
         self._engine: Optional[ViltEngine] = None
         self._params: Dict[str, nn.Parameter] = {}
         self._sentinels: Tuple[str, str] = ("", "")
+        self._param_version = None      # sum of the parameters' torch version counters at the last engine() call
         self.ddp = None                 # climb_amd.parallel.GradientAllReducer, when data-parallel
 
     def __deepcopy__(self, memo):
@@ -174,11 +175,21 @@ class _EngineHost:
                     p.grad = None
             names = list(named.keys())
             self._engine, self._params, self._sentinels = eng, named, (names[0], names[-1])
+            self._param_version = None
             if self.ddp is not None:
                 self.ddp.attach(eng)
         eng = self._engine
+        # Any torch-side write to a bound parameter (load_state_dict, p.copy_(), a stock torch optimizer, init code) bumps THAT
+        # parameter's version counter, not the flat buffer's: the bf16 operand shadows must be rebuilt from the fp32 master then.
+        # (The fused AdamW writes through the C ABI, bumps nothing, and refreshes the shadow itself.)
+        ver = 0
         for n, p in self._params.items():
             eng.requires_grad[n] = p.requires_grad
+            ver += p._version
+        if ver != self._param_version:
+            if self._param_version is not None:
+                eng.params_updated()
+            self._param_version = ver
         eng.active_adapter = self.encoder.vilt.active_adapters
         return eng
 
@@ -259,11 +270,17 @@ class _EncoderFn(torch.autograd.Function):
         pooled = eng.encoder_forward(enc["input_ids"], enc["token_type_ids"], enc["attention_mask"], enc["pixel_values"], img_type,
                                      pixel_mask=enc.get("pixel_mask"))
         ctx.host = host
+        ctx.generation = eng.saved["generation"]
         return pooled.clone()
 
     @staticmethod
     def backward(ctx, dpooled):
         host = ctx.host
+        if host._engine.saved is None or host._engine.saved.get("generation") != ctx.generation:
+            # activations live in the engine's single workspace, not in the autograd graph: a second grad-enabled forward
+            # before this backward has overwritten them
+            raise RuntimeError("climb_amd: backward of a forward whose saved activations were overwritten by a later forward; "
+                               "run backward before the next grad-enabled forward (or sum the losses of ONE forward)")
         host.before_backward()
         first, emb = host.frozen_prefix()
         host._engine.encoder_backward(dpooled.contiguous().float(), first_layer=first, embeddings=emb)
@@ -526,7 +543,8 @@ class ViltContinualLearner(ContinualLearner):
         if ewc is not None and ewc.do_ewc():
             ewc_task, ewc_loss = ewc.add_penalty_gradient(self)
         host.after_backward()
-        return loss, (pooled, logits), ewc_task, ewc_loss
+        # `pooled` is a view of the workspace the next step overwrites: hand the caller its own copy (49 K floats)
+        return loss, (pooled.clone(), logits), ewc_task, ewc_loss
 
     # --- the same step captured once into a hipGraph and replayed: the ~330 kernel launches of a step become one graph launch
     # (HIP streams and graphs instead of a tracing compiler).  Inputs are copied into static buffers; the returned tensors are
@@ -559,7 +577,10 @@ class ViltContinualLearner(ContinualLearner):
                 out = self.fused_forward_backward(task_key, st_img, st_texts, st_target)
             touched = list(eng.touched)
             host.drop_grads()                              # capture does not execute; start from clean gradients
-            cs = graphs[key] = dict(graph=g, texts=st_texts, img=st_img, target=st_target, out=out, touched=touched, engine=eng)
+            # the captured kernels hold raw pointers into this Workspace: the cache entry keeps it alive past the engine's
+            # own three-shape eviction
+            cs = graphs[key] = dict(graph=g, texts=st_texts, img=st_img, target=st_target, out=out, touched=touched, engine=eng,
+                                    ws=eng.saved["ws"])
         host.before_backward()
         for k, v in texts.items():
             cs["texts"][k].copy_(v, non_blocking=True)

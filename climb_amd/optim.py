@@ -86,6 +86,32 @@ class FusedAdamW(torch.optim.Optimizer):
         eng.params_updated(shadow_fresh=shadow is not None)
         return loss
 
+    # ---- checkpointing: the moments and per-parameter step counts live in flat buffers outside `self.state`, so the inherited
+    # state_dict() would serialise nothing and a resume would silently restart the moments and the bias correction.
+    def state_dict(self):
+        sd = super().state_dict()
+        if self._m is not None and self._steps:
+            sd["climb_amd_flat"] = dict(m=self._m.detach().clone(), v=self._v.detach().clone(), steps=dict(self._steps),
+                                        total=int(self._eng.layout.total))
+        return sd
+
+    def load_state_dict(self, state_dict):
+        flat = state_dict.get("climb_amd_flat")
+        super().load_state_dict({k: v for k, v in state_dict.items() if k != "climb_amd_flat"})
+        if flat is None:
+            self._steps = {}
+            if self._m is not None:
+                self._m.zero_()
+                self._v.zero_()
+            return
+        eng = self._prepare()
+        if int(flat["total"]) != int(eng.layout.total):
+            raise ValueError(f"FusedAdamW.load_state_dict: optimizer state was saved for a parameter layout of {flat['total']} elements, "
+                             f"this model has {eng.layout.total} (different task heads / adapters?)")
+        self._m.copy_(flat["m"])
+        self._v.copy_(flat["v"])
+        self._steps = dict(flat["steps"])
+
     def zero_grad(self, set_to_none: bool = True):
         """One memset of the flat gradient buffer; every `.grad` becomes None (torch's set_to_none=True behaviour)."""
         self._host.engine()

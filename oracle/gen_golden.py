@@ -1,6 +1,6 @@
 """Generate tests/golden/*.npz by running the CLiMB reference itself.  BUILD-CONTAINER ONLY.
 
-Usage:  python oracle/gen_golden.py            (needs /root/reference; ~2 min on 8 cores)
+Usage:  python oracle/gen_golden.py [fullsize|varres|cl_eval]   (needs /root/reference; ~5 min on 8 cores)
 
 Every fixture is DATA: outputs of the reference's own `ViltContinualLearner`, `*Trainer.train_step`,
 `EWC.compute_ewc_loss` and `EWC.save_task_parameters` on seeded synthetic inputs.  Weights and inputs
@@ -258,7 +258,7 @@ def case_nlvr2(fname, b=2, tasks=("vqa", "nlvr2"), wseed=42, dseed=3):
     e1 = vo.synthetic_encodings(2 * b, seed=dseed)
     enc = dict(input_ids=e1["input_ids"][:b], token_type_ids=e1["token_type_ids"][:b],
                attention_mask=e1["attention_mask"][:b], pixel_values=e1["pixel_values"], pixel_mask=e1["pixel_mask"])
-    labels = torch.tensor([1, 0][:b])
+    labels = torch.tensor([1, 0][:b]) if b <= 2 else torch.from_numpy(np.random.default_rng([dseed, 13]).integers(0, 2, size=(b,), dtype=np.int64))
     model = ri.build_reference_learner(tasks, P)
     model.train()
     trainer = ri.make_trainer("nlvr2")
@@ -287,7 +287,7 @@ def case_vcr(fname, b=2, tasks=("snli-ve", "vcr"), wseed=42, dseed=4):
     e1 = vo.synthetic_encodings(4 * b, seed=dseed, ragged_text=True)
     enc = dict(input_ids=e1["input_ids"], token_type_ids=e1["token_type_ids"], attention_mask=e1["attention_mask"],
                pixel_values=e1["pixel_values"][:b], pixel_mask=e1["pixel_mask"][:b])
-    labels = torch.tensor([2, 0][:b])
+    labels = torch.tensor([2, 0][:b]) if b <= 2 else torch.from_numpy(np.random.default_rng([dseed, 13]).integers(0, 4, size=(b,), dtype=np.int64))
     model = ri.build_reference_learner(tasks, P)
     model.eval()
     trainer = ri.make_trainer("vcr")
@@ -399,6 +399,14 @@ def case_cl_eval(fname="cl_eval.json"):
     json.dump(out, open(os.path.join(OUT, fname), "w"), indent=1)
 
 
+def case_fullsize():
+    """BASELINE configs[1] at its own size (64 sequences of 40 tokens + 384x384 per GPU) and the equal-sized NLVR2 / VCR batches
+    (32 pairs, 16 x 4 choices): the reference's own `*Trainer.train_step` (REF/train/visionlanguage_tasks/train_vqa.py:135-174)."""
+    case_single_image("vqa", ["vqa", "nlvr2"], 64, "vqa_b64.npz", dseed=64)
+    case_nlvr2("nlvr2_b32.npz", b=32, dseed=32)
+    case_vcr("vcr_b16.npz", b=16, dseed=16)
+
+
 def main():
     assert ri.reference_available(), "needs /root/reference (build container only)"
     os.makedirs(OUT, exist_ok=True)
@@ -408,6 +416,9 @@ def main():
         return
     if len(sys.argv) > 1 and sys.argv[1] == "cl_eval":
         case_cl_eval()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "fullsize":
+        case_fullsize()
         return
     case_single_image("vqa", ["vqa", "nlvr2"], 2, "vqa_b2.npz")
     case_single_image("vqa", ["vqa", "nlvr2"], 3, "vqa_b3_ragged.npz", ragged=True, dseed=2)
@@ -420,6 +431,7 @@ def main():
     case_steps("vqa_b2_10steps.npz")
     case_varres("vqa_b4_varres.npz")
     case_cl_eval()
+    case_fullsize()
     print("golden fixtures written to", OUT)
 
 
