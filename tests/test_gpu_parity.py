@@ -374,6 +374,49 @@ def test_bf16_mode_step_vs_oracle(golden_dir):
     assert abs(float(loss2) - float(loss)) > 1e-3 * abs(float(loss)), "the update must change the loss"
 
 
+def test_bf16_shadows_follow_torch_side_parameter_writes(tmp_path):
+    """nn.Module.load_state_dict / p.copy_() on a BOUND bf16 model write the fp32 master through the parameter
+    views; the bf16 operand shadows (straight and transposed) must be rebuilt, or every encoder GEMM keeps the old weights.
+    This is what `eval_forgetting` does (load a checkpoint into an already-used model, then eval)."""
+    dev = _dev()
+    B = 4
+    pixels, texts, target = _rand_batch(B, 5, dev)
+    model, _ = make_model(["vqa"], 42, precision="bf16")
+    model.train()
+    opt = model.create_optimizer({"lr": 1e-3, "weight_decay": 1e-2, "adam_epsilon": 1e-8})
+    model.fused_forward_backward("vqa", pixels, texts, target)          # shadows built, one optimizer step taken
+    opt.step()
+    opt.zero_grad()
+    other = vo.init_params(["vqa"], 43)                                   # a different model's weights
+    path = str(tmp_path / "ckpt.pt")
+    torch.save(other, path)
+    model.load_state_dict(torch.load(path))
+    model.eval()
+    with torch.no_grad():
+        got = model(task_key="vqa", images=pixels, texts=texts)[1].clone()
+    fresh, _ = make_model(["vqa"], 43, precision="bf16")
+    fresh.eval()
+    with torch.no_grad():
+        want = fresh(task_key="vqa", images=pixels, texts=texts)[1].clone()
+    _close(got, want, 1e-5, "logits after load_state_dict vs a freshly built model")
+    # an in-place write to ONE weight (what a stock torch optimizer does) must be seen too
+    with torch.no_grad():
+        dict(model.named_parameters())["vilt_encoder.vilt.encoder.layer.3.output.dense.weight"].mul_(0.5)
+        changed = model(task_key="vqa", images=pixels, texts=texts)[1].clone()
+    assert float((changed - got).abs().max()) > 1e-4 * float(got.abs().max())
+    # optimizer state survives a state_dict round trip (moments + per-parameter step counts)
+    model.train()
+    opt2 = model.create_optimizer({"lr": 1e-3, "weight_decay": 1e-2, "adam_epsilon": 1e-8})
+    model.fused_forward_backward("vqa", pixels, texts, target)
+    opt2.step()
+    opt2.zero_grad()
+    sd = opt2.state_dict()
+    assert "climb_amd_flat" in sd and float(sd["climb_amd_flat"]["v"].sum()) > 0
+    opt3 = model.create_optimizer({"lr": 1e-3, "weight_decay": 1e-2, "adam_epsilon": 1e-8})
+    opt3.load_state_dict(sd)
+    assert opt3._steps == opt2._steps and torch.equal(opt3._m, opt2._m) and torch.equal(opt3._v, opt2._v)
+
+
 # ------------------------------------------------------------------------------------------------ Houlsby adapters (unpinned)
 @pytest.mark.parametrize("precision,tol", [("fp32", TOL), ("bf16", 4e-2)])
 def test_houlsby_adapters_vs_oracle_restatement(precision, tol):
@@ -439,6 +482,83 @@ def test_houlsby_adapters_vs_oracle_restatement(precision, tol):
         assert torch.equal(p_vqa, p_back) and torch.equal(l_vqa, l_back)
     assert torch.allclose(p_vqa, p_back, rtol=1e-5, atol=1e-6) and torch.allclose(l_vqa, l_back, rtol=1e-5, atol=1e-5)
     assert not torch.allclose(l_vqa, l_other)
+
+
+# ------------------------------------------------------------------------------------------------ full size vs the REFERENCE
+def _full_size_inputs(z):
+    """Rebuild the seeded inputs of a tests/golden/*_b{64,32,16}.npz fixture (oracle/gen_golden.py::case_fullsize)."""
+    m = _meta(z)
+    task = m["task"]
+    if task == "vqa":
+        B = int(m["B"])
+        enc = vo.synthetic_encodings(B, seed=int(m["dseed"]))
+        images, texts = enc_to_inputs(enc)
+        return task, images, texts, vo.synthetic_vqa_targets(B, seed=int(m["dseed"]))
+    b = int(m["b"])
+    if task == "nlvr2":
+        e1 = vo.synthetic_encodings(2 * b, seed=int(m["dseed"]))
+        texts = dict(input_ids=e1["input_ids"][:b], token_type_ids=e1["token_type_ids"][:b], attention_mask=e1["attention_mask"][:b])
+        return task, e1["pixel_values"], texts, torch.from_numpy(z["labels"])
+    e1 = vo.synthetic_encodings(4 * b, seed=int(m["dseed"]), ragged_text=True)
+    texts = dict(input_ids=e1["input_ids"], token_type_ids=e1["token_type_ids"], attention_mask=e1["attention_mask"])
+    return task, e1["pixel_values"][:b], texts, torch.from_numpy(z["labels"])
+
+
+def full_size_errors(z, precision):
+    """One step of the HIP path on a full-size reference fixture; relative errors (max|d| / max|ref|) against the reference's own
+    outputs and the fraction of rows whose argmax prediction equals the reference's.  Also used by bench.py (`bf16_vs_ref`)."""
+    m = _meta(z)
+    task, images, texts, target = _full_size_inputs(z)
+    model, _ = make_model(m["tasks"].split(","), int(m["wseed"]), precision=precision)
+    model.train() if task != "vcr" else model.eval()          # the VCR fixture is eval mode (head dropout is the only RNG on the path)
+    loss, (pooled, logits), _, _ = model.fused_forward_backward(task, images, texts, target)
+
+    def rel(a, b):
+        a = torch.as_tensor(np.asarray(a.detach().float().cpu())).double()
+        b = torch.as_tensor(np.asarray(b)).double()
+        return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+    G = grads_of(model)
+    names = [str(n) for n in z["grad_names"]]
+    norms, heads = _summary(G, names)
+    big = z["grad_norms"] > 1e-3 * z["grad_norms"].max()
+    gn = np.abs(norms - z["grad_norms"])[big] / z["grad_norms"][big]
+    out = dict(pooled=rel(pooled, z["pooled"]), logits=rel(logits, z["logits"]), loss=rel(loss, z["loss"]),
+               argmax_agreement=float((logits.argmax(-1).cpu().numpy() == z["logits"].argmax(-1)).mean()), rows=int(logits.shape[0]),
+               grad_norm_median=float(np.median(gn)), grad_norm_max=float(gn.max()),
+               grad_heads=rel(torch.from_numpy(heads), z["grad_heads"]))
+    del model
+    torch.cuda.empty_cache()
+    return out
+
+
+FULL_SIZE = ["vqa_b64.npz", "nlvr2_b32.npz", "vcr_b16.npz"]
+
+
+@pytest.mark.parametrize("fname", FULL_SIZE)
+def test_full_size_fp32_vs_reference(golden_dir, fname):
+    """BASELINE.json configs[1] at ITS OWN size (64 sequences x (40 tokens + 384x384)) and the equal-sized NLVR2 (32 pairs) / VCR
+    (16 x 4 choices) batches: the HIP path in the parity mode against what the reference's `*Trainer.train_step` computed
+    (REF train_vqa.py:135-174).  These sizes select the 192x192 three-stage, 256x256 and one-round split kernels."""
+    e = full_size_errors(np.load(os.path.join(golden_dir, fname)), "fp32")
+    print(f"{fname} fp32 vs reference: {e}")
+    assert e["pooled"] <= TOL and e["logits"] <= TOL and e["loss"] <= TOL
+    assert e["argmax_agreement"] == 1.0, "argmax task predictions must be bit-exact on every row"
+    assert e["grad_norm_max"] <= TOL and e["grad_heads"] <= TOL
+
+
+# error budget of the throughput mode at the benchmark's size, measured against the REFERENCE (DESIGN.md section 3 tabulates where it comes from)
+BF16_FULL = dict(pooled=2.5e-2, logits=1.2e-2, loss=1e-3, grad_norm_max=3e-2)
+
+
+@pytest.mark.parametrize("fname", FULL_SIZE)
+def test_full_size_bf16_vs_reference(golden_dir, fname):
+    e = full_size_errors(np.load(os.path.join(golden_dir, fname)), "bf16")
+    print(f"{fname} bf16 vs reference: {e}")
+    for k, lim in BF16_FULL.items():
+        assert e[k] <= lim, (k, e[k], lim)
+    # random-init heads put many top-2 logits closer than bf16's error (the smallest margin of vqa_b64 is 4e-4 of the logit scale):
+    # the agreement is REPORTED (bench.py prints it) and bounded from below, it cannot be 100 % in this mode
+    assert e["argmax_agreement"] >= 0.9
 
 
 # ------------------------------------------------------------------------------------------------ full size (bs = 64) properties
