@@ -51,6 +51,11 @@ def load():
         fn.restype = ctypes.c_int if ret == "int" else ctypes.c_char_p
         fn.argtypes = [_CT[t] for t in types]
     _lib = lib
+    # developer knob for A/B measurements: CLIMB_AMD_OPTIONS="7=0,5=1" -> climb_set_option(7, 0); climb_set_option(5, 1)
+    for kv in filter(None, os.environ.get("CLIMB_AMD_OPTIONS", "").split(",")):
+        k, v = kv.split("=")
+        if lib.climb_set_option(int(k), int(v)) != 0:
+            raise RuntimeError(f"CLIMB_AMD_OPTIONS: climb_set_option({k}, {v}) rejected")
     return lib
 
 

@@ -18,24 +18,8 @@
 //       consecutive m-rows in 4 different bank quarters: conflict-free.
 // Staging is LDS-DMA (global_load_lds_dwordx4, swizzle applied to the per-lane SOURCE address) whenever the shape allows;
 // a register-staged variant of each kernel handles ragged K / ragged reduction tails.
-#include "common.h"
+#include "gemm_bf16_nt.h"
 
-#define GB_BM 128
-#define GB_BN 128
-#define GB_BK 64
-
-__device__ __forceinline__ int swz(int row) {  // chunk XOR mask: rows (r, r+2) differ in bit 2, 16 rows of a group all distinct with parity
-  int y = (row >> 1) & 7;
-  return ((y & 1) << 2) | (y >> 1);
-}
-
-typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
-
-__device__ __forceinline__ bf16x8 as_bf16x8(u32x4 v) {
-  union { u32x4 u; bf16x8 b; } c;
-  c.u = v;
-  return c.b;
-}
 
 // ---------------------------------------------------------------------------------------------------------------- NT
 // stage one [128][64] tile: thread t handles chunks (row = t/8 + 32p, c = t%8), p = 0..3
@@ -59,122 +43,6 @@ __device__ __forceinline__ void nt_store(const u32x4 (&r)[4], unsigned char* __r
   }
 }
 
-// LDS-DMA staging (global_load_lds_dwordx4): no VGPR round trip and no ds_write pass -- the register-staged path spends
-// more LDS cycles on its 13-cycle ds_write_b128s than on the fragment reads.  The DMA writes LDS linearly
-// (wave-uniform base + lane*16), so the swizzle is applied on the SOURCE side: the lane that owns LDS slot (row, cpos)
-// fetches logical chunk cpos ^ swz(row) of that row.  A [128][64] tile is 16 wave-instructions, dealt evenly to NW waves.
-typedef __attribute__((address_space(3))) void lds_void_t;
-typedef __attribute__((address_space(1))) const void gbl_void_t;
-template <int NW, int ROWS = 128>
-__device__ __forceinline__ void nt_glds(const bf16_t* __restrict__ P, long ld, int row0, int k0, int R, unsigned char* __restrict__ S) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-  for (int i = 0; i < ROWS / 8 / NW; ++i) {
-    const int j = wave * (ROWS / 8 / NW) + i;
-    const int slot = j * 64 + lane, row = slot >> 3, c = (slot & 7) ^ swz(row);
-    int grow = row0 + row;
-    grow = grow < R ? grow : R - 1;
-    __builtin_amdgcn_global_load_lds((gbl_void_t*)(P + (long)grow * ld + k0 + c * 8), (lds_void_t*)(S + j * 1024), 16, 0, 0);
-  }
-}
-
-// Epilogue.  In the 32x32 accumulator layout a lane owns ONE output row and 4-column groups of it, so a direct store touches 32
-// different rows with 8-16 bytes each: 8x the memory transactions of a row-contiguous store, and measured (r01 ablation: 633 -> 448
-// us per layer with the epilogue removed) the dominant cost of the K = 768 GEMMs.  Instead every wave turns its 32 x (NI*32)
-// block through a PRIVATE fp32 LDS region (the k-loop buffers are free by then) and then walks it row-major: 16 B of LDS per lane,
-// NI*8 lanes per row, so bias / residual / pre-activation are read and C / aux_out written as whole 128-byte lines.
-// Staged row r holds 16-byte chunk c at chunk position (c & ~7) | ((c ^ r) & 7): the transposing ds_write_b128s (8 consecutive
-// rows, same chunk) and the row-major ds_read_b128s are both bank-conflict free.  No workgroup barrier: the region is per wave
-// and LDS operations of one wave execute in order.
-// The residual / pre-activation operand of the epilogue, fetched BEFORE the k-loop in the same row-major lane assignment the
-// epilogue uses: its latency (measured: 36 us per layer when loaded in the epilogue) disappears under the MFMAs.
-template <int EPI, int CNT>
-struct AuxRegs {
-  float4 r[CNT];     // fp32 residual            (EPI_RESID, EPI_RESID2)
-  uint2 h[CNT];      // 4 bf16: pre-activation   (EPI_DGELU, EPI_DSILU) or second residual (EPI_RESID2)
-};
-template <int EPI, int NI, int MJ>
-__device__ __forceinline__ void nt_aux_prefetch(AuxRegs<EPI, NI * 4 * MJ>& ax, int mw, int nw, int M, int N, const void* __restrict__ aux, long ldaux,
-                                                const bf16_t* __restrict__ aux2, long ldaux2) {
-  constexpr int CPR = NI * 8;
-  const int lane = threadIdx.x & 63;
-#pragma unroll
-  for (int j = 0; j < MJ; ++j)
-#pragma unroll
-    for (int p = 0; p < NI * 4; ++p) {
-      const int q = p * 64 + lane, r = q / CPR, c = q % CPR;
-      const int m = min(mw + j * 32 + r, M - 1), n = min(nw + c * 4, N - 4);       // clamped: out-of-range results are never used
-      if (EPI == EPI_RESID || EPI == EPI_RESID2) ax.r[j * NI * 4 + p] = ld4(reinterpret_cast<const float*>(aux) + (long)m * ldaux + n);
-      if (EPI == EPI_DGELU || EPI == EPI_DSILU) ax.h[j * NI * 4 + p] = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(aux) + (long)m * ldaux + n);
-      if (EPI == EPI_RESID2) ax.h[j * NI * 4 + p] = *reinterpret_cast<const uint2*>(aux2 + (long)m * ldaux2 + n);
-    }
-}
-__device__ __forceinline__ float4 bf16x4_to_f32(uint2 r) {
-  return make_float4(__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16), __uint_as_float(r.y & 0xffff0000u));
-}
-
-template <typename TO, int EPI, int NI, int MJ>
-__device__ __forceinline__ void nt_epilogue(const f32x16 (&acc)[NI][MJ], const AuxRegs<EPI, NI * 4 * MJ>& ax, unsigned char* __restrict__ stage, int mw,
-                                            int nw, int M, int N, TO* __restrict__ C, long ldc, const float* __restrict__ bias,
-                                            bf16_t* __restrict__ aux_out, long ldauxo) {
-  constexpr int CPR = NI * 8, PITCH = NI * 128;          // chunks / bytes per staged row
-  const int lane = threadIdx.x & 63, half = lane >> 5, l31 = lane & 31;
-#pragma unroll
-  for (int j = 0; j < MJ; ++j) {
-#pragma unroll
-    for (int i = 0; i < NI; ++i)
-#pragma unroll
-      for (int g = 0; g < 4; ++g)
-        *reinterpret_cast<float4*>(stage + l31 * PITCH + ((i * 8 + ((2 * g + half) ^ (l31 & 7))) << 4)) =
-            make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
-#pragma unroll
-    for (int p = 0; p < NI * 4; ++p) {
-      const int q = p * 64 + lane, r = q / CPR, c = q % CPR;
-      float4 v = *reinterpret_cast<const float4*>(stage + r * PITCH + (((c & ~7) | ((c ^ r) & 7)) << 4));
-      const int m = mw + j * 32 + r, n = nw + c * 4;
-      if (m >= M || n >= N) continue;
-      if (bias) {
-        const float4 bv = ld4(bias + n);
-        v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
-      }
-      if (EPI == EPI_GELU) {
-        st4(aux_out + (long)m * ldauxo + n, v);
-        v = make_float4(gelu_fast(v.x), gelu_fast(v.y), gelu_fast(v.z), gelu_fast(v.w));
-      } else if (EPI == EPI_RESID) {
-        const float4 rv = ax.r[j * NI * 4 + p];
-        v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
-      } else if (EPI == EPI_DGELU) {
-        const float4 uv = bf16x4_to_f32(ax.h[j * NI * 4 + p]);
-        v.x *= dgelu_fast(uv.x); v.y *= dgelu_fast(uv.y); v.z *= dgelu_fast(uv.z); v.w *= dgelu_fast(uv.w);
-      } else if (EPI == EPI_SILU) {
-        st4(aux_out + (long)m * ldauxo + n, v);
-        v = make_float4(silu_f(v.x), silu_f(v.y), silu_f(v.z), silu_f(v.w));
-      } else if (EPI == EPI_DSILU) {
-        const float4 uv = bf16x4_to_f32(ax.h[j * NI * 4 + p]);
-        v.x *= dsilu_f(uv.x); v.y *= dsilu_f(uv.y); v.z *= dsilu_f(uv.z); v.w *= dsilu_f(uv.w);
-      } else if (EPI == EPI_RESID2) {
-        const float4 rv = ax.r[j * NI * 4 + p];
-        const float4 yv = bf16x4_to_f32(ax.h[j * NI * 4 + p]);
-        v.x += rv.x + yv.x; v.y += rv.y + yv.y; v.z += rv.z + yv.z; v.w += rv.w + yv.w;
-      }
-      st4(C + (long)m * ldc + n, v);
-    }
-  }
-}
-
-// XCD-aware tile order.  Blocks are dealt round-robin to the 8 XCDs (private 4 MB L2 each); remap so that every XCD owns a
-// CONTIGUOUS chunk of a supertile order: groups of GM M-tiles, inside a group N-tile-major.  The ~64 workgroups an XCD runs
-// concurrently then cover ~8 A panels x ~8 B panels (~3 MB at K = 768) instead of 64 A panels x 1 B panel, so both operands are
-// re-read from that L2, not from HBM / Infinity Cache.
-template <int GM>
-__device__ __forceinline__ void nt_tile(int nbm, int nbn, int& tm, int& tn) {
-  const int nwg = nbm * nbn, q = nwg / 8, rr = nwg % 8, xcd = blockIdx.x % 8, idx = blockIdx.x / 8;
-  const int bid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + idx;      // bijective for any nwg
-  const int per_group = GM * nbn, grp = bid / per_group, in = bid - grp * per_group;
-  const int rows = min(GM, nbm - grp * GM);          // last group may hold fewer than GM M-tiles
-  tn = in / rows;
-  tm = grp * GM + (in - tn * rows);
-}
 
 // 128 x 128 tile; waves arranged (8/MJ/2) x 2, each owning MJ*32 rows x 64 columns: MJ = 1 -> 8 waves (twice the waves per CU
 // hiding LDS-DMA / L2 latency for the same LDS footprint, at 1.5x the fragment reads per MFMA); MJ = 2 -> 4 waves.
@@ -383,7 +251,6 @@ __global__ __launch_bounds__(384) void gemm_bf16_nt96_kernel(const bf16_t* __res
 // extra occupancy and prefetch depth return.
 #define N192_T 192
 #define N192_STAGE (2 * N192_T * GB_BK * 2)      // A + B image of one k-tile: 48 KB
-template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 template <typename TO, int EPI>
 __global__ __launch_bounds__(768) void gemm_bf16_nt192_kernel(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ B, long ldb,
                                                               TO* __restrict__ C, long ldc, int M, int N, int K, const float* __restrict__ bias,
@@ -462,12 +329,16 @@ static int g_tn_waves = 8;     // measured (r01): 8 waves of 32 x 64 282 us per 
 static int g_nt_waves = 8;     // measured on MI355X (r01): 8 waves 537 TF vs 4 waves 514 TF average over the per-layer shapes
 static int g_nt_96 = 1;        // 96x192 tiles when they tile the problem into full rounds
 static int g_nt_192 = 1;       // 192x192 deep-prefetch tiles for large problems with N % 192 == 0
+static int g_nt_256 = 1;       // persistent 256-row tiles (gemm_bf16_ntp.hip): 0 never, 1 auto (large problems), 2 / 3 force 256 / 192 columns
 static int g_nt_small_m = 1;   // 64x128 tiles for shapes whose 128x128 tiling quantises badly on 512 workgroup slots
 extern "C" int climb_set_option(int key, int value) {
   if (key == 1 && (value == 4 || value == 8)) { g_nt_waves = value; return CLIMB_OK; }
   if (key == 2) { g_nt_small_m = value; return CLIMB_OK; }
   if (key == 4) { g_nt_96 = value; return CLIMB_OK; }
   if (key == 5) { g_nt_192 = value; return CLIMB_OK; }
+  if (key == 7 && value >= 0 && value <= 3) { g_nt_256 = value; return CLIMB_OK; }
+  if (key == 8) { climb_nt256_set_probe(value != 0); return CLIMB_OK; }
+  if (key == 9 && value >= 0) { climb_nt256_set_grid(value); return CLIMB_OK; }
   if (key == 6 && (value == 4 || value == 8)) { g_tn_waves = value; return CLIMB_OK; }
   if (key == 3 && value > 0) { g_tn_target = value; return CLIMB_OK; }
   return CLIMB_EINVAL;
@@ -491,6 +362,25 @@ static int nt_dispatch(const bf16_t* A, long lda, const bf16_t* B, long ldb, TO*
   // measured (r01, M = 12288): the single-round N = 768 GEMMs gain 15-25 % (K = 3072: 102 -> 79 us); on multi-round shapes the
   // epilogue-heavy kernels lose the second resident workgroup that computes while the first one stores, and come out 5-12 % slower
   const bool use192 = glds && g_nt_192 == 1 && (N % N192_T) == 0 && K >= 2 * GB_BK && nwg192 >= 160 && nwg192 <= 256;
+  // persistent 256 x {256, 192} tiles (gemm_bf16_ntp.hip): the tile width whose last round of 256 workgroups wastes less
+  const bool epi256 = epi == EPI_NONE || epi == EPI_GELU || epi == EPI_RESID || epi == EPI_DGELU;
+  if (glds && epi256 && K >= 2 * GB_BK && g_nt_256 != 0) {
+    const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256), t192 = (long)((M + 255) / 256) * ((N + 191) / 192);
+    const long c256 = (t256 + 255) / 256 * 256, c192 = (t192 + 255) / 256 * 192;       // rounds x tile width
+    int bn = c192 < c256 ? 192 : 256;
+    if (g_nt_256 == 2) bn = 256;
+    if (g_nt_256 == 3) bn = 192;
+    const bool big = (long)M * N >= 2048L * 768;            // below that the 64 x 128 / 128 x 128 kernels fill the chip better
+    // measured (r02, M = 12288): at K = 768 the single-round N = 768 shapes are a tie or better on the 192 x 192 three-stage kernel
+    // (dctx 24.6 vs 26.9 us); from K = 2304 on the persistent kernel's k-loop wins (down 88 -> 81, dhn 74 -> 69, dxn 53 -> 51 us)
+    const bool keep192 = use192 && K < 1536;
+    if (g_nt_256 >= 2 || (big && !keep192)) {
+      int rc = climb_nt256_launch(bn, A, lda, B, ldb, C, ldc, sizeof(TO) == 4 ? CLIMB_DT_F32 : CLIMB_DT_BF16, M, N, K, bias, epi, aux, ldaux, aux_out, ldauxo,
+                                  aux2, ldaux2, st);
+      if (rc == CLIMB_OK) { LAUNCH_CHECK(); return CLIMB_OK; }
+      if (rc != CLIMB_EUNSUPPORTED) return rc;
+    }
+  }
 #define NT_LAUNCH(E)                                                                                                           \
   do {                                                                                                                         \
     if (use192) {                                                                                                              \

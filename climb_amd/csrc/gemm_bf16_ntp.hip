@@ -1,0 +1,348 @@
+// bf16 NT GEMM, 256 x (64 NI) x 64 tiles (NI = 4: 256 x 256, NI = 3: 256 x 192), ONE persistent workgroup of 8 waves per CU,
+// NI phases per k-tile with counted vmcnt (the "8-phase" structure of the CDNA4 GEMM playbook: 8 phases = 2 k-tiles of 256 x 256).
+//
+// Why it exists.  The 128 x 128 kernel of gemm_bf16.hip drains vmcnt(0) at a barrier every k-tile (~30 % MFMA utilisation); the
+// 192 x 192 three-stage kernel keeps two k-tiles in flight but its 32 x 96 wave tiles read 42 B of LDS per kFLOP and stop at ~840 TF.
+// Here a wave owns 64 x (32 NI): 23 - 26 B of LDS per kFLOP, and the phases below keep a whole k-tile of LDS-DMA in flight across
+// the barriers.  Measured (r02, M = 12288, random operands): k-loop 1290 - 1380 TF at large K (the 128 x 128 kernel: 930 - 990).
+//
+// Geometry.  Waves 4 (M) x 2 (N); wave (wr, wc) owns rows wr*64 .. +64, columns wc*32 NI .. +32 NI = [NI n-blocks][2 m-blocks] of
+// v_mfma_f32_32x32x16_bf16 (128 / 96 accumulator registers), operands swapped as in gemm_bf16.hip (a lane owns one output row x 4
+// consecutive columns per register group: the LDS-turned row-contiguous epilogue of gemm_bf16_nt.h is reused).
+//
+// LDS: 2 k-tile buffers of { A image [256 rows][64 k] = 32 KB | NI B units of 8 KB }.  B unit p holds the rows of n-block p of BOTH
+// wave columns ({wc*32 NI + 32 p + 0..31}), so that in phase p every wave reads unit p and the unit is dead when the phase is over.
+// All images have 128-B rows with the 16-B chunks XOR-swizzled by swz(row); they are filled by LDS-DMA (global_load_lds_dwordx4)
+// with the swizzle applied on the SOURCE address.  Staging units: A0 / A1 = rows 0..127 / 128..255 (2 DMA instructions per lane
+// each), B_p (1 instruction per lane).
+//
+// Phase p of k-tile T = { ds_read the fragments of n-block p (4 x ds_read_b128; in phase 0 also the A fragments of both m-blocks,
+// 8 x, kept for the whole k-tile); issue this phase's staging units; counted vmcnt; s_barrier; 8 MFMAs under s_setprio(1);
+// s_barrier }.  The two wave groups (waves 0-3 / 4-7: one of each per SIMD) run staggered by one barrier, so while one group
+// issues MFMAs the other issues its ds_reads / DMAs.  With that stagger the placement rules are (derivation in DESIGN.md):
+//   RAW  data whose vmcnt wait sits before the first barrier of phase w may be read from phase w + 1 on;
+//   WAR  a unit whose last ds_read is in phase q may be restaged from phase q + 2 on.
+// The issue schedule (ntp_sched) puts every unit at the earliest phase WAR allows and the wait counts are DERIVED from it at compile
+// time (ntp_wait simulates the issue sequence, including the two tail k-tiles and the prologue), so the two cannot drift apart.
+// vmcnt is never 0 in the main loop: 7 - 10 DMA instructions (about one k-tile) stay in flight across every barrier.
+//
+// Persistent: gridDim.x = min(tiles, 256); workgroup b walks tiles b, b + grid, ... (same XCD, XCD-contiguous supertile order), so
+// the epilogue's global stores drain under the next tile's k-loop instead of delaying the workgroup's exit (measured: the store burst
+// of a 256-CU round is 5 - 13 us of HBM-write time that a one-tile-per-workgroup launch exposes after every round).
+#include "gemm_bf16_nt.h"
+
+#define NTP_BM 256
+#define NTP_A_BYTES (NTP_BM * GB_BK * 2)      // 32 KB
+#define NTP_B_UNIT (64 * GB_BK * 2)           // 8 KB
+
+// ---------------------------------------------------------------------------------------------------- schedule (compile time)
+// unit ids: 0 = A0, 1 = A1, 2 + p = B_p.  ntp_sched(NI, phase, k) = k-th unit issued in that phase of the body of k-tile T, encoded
+// unit * 4 + d where the data belongs to k-tile T + d; -1 = none.
+#ifndef NTP_VARIANT
+#define NTP_VARIANT 0     // measured (r02): variants 0 and 1 are within noise of each other on every shape; 0 issues 2 DMAs per lane per phase
+#endif
+#define NTP_MAXI 3        // staging units issued per phase, at most
+constexpr int ntp_sched(int NI, int p, int k) {
+#define U_(unit, d) ((unit) * 4 + (d))
+  if (NI == 4) {
+    if (NTP_VARIANT == 0) {   // two DMA instructions per lane in every phase; B_0 has 3 phases from issue to its wait, the rest 4 - 5
+      const int t[4][NTP_MAXI] = {{U_(2, 1), U_(3, 1), -1}, {U_(4, 1), U_(5, 1), -1}, {U_(0, 2), -1, -1}, {U_(1, 2), -1, -1}};
+      return t[p][k];
+    }
+    // every unit at the EARLIEST phase WAR allows (A and B_0: dead after phase 0 -> phase 2; B_q -> phase q + 2): 4 - 5 phases of slack each
+    const int t[4][NTP_MAXI] = {{U_(4, 1), -1, -1}, {U_(5, 1), -1, -1}, {U_(0, 2), U_(2, 2), -1}, {U_(1, 2), U_(3, 2), -1}};
+    return t[p][k];
+  }
+  if (NTP_VARIANT == 0) {
+    const int t[3][NTP_MAXI] = {{U_(1, 1), U_(2, 1), -1}, {U_(3, 1), U_(4, 1), -1}, {U_(0, 2), -1, -1}};
+    return t[p][k];
+  }
+  const int t[3][NTP_MAXI] = {{U_(3, 1), -1, -1}, {U_(4, 1), -1, -1}, {U_(0, 2), U_(1, 2), U_(2, 2)}};      // 3 phases of slack for every unit
+  return t[p][k];
+#undef U_
+}
+constexpr int ntp_nglds(int unit) { return unit < 2 ? 2 : 1; }
+// is (unit, tile t) read by the phase that FOLLOWS phase p of k-tile T?
+constexpr bool ntp_needed_next(int NI, int T, int p, int unit, int t) {
+  if (p + 1 < NI) return t == T && unit == 2 + p + 1;
+  return t == T + 1 && unit <= 2;             // next k-tile's phase 0: A0, A1, B_0
+}
+// vmcnt for the wait in phase p of k-tile T (after that phase's own issues) when the k-loop has nk tiles; -1 = nothing to wait for.
+// T = -1, p = NI - 1 is the prologue's wait.
+constexpr int ntp_wait(int NI, int nk, int T, int p) {
+  int cum = 0, need_end = -1;
+  for (int Tb = -2; Tb <= T; ++Tb)
+    for (int pb = 0; pb < NI; ++pb) {
+      if (Tb == T && pb > p) break;
+      for (int k = 0; k < NTP_MAXI; ++k) {
+        const int e = ntp_sched(NI, pb, k);
+        if (e < 0) continue;
+        const int unit = e / 4, t = Tb + e % 4;
+        if (t < 0 || t >= nk) continue;
+        cum += ntp_nglds(unit);
+        if (ntp_needed_next(NI, T, p, unit, t)) need_end = cum;
+      }
+    }
+  return need_end < 0 ? -1 : cum - need_end;
+}
+// the hand-derived counts of the 256 x 256 schedule (main loop, second-to-last k-tile, last k-tile, prologue)
+#if NTP_VARIANT == 0
+static_assert(ntp_wait(4, 6, 2, 0) == 8 && ntp_wait(4, 6, 2, 1) == 9 && ntp_wait(4, 6, 2, 2) == 10 && ntp_wait(4, 6, 2, 3) == 7, "main");
+static_assert(ntp_wait(4, 6, 4, 0) == 8 && ntp_wait(4, 6, 4, 1) == 9 && ntp_wait(4, 6, 4, 2) == 8 && ntp_wait(4, 6, 4, 3) == 3, "nk-2");
+static_assert(ntp_wait(4, 6, 5, 0) == 2 && ntp_wait(4, 6, 5, 1) == 1 && ntp_wait(4, 6, 5, 2) == 0 && ntp_wait(4, 6, 5, 3) == -1, "nk-1");
+static_assert(ntp_wait(4, 6, -1, 3) == 7 && ntp_wait(4, 2, -1, 3) == 7 && ntp_wait(4, 2, 0, 3) == 3 && ntp_wait(4, 2, 1, 0) == 2, "prologue / nk = 2");
+static_assert(ntp_wait(3, 6, 2, 0) == 6 && ntp_wait(3, 6, 2, 1) == 7 && ntp_wait(3, 6, 2, 2) == 4, "192 main");
+#endif
+
+template <int NI>
+struct NtpStage {
+  unsigned a_off[4];       // per lane: byte offset (from A) of its 4 DMA sources of the A image, k-tile 0
+  unsigned b_off[NI];      // per lane: byte offset (from B) of its DMA source of B unit p
+  unsigned wid;            // wave index (uniform)
+};
+
+// issue the staging units of phase P of the body of k-tile T (D1 / D2: units of k-tile T + 1 / T + 2 are still inside the k-loop)
+template <int NI, int P, bool D1, bool D2, int K_ = 0>
+__device__ __forceinline__ void ntp_issue(const NtpStage<NI>& sg, const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
+                                          unsigned char* __restrict__ smem, int T) {
+  if constexpr (K_ < NTP_MAXI) {
+    constexpr int BUF = NTP_A_BYTES + NI * NTP_B_UNIT;
+    constexpr int e = ntp_sched(NI, P, K_);
+    if constexpr (e >= 0) {
+      constexpr int unit = e / 4, d = e % 4;
+      if constexpr ((d == 1 && D1) || (d == 2 && D2)) {
+        const int t = T + d;
+        unsigned char* buf = smem + (t & 1) * BUF;
+        const long koff = (long)t * (GB_BK * 2);               // bytes along k: uniform, folds into the scalar base
+        if constexpr (unit < 2) {
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)(reinterpret_cast<const unsigned char*>(A) + koff + sg.a_off[unit * 2 + i]),
+                                             (lds_void_t*)(buf + unit * (NTP_A_BYTES / 2) + (sg.wid * 2 + i) * 1024), 16, 0, 0);
+        } else {
+          __builtin_amdgcn_global_load_lds((gbl_void_t*)(reinterpret_cast<const unsigned char*>(B) + koff + sg.b_off[unit - 2]),
+                                           (lds_void_t*)(buf + NTP_A_BYTES + (unit - 2) * NTP_B_UNIT + sg.wid * 1024), 16, 0, 0);
+        }
+      }
+    }
+    ntp_issue<NI, P, D1, D2, K_ + 1>(sg, A, B, smem, T);
+  }
+}
+
+__device__ __forceinline__ bf16x8 ntp_frag(const unsigned char* __restrict__ p) { return as_bf16x8(*reinterpret_cast<const u32x4*>(p)); }
+
+template <int NI, int P, bool D1, bool D2, int W>
+__device__ __forceinline__ void ntp_phase(f32x16 (&acc)[NI][2], bf16x8 (&a)[2][4], const NtpStage<NI>& sg, const bf16_t* __restrict__ A,
+                                          const bf16_t* __restrict__ B, unsigned char* __restrict__ smem, int T, const unsigned (&aoff)[4],
+                                          const unsigned (&boff)[4]) {
+  constexpr int BUF = NTP_A_BYTES + NI * NTP_B_UNIT;
+  const unsigned char* buf = smem + (T & 1) * BUF;
+  bf16x8 b[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) b[ks] = ntp_frag(buf + NTP_A_BYTES + P * NTP_B_UNIT + boff[ks]);
+  if constexpr (P == 0) {
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) a[jj][ks] = ntp_frag(buf + jj * 4096 + aoff[ks]);
+  }
+  ntp_issue<NI, P, D1, D2>(sg, A, B, smem, T);
+  if constexpr (W >= 0) wait_vmcnt<(W < 0 ? 0 : W)>();
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) acc[P][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[ks], a[jj][ks], acc[P][jj], 0, 0, 0);
+  __builtin_amdgcn_s_setprio(0);
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// one k-tile; MODE 0: main loop (T <= nk - 3), 1: T = nk - 2, 2: T = nk - 1
+template <int NI, int MODE, int P = 0>
+__device__ __forceinline__ void ntp_ktile(f32x16 (&acc)[NI][2], bf16x8 (&a)[2][4], const NtpStage<NI>& sg, const bf16_t* __restrict__ A,
+                                          const bf16_t* __restrict__ B, unsigned char* __restrict__ smem, int T, const unsigned (&aoff)[4],
+                                          const unsigned (&boff)[4]) {
+  if constexpr (P < NI) {
+    constexpr int W = ntp_wait(NI, 6, MODE == 0 ? 2 : (MODE == 1 ? 4 : 5), P);
+    ntp_phase<NI, P, MODE <= 1, MODE == 0, W>(acc, a, sg, A, B, smem, T, aoff, boff);
+    ntp_ktile<NI, MODE, P + 1>(acc, a, sg, A, B, smem, T, aoff, boff);
+  }
+}
+template <int NI, int P = 0>
+__device__ __forceinline__ void ntp_prologue(const NtpStage<NI>& sg, const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
+                                             unsigned char* __restrict__ smem) {
+  // what the bodies of k-tiles -2 and -1 would have issued, in the same order
+  if constexpr (P < NI) {
+    ntp_issue<NI, P, false, true>(sg, A, B, smem, -2);
+    ntp_prologue<NI, P + 1>(sg, A, B, smem);
+  } else if constexpr (P < 2 * NI) {
+    ntp_issue<NI, P - NI, true, true>(sg, A, B, smem, -1);
+    ntp_prologue<NI, P + 1>(sg, A, B, smem);
+  }
+}
+
+// Epilogue of one wave: its 64 x (32 NI) block goes out as sub-blocks of 32 rows x (32 NIE) columns (NIE = 2 for NI = 4: the 16
+// residual float4s of a full-width block next to 128 accumulators spill; NIE = 3 for NI = 3), each turned through the wave's private
+// NIE*4 KB staging region; the residual / pre-activation operands of sub-block s + 1 are fetched while sub-block s drains.
+template <int NI> struct NtpEpi { static constexpr int NIE = NI == 4 ? 2 : NI, PER_ROW = NI / NIE, NSB = 2 * PER_ROW; };
+template <int S, typename TO, int EPI, int NI>
+__device__ __forceinline__ void ntp_epilogue(const f32x16 (&acc)[NI][2], AuxRegs<EPI, NtpEpi<NI>::NIE * 4> cur, bool first, unsigned char* __restrict__ stage,
+                                             int el, int mw, int nw, int M, int N, TO* __restrict__ C, long ldc, const float* __restrict__ bias,
+                                             const void* __restrict__ aux, long ldaux, bf16_t* __restrict__ aux_out, long ldauxo) {
+  using E = NtpEpi<NI>;
+  if constexpr (S < E::NSB) {
+    constexpr int J = S / E::PER_ROW, H = S % E::PER_ROW;
+    if constexpr (S == 0) nt_aux_prefetch_l<EPI, E::NIE, 1>(cur, el, mw, nw, M, N, aux, ldaux, nullptr, 0);
+    {
+      f32x16 blk[E::NIE];
+#pragma unroll
+      for (int i = 0; i < E::NIE; ++i) blk[i] = acc[H * E::NIE + i][J];
+      nt_epi_stage<E::NIE>(blk, stage, el);
+    }
+    __builtin_amdgcn_sched_barrier(0);      // order pinned: this sub-block's accumulators are dead before the next one's operands arrive
+    AuxRegs<EPI, E::NIE * 4> nxt;
+    if constexpr (S + 1 < E::NSB) {
+      constexpr int J1 = (S + 1) / E::PER_ROW, H1 = (S + 1) % E::PER_ROW;
+      nt_aux_prefetch_l<EPI, E::NIE, 1>(nxt, el, mw + J1 * 32, nw + H1 * E::NIE * 32, M, N, aux, ldaux, nullptr, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    nt_epi_drain<TO, EPI, E::NIE, 0>(cur, stage, el, mw + J * 32, nw + H * E::NIE * 32, M, N, C, ldc, bias, aux_out, ldauxo);
+    __builtin_amdgcn_sched_barrier(0);
+    ntp_epilogue<S + 1, TO, EPI, NI>(acc, nxt, false, stage, el, mw, nw, M, N, C, ldc, bias, aux, ldaux, aux_out, ldauxo);
+  }
+}
+
+template <typename TO, int EPI, int NI>
+__global__ __launch_bounds__(512) void gemm_bf16_ntp_kernel(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ B, long ldb,
+                                                            TO* __restrict__ C, long ldc, int M, int N, int K, const float* __restrict__ bias,
+                                                            const void* __restrict__ aux, long ldaux, bf16_t* __restrict__ aux_out, long ldauxo, int probe) {
+  constexpr int BN = 64 * NI;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // 2 x (32 KB + NI x 8 KB) = 128 KB / 112 KB
+  const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wid >> 1, wc = wid & 1, grp = wid >> 2, half = lane >> 5, l31 = lane & 31;
+  const int nbm = (M + NTP_BM - 1) / NTP_BM, nbn = (N + BN - 1) / BN;
+  // fragment read offsets: row (wr*64 | wc*32) + l31 (+ 32 for the second m-block), k-chunk 2 ks + half, swizzled
+  unsigned aoff[4], boff[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const int cs = ((2 * ks + half) ^ swz(l31)) << 4;       // swz() only looks at row bits 1..3: the same for every block of a wave
+    aoff[ks] = (wr * 64 + l31) * 128 + cs;
+    boff[ks] = (wc * 32 + l31) * 128 + cs;
+  }
+  const int nk = K / GB_BK;                                  // >= 2 (launcher)
+  for (int id = blockIdx.x; id < nbm * nbn; id += gridDim.x) {
+    int tm, tn;
+    nt_tile_id<8>(id, nbm, nbn, tm, tn);
+    const int m0 = tm * NTP_BM, n0 = tn * BN;
+    // LDS-DMA plan: a 1 KB piece = 8 rows x 8 chunks; wave w issues pieces 2w, 2w + 1 of A0 and of A1 and piece w of every B unit
+    NtpStage<NI> sg;
+    sg.wid = wid;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int slot = (wid * 2 + i) * 64 + lane, r = u * 128 + (slot >> 3), c = (slot & 7) ^ swz(r);
+        int arow = m0 + r;
+        arow = arow < M ? arow : M - 1;                     // clamped rows are computed but never stored
+        sg.a_off[u * 2 + i] = (unsigned)(((long)arow * lda + c * 8) * 2);
+      }
+#pragma unroll
+    for (int p = 0; p < NI; ++p) {
+      const int slot = wid * 64 + lane, r = slot >> 3, c = (slot & 7) ^ swz(r);       // r = 0..63: wave column r >> 5, row r & 31 of n-block p
+      int brow = n0 + (r >> 5) * (32 * NI) + p * 32 + (r & 31);
+      brow = brow < N ? brow : N - 1;
+      sg.b_off[p] = (unsigned)(((long)brow * ldb + c * 8) * 2);
+    }
+    f32x16 acc[NI][2];   // [n block][m block]
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    bf16x8 a[2][4];
+    ntp_prologue<NI>(sg, A, B, smem);
+    wait_vmcnt<ntp_wait(NI, 6, -1, NI - 1)>();               // A0, A1, B_0 of k-tile 0: this wave's pieces have landed
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();                            // ... and everybody else's
+    if (grp == 1) __builtin_amdgcn_s_barrier();              // group 1 runs one barrier behind group 0 from here on
+    __builtin_amdgcn_sched_barrier(0);
+    int T = 0;
+    for (; T + 2 < nk; ++T) ntp_ktile<NI, 0>(acc, a, sg, A, B, smem, T, aoff, boff);
+    ntp_ktile<NI, 1>(acc, a, sg, A, B, smem, T, aoff, boff);
+    ntp_ktile<NI, 2>(acc, a, sg, A, B, smem, T + 1, aoff, boff);
+    if (grp == 0) __builtin_amdgcn_s_barrier();              // re-align the groups: every wave is past its last fragment read
+    __builtin_amdgcn_sched_barrier(0);
+    if (probe) {          // measurement aid (climb_set_option 8): the k-loop alone, accumulators kept live, nothing stored
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(acc[i][j][r]));
+    } else {
+      // epilogue: the k-tile buffers are free; each wave turns its block through a private staging region inside them.
+      // `el` is the lane id behind an opaque move, so that none of the epilogue's address arithmetic is hoisted out of the tile
+      // loop and kept in registers across the k-loop (measured: 27 spilled registers and a vmcnt(0) in the k-loop otherwise).
+      int el = lane;
+      asm volatile("" : "+v"(el));
+      ntp_epilogue<0, TO, EPI, NI>(acc, AuxRegs<EPI, NtpEpi<NI>::NIE * 4>(), true, smem + wid * (NtpEpi<NI>::NIE * 4096), el, m0 + wr * 64,
+                                   n0 + wc * (32 * NI), M, N, C, ldc, bias, aux, ldaux, aux_out, ldauxo);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();       // the staging regions are the next tile's k-tile buffers
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+static int g_nt256_probe = 0, g_nt256_grid = 256;
+void climb_nt256_set_probe(int v) { g_nt256_probe = v; }
+void climb_nt256_set_grid(int v) { g_nt256_grid = v; }
+
+template <typename TO, int EPI, int NI>
+static int ntp_launch_one(int nwg, hipStream_t st, const bf16_t* A, long lda, const bf16_t* B, long ldb, TO* C, long ldc, int M, int N, int K,
+                          const float* bias, const void* aux, long ldaux, bf16_t* aux_out, long ldauxo) {
+  constexpr int LDS = 2 * (NTP_A_BYTES + NI * NTP_B_UNIT);
+  static bool configured = false;      // per instantiation; the attribute is sticky for the process
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_ntp_kernel<TO, EPI, NI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) return (int)e;
+    configured = true;
+  }
+  hipLaunchKernelGGL((gemm_bf16_ntp_kernel<TO, EPI, NI>), dim3(nwg), dim3(512), LDS, st, A, lda, B, ldb, C, ldc, M, N, K, bias, aux, ldaux, aux_out,
+                     ldauxo, g_nt256_probe);
+  return CLIMB_OK;
+}
+
+// bn 256 / 192; c_dtype 0 fp32 / 1 bf16.  Requires K % 64 == 0, K >= 128 and operands below 4 GB (32-bit DMA source offsets).
+int climb_nt256_launch(int bn, const bf16_t* A, long lda, const bf16_t* B, long ldb, void* C, long ldc, int c_dtype, int M, int N, int K, const float* bias,
+                       int epi, const void* aux, long ldaux, bf16_t* aux_out, long ldauxo, const bf16_t* aux2, long ldaux2, hipStream_t st) {
+  if ((bn != 256 && bn != 192) || (K % GB_BK) || K < 2 * GB_BK) return CLIMB_EUNSUPPORTED;
+  if (((long)M * lda + K) * 2 >= (1L << 32) || ((long)N * ldb + K) * 2 >= (1L << 32)) return CLIMB_EUNSUPPORTED;
+  // 16 residual float4s per lane next to 128 accumulators spill (measured: 80 B/lane of scratch): the residual epilogue only exists
+  // for the 192-wide tile, which is also the width the layer's residual GEMMs (N = 768) tile best with
+  if (epi == EPI_RESID) bn = 192;
+  int nwg = ((M + NTP_BM - 1) / NTP_BM) * ((N + bn - 1) / bn);
+  if (g_nt256_grid > 0 && nwg > g_nt256_grid) nwg = g_nt256_grid;       // persistent: one workgroup per CU walks the tiles
+#define LNTP(TO, E, NI_) return ntp_launch_one<TO, E, NI_>(nwg, st, A, lda, B, ldb, (TO*)C, ldc, M, N, K, bias, aux, ldaux, aux_out, ldauxo)
+#define LNTP_EPI(TO, NI_)                     \
+  switch (epi) {                              \
+    case EPI_NONE: LNTP(TO, EPI_NONE, NI_);   \
+    case EPI_GELU: LNTP(TO, EPI_GELU, NI_);   \
+    case EPI_DGELU: LNTP(TO, EPI_DGELU, NI_); \
+    default: break;                           \
+  }
+  if (c_dtype == CLIMB_DT_F32 && bn == 256) { LNTP_EPI(float, 4) }
+  if (c_dtype == CLIMB_DT_BF16 && bn == 256) { LNTP_EPI(bf16_t, 4) }
+  if (c_dtype == CLIMB_DT_F32 && bn == 192) { LNTP_EPI(float, 3) if (epi == EPI_RESID) LNTP(float, EPI_RESID, 3); }
+  if (c_dtype == CLIMB_DT_BF16 && bn == 192) { LNTP_EPI(bf16_t, 3) if (epi == EPI_RESID) LNTP(bf16_t, EPI_RESID, 3); }
+#undef LNTP_EPI
+#undef LNTP
+  return CLIMB_EUNSUPPORTED;
+}

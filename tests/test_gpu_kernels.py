@@ -286,6 +286,74 @@ def test_gemm_bf16_nt(M, N, K):
     assert _rel(C16.float(), ur.grad) < 5e-3
 
 
+@pytest.mark.parametrize("force", [2, 3])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (300, 328, 192), (1000, 2304, 768), (512, 3072, 768), (256, 768, 3072), (777, 512, 2304)])
+def test_gemm_bf16_nt_256_tiles(M, N, K, force):
+    """The persistent 256 x 256 (option 7 = 2) / 256 x 192 (= 3) counted-vmcnt kernel forced on at shapes that walk its edges: the
+    minimum of two k-tiles, an odd k-tile count, ragged last row / column tiles, every epilogue it implements, both output types --
+    against float64 of the same bf16-rounded operands."""
+    from climb_amd import _lib
+    dev = _dev()
+    g = torch.Generator().manual_seed(M + N + K)
+    A, W = _bf(torch.randn(M, K, generator=g)), _bf(torch.randn(N, K, generator=g) * 0.05)
+    bias = torch.randn(N, generator=g)
+    ref = A.double() @ W.double().t() + bias.double()
+    Ad, Wd, bd = A.to(dev), W.to(dev), bias.to(dev)
+    _lib.call("climb_set_option", 7, force)
+    try:
+        C32 = torch.full((M + 1, N), 7.0, device=dev)          # one guard row: a tile that stores past M would be seen
+        _lib.call("climb_gemm_bf16_nt", Ad, K, Wd, K, C32, N, 0, M, N, K, bd, 0, None, 0, None, 0, None, 0, _st())
+        assert _rel(C32[:M], ref) < 1e-5 and bool((C32[M] == 7.0).all())
+        C16 = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+        U = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+        _lib.call("climb_gemm_bf16_nt", Ad, K, Wd, K, C16, N, 1, M, N, K, bd, 1, None, 0, U, N, None, 0, _st())
+        assert _rel(U.float(), ref) < 5e-3 and _rel(C16.float(), gelu(ref)) < 5e-3
+        R = torch.randn(M, N, generator=g).to(dev)
+        _lib.call("climb_gemm_bf16_nt", Ad, K, Wd, K, C32, N, 0, M, N, K, bd, 2, R, N, None, 0, None, 0, _st())
+        assert _rel(C32[:M], ref + R.cpu().double()) < 1e-5
+        Uin = _bf(torch.randn(M, N, generator=g)).to(dev)
+        _lib.call("climb_gemm_bf16_nt", Ad, K, Wd, K, C16, N, 1, M, N, K, None, 3, Uin, N, None, 0, None, 0, _st())
+        ur = Uin.cpu().double().requires_grad_(True)
+        gelu(ur).backward(A.double() @ W.double().t())
+        assert _rel(C16.float(), ur.grad) < 5e-3
+    finally:
+        _lib.call("climb_set_option", 7, 1)
+
+
+@pytest.mark.parametrize("force", [2, 3])
+@pytest.mark.parametrize("N,K", [(2304, 768), (3072, 768), (768, 3072)])
+def test_gemm_bf16_nt_256_race_screen_full_size(N, K, force):
+    """Benchmark-size launches (M = 12288: every CU busy, several rounds) of the 256 x 256 kernel, repeated: its LDS-DMA /
+    barrier placement is a hand-counted schedule, and an early fragment read would show as rare wrong tiles under load.  Both
+    kernels accumulate k in the same order with the same MFMA, so the fp32 result must equal the 128 x 128 two-barrier kernel's
+    BIT FOR BIT, every time."""
+    from climb_amd import _lib
+    dev = _dev()
+    M = 12288
+    g = torch.Generator(device=dev).manual_seed(N + K)
+    Ad = torch.randn(M, K, device=dev, generator=g).bfloat16()
+    Wd = (torch.randn(N, K, device=dev, generator=g) * 0.05).bfloat16()
+    ref = torch.empty(M, N, device=dev)
+    try:
+        _lib.call("climb_set_option", 7, 0)
+        _lib.call("climb_set_option", 5, 0)
+        _lib.call("climb_gemm_bf16_nt", Ad, K, Wd, K, ref, N, 0, M, N, K, None, 0, None, 0, None, 0, None, 0, _st())
+        # spot-check the reference kernel itself on a block of rows against float64
+        rows = torch.arange(0, M, 97, device=dev)
+        r64 = Ad[rows].double() @ Wd.double().t()
+        assert _rel(ref[rows], r64) < 1e-5
+        _lib.call("climb_set_option", 7, force)
+        out = torch.empty(M, N, device=dev)
+        for it in range(6):
+            out.fill_(float("nan"))
+            _lib.call("climb_gemm_bf16_nt", Ad, K, Wd, K, out, N, 0, M, N, K, None, 0, None, 0, None, 0, None, 0, _st())
+            bad = int((out != ref).sum())
+            assert bad == 0, f"iteration {it}: {bad} elements differ from the two-barrier kernel"
+    finally:
+        _lib.call("climb_set_option", 7, 1)
+        _lib.call("climb_set_option", 5, 1)
+
+
 @pytest.mark.parametrize("M,N,K", [(64, 128, 128), (384, 768, 768), (1000, 2304, 768), (300, 768, 3072), (130, 48, 768)])
 def test_gemm_bf16_tn_weight_grad(M, N, K):
     from climb_amd import _lib

@@ -26,6 +26,10 @@ def timeit(fn, iters=20):
 if __name__ == "__main__":
     if os.environ.get("NT_WAVES") is not None:
         _lib.call("climb_set_option", 1, int(os.environ["NT_WAVES"]))
+    if os.environ.get("NT256") is not None:
+        _lib.call("climb_set_option", 7, int(os.environ["NT256"]))
+    if os.environ.get("NT256_GRID") is not None:
+        _lib.call("climb_set_option", 9, int(os.environ["NT256_GRID"]))
     if os.environ.get("NT192") is not None:
         _lib.call("climb_set_option", 5, int(os.environ["NT192"]))
     if os.environ.get("TN_WAVES") is not None:

@@ -7,8 +7,13 @@ from climb_amd import _lib
 from tools.gemm_bench import timeit, dev, st
 
 M = 12288
-for N in (768, 2304, 3072, 4096):
-    for K in (768, 1536, 3072, 6144, 12288):
+for key, env in ((7, "NT256"), (5, "NT192"), (8, "NT256_PROBE"), (9, "NT256_GRID")):
+    if os.environ.get(env) is not None:
+        _lib.call("climb_set_option", key, int(os.environ[env]))
+NS = [int(v) for v in os.environ.get("NS", "768,2304,3072,4096").split(",")]
+KS = [int(v) for v in os.environ.get("KS", "768,1536,3072,6144,12288").split(",")]
+for N in NS:
+    for K in KS:
         A = torch.randn(M, K, device=dev).bfloat16()
         W = (torch.randn(N, K, device=dev) * 0.05).bfloat16()
         C = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
