@@ -7,11 +7,15 @@ Semantics follow REF/train/visionlanguage_tasks/train_vqa.py (:121-282) and its 
 but for names, dataloaders and the loss -- verified by diff).  `train_step` runs the fused HIP step
 (forward + loss + backward [+ EWC term], no autograd graph); the optimizer is the fused AdamW.
 
-Dataset construction is host I/O and out of scope for this round: dataloaders are injected."""
+Construction matches the reference's call `Trainer(args, task_configs, model_config, device)`
+(REF/train/train_upstream_continual_learning.py:240, :254, :314): the train / validation loaders are built from
+`args.climb_data_dir` + the task's `data_dir` with climb_amd.data.datasets (the reference's file formats).  Tests and pipelines that
+already hold loaders may inject them through the optional `train_dataloader` / `val_dataloader` keywords instead."""
 from __future__ import annotations
 
 import copy
 import logging
+import os
 from typing import Dict, Optional, Tuple
 
 import torch
@@ -58,10 +62,14 @@ class VLTaskTrainer(TaskTrainer):
         self.task_config = task_configs[self.task_key]
         self.visual_input_type = model_config.get("visual_input_type", "pil-image")
         self.batch2inputs_converter = model_config.get("batch2inputs_converter", convert_batch_to_vilt_input_dict)
-        self.train_dataloader, self.val_dataloader = train_dataloader, val_dataloader
         if train_dataloader is None:
-            raise RuntimeError(f"{type(self).__name__}: pass train_dataloader/val_dataloader -- dataset loading (PIL, annotation "
-                               "parsing) is host I/O kept outside this package (SURVEY.md row F1)")
+            if getattr(args, "climb_data_dir", None) is None:
+                raise RuntimeError(f"{type(self).__name__}: needs args.climb_data_dir (the reference's data tree) or injected "
+                                   "train_dataloader / val_dataloader")
+            self.data_dir = os.path.join(args.climb_data_dir, self.task_config["data_dir"])
+            train_dataloader, built_val = self.build_dataloaders(args, task_configs)
+            val_dataloader = val_dataloader if val_dataloader is not None else built_val
+        self.train_dataloader, self.val_dataloader = train_dataloader, val_dataloader
         self.num_epochs = self.task_config["num_epochs"]
         self.lr = self.task_config["lr"]
         self.adam_epsilon = self.task_config["adam_epsilon"]
@@ -70,6 +78,10 @@ class VLTaskTrainer(TaskTrainer):
         self.loss_criterion = nn.BCEWithLogitsLoss(reduction="mean") if self.task_key == "vqa" else nn.CrossEntropyLoss()
         self.max_steps = len(self.train_dataloader) * self.num_epochs
         self.warmup_ratio = 0.1       # hard-coded in the reference too (train_vqa.py:97)
+
+    def build_dataloaders(self, args, task_configs: Dict):
+        """(train loader, validation loader) from the reference's data tree; one override per task below."""
+        raise NotImplementedError
 
     def get_train_dataloader(self):
         return self.train_dataloader
@@ -154,6 +166,14 @@ class VQATrainer(VLTaskTrainer):
     task_key = "vqa"
     target_field = "target_scores"
 
+    def build_dataloaders(self, args, task_configs):
+        """REF train_vqa.py:64-83"""
+        from ..data.datasets import MSCOCOImagesDataset, build_vqa_dataloader
+        coco = task_configs[self.task_config["images_source"]]
+        self.images_dataset = MSCOCOImagesDataset(os.path.join(args.climb_data_dir, coco["data_dir"]), getattr(args, "visual_input_type", self.visual_input_type))
+        return tuple(build_vqa_dataloader(args=args, data_dir=self.data_dir, images_dataset=self.images_dataset, split=sp,
+                                          visual_input_type=self.visual_input_type) for sp in ("train", "val"))
+
     def compute_score_with_logits(self, logits: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
         """REF train_vqa.py:99-113: VQA score of the argmax answer."""
         idx = torch.max(logits, 1)[1]
@@ -169,10 +189,30 @@ class VQATrainer(VLTaskTrainer):
 class NLVR2Trainer(VLTaskTrainer):
     task_key = "nlvr2"
 
+    def build_dataloaders(self, args, task_configs):
+        """REF train_nlvr2.py:65-73"""
+        from ..data.datasets import build_nlvr2_dataloader
+        return tuple(build_nlvr2_dataloader(args=args, data_dir=self.data_dir, split=sp, visual_input_type=self.visual_input_type) for sp in ("train", "val"))
+
 
 class SNLIVETrainer(VLTaskTrainer):
     task_key = "snli-ve"
 
+    def build_dataloaders(self, args, task_configs):
+        """REF train_snli_ve.py:64-81 (validation split is `dev`)"""
+        from ..data.datasets import Flickr30KImagesDataset, build_snli_ve_dataloader
+        flickr = task_configs[self.task_config["images_source"]]
+        images = Flickr30KImagesDataset(os.path.join(args.climb_data_dir, flickr["data_dir"]), visual_input_type=self.visual_input_type)
+        return tuple(build_snli_ve_dataloader(args=args, data_dir=self.data_dir, images_dataset=images, split=sp,
+                                              visual_input_type=self.visual_input_type) for sp in ("train", "dev"))
+
 
 class VCRTrainer(VLTaskTrainer):
     task_key = "vcr"
+
+    def build_dataloaders(self, args, task_configs):
+        """REF train_vcr.py:59-76"""
+        from ..data.datasets import build_vcr_dataloader
+        self.task_type = self.task_config["task_type"]
+        return tuple(build_vcr_dataloader(args=args, data_dir=self.data_dir, split=sp, task_type=self.task_type,
+                                          visual_input_type=self.visual_input_type) for sp in ("train", "val"))

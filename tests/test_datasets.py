@@ -1,0 +1,100 @@
+"""Row F1: the four VL datasets, their collate functions and loader conventions against what the REFERENCE's own dataset classes
+produce on the same synthetic data tree (tests/golden/datasets.json, written by oracle/gen_golden_datasets.py), plus the trainer
+constructor the upstream driver calls.  CPU only."""
+import json
+import os
+import shutil
+import types
+
+import pytest
+import torch
+
+from tests import synth_data as sd
+
+
+@pytest.fixture(scope="module")
+def tree(tmp_path_factory):
+    root = str(tmp_path_factory.mktemp("climb_data"))
+    sd.make_climb_data_tree(root, n_train=8, n_val=4, seed=0)
+    shutil.copytree(os.path.join(root, "vqav2"), os.path.join(root, "vqav2-tok"))
+    return root
+
+
+def _dump(batch):
+    out = {}
+    for k, v in batch.items():
+        if k == "images":
+            out[k] = [[list(i.size) for i in im] if isinstance(im, list) else list(im.size) for im in v]
+        elif k == "target_scores":
+            out[k] = [[int(r), int(c), round(float(v[r, c]), 6)] for r, c in v.nonzero().tolist()]
+            out["target_scores_shape"] = list(v.shape)
+        elif hasattr(v, "tolist"):
+            out[k] = v.tolist()
+        else:
+            out[k] = v
+    return out
+
+
+def test_datasets_equal_the_reference_on_the_synthetic_tree(tree, golden_dir):
+    import transformers
+    from climb_amd.data import datasets as D
+    g = json.load(open(os.path.join(golden_dir, "datasets.json")))
+    args = types.SimpleNamespace(batch_size=g["batch_size"], num_workers=0, visual_input_type="pil-image")
+    tok = sd.make_tokenizer(sd.write_vocab(os.path.join(tree, "vocab.txt")))
+    coco = D.MSCOCOImagesDataset(os.path.join(tree, "ms-coco"), "pil-image")
+    flickr = D.Flickr30KImagesDataset(os.path.join(tree, "flickr30k"), "pil-image")
+    loaders = {
+        "vqa/val": D.build_vqa_dataloader(args, os.path.join(tree, "vqav2"), coco, "val", "pil-image"),
+        "vqa/val/tokenized": D.build_vqa_dataloader(args, os.path.join(tree, "vqav2-tok"), coco, "val", "pil-image", tokenizer=tok),
+        "nlvr2/val": D.build_nlvr2_dataloader(args, os.path.join(tree, "nlvr2"), "val", "pil-image"),
+        "snli-ve/dev": D.build_snli_ve_dataloader(args, os.path.join(tree, "snli-ve"), flickr, "dev", "pil-image"),
+        "vcr/val": D.build_vcr_dataloader(args, os.path.join(tree, "vcr") + "/", "val", "qa", "pil-image"),
+    }
+    assert set(loaders) == set(g["loaders"])
+    for name, dl in loaders.items():
+        want = g["loaders"][name]
+        assert len(dl.dataset) == want["n_examples"] and len(dl) == want["n_batches"], name
+        got = [_dump(b) for b in dl]
+        assert json.loads(json.dumps(got)) == want["batches"], name          # texts, labels, soft targets, token ids, image sizes, keys
+    for pl in g["process_list"]:
+        assert D.process_list(pl["text"], pl["objects"]) == pl["out"]
+    # loader conventions of the reference: NLVR2 halves and VCR quarters the batch size; training splits shuffle
+    assert loaders["nlvr2/val"].batch_size == 2 and loaders["vcr/val"].batch_size == 1 and loaders["vqa/val"].batch_size == 4
+    tr = D.build_vqa_dataloader(args, os.path.join(tree, "vqav2"), coco, "train", "pil-image")
+    assert len(tr.dataset) == g["train_sizes"]["vqa"] and isinstance(tr.sampler, torch.utils.data.RandomSampler)
+    # the parse caches are the reference's own pickle files: a second construction reads them
+    assert os.path.exists(os.path.join(tree, "vqav2", "cached_vqa_data", "vqa_val.pkl"))
+    again = D.VQADataset(os.path.join(tree, "vqav2"), coco, "val")
+    assert again.data == loaders["vqa/val"].dataset.data
+
+
+def test_pre_shrink_size_rule_and_vqa_soft_scores():
+    from climb_amd.data import datasets as D
+    assert D.resized_output_size(500, 400) == (480, 384)            # shorter edge -> 384
+    assert D.resized_output_size(400, 1000) == (256, 640)           # ... unless the longer edge would pass 640
+    assert D.resized_output_size(640, 480) == (512, 384)
+    assert [D.get_score(k) for k in range(6)] == [0.0, 0.3, 0.6, 0.9, 1.0, 1.0]
+    t = D.target_tensor(10, [3, 7], [0.3, 1.0])
+    assert t[3] == pytest.approx(0.3) and t[7] == 1.0 and float(t.sum()) == pytest.approx(1.3)
+    raw = D.image_collate([torch.zeros(3, 4, 5), torch.ones(3, 4, 5)], "raw")
+    assert raw.shape == (2, 3, 4, 5)
+    feats = D.image_collate([torch.ones(2, 8), torch.ones(5, 8)], "fast-rcnn")
+    assert feats.shape == (2, 5, 8) and float(feats[0, 2:].abs().sum()) == 0.0
+
+
+def test_trainers_are_constructible_the_way_the_upstream_driver_constructs_them(tree):
+    """REF/train/train_upstream_continual_learning.py:254: `task_trainer_class(args, task_configs, model_config, device)`."""
+    from climb_amd.configs.model_configs import model_configs
+    from climb_amd.configs.task_configs import task_configs
+    args = types.SimpleNamespace(batch_size=4, num_workers=0, visual_input_type="pil-image", climb_data_dir=tree, cl_algorithm="sequential_ft")
+    sizes = {"vqa": (2, 1), "nlvr2": (4, 2), "snli-ve": (2, 1), "vcr": (8, 4)}        # batches per epoch: train, validation
+    for task, (ntr, nva) in sizes.items():
+        trainer = task_configs[task]["task_trainer"](args, task_configs, model_configs["vilt"], torch.device("cpu"))
+        assert len(trainer.get_train_dataloader()) == ntr and len(trainer.val_dataloader) == nva
+        assert trainer.max_steps == ntr * task_configs[task]["num_epochs"]
+        batch = next(iter(trainer.val_dataloader))
+        inputs = trainer.batch2inputs_converter(batch)
+        assert set(inputs) == {"images", "texts"} and len(inputs["texts"]) == len(batch["raw_texts"])
+        assert callable(trainer.get_collate_fn())
+    with pytest.raises(RuntimeError):
+        task_configs["vqa"]["task_trainer"](types.SimpleNamespace(batch_size=4), task_configs, model_configs["vilt"], torch.device("cpu"))

@@ -138,7 +138,8 @@ def test_process_inputs_equals_vilt_processor(tmp_path):
     from climb_amd.modeling import create_continual_learner_map
     vocab = ["[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]"] + "what is the man holding a red umbrella dog on left ? color ##s two".split()
     (tmp_path / "vocab.txt").write_text("\n".join(vocab) + "\n")
-    tok = transformers.BertTokenizerFast(vocab_file=str(tmp_path / "vocab.txt"), do_lower_case=True)
+    from tests.synth_data import make_tokenizer
+    tok = make_tokenizer(str(tmp_path / "vocab.txt"), fast=True)          # (transformers 5.x ignores `vocab_file=`: every word would be [UNK])
     proc = transformers.ViltProcessor(image_processor=_hf_processor(), tokenizer=tok)
     dev = torch.device("cuda:0")
     model = create_continual_learner_map["vilt"](model_name_or_path="random-init:3", ordered_cl_tasks=["vqa"], model_config=model_configs["vilt"],
