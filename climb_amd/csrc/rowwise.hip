@@ -498,9 +498,14 @@ __device__ __forceinline__ void bilinear_tap(int o, int out, int in, int& i0, in
 // dims != NULL (variable resolution, HF:92-178): patch (py, px) of sample b is valid iff py < h_b and px < w_b; valid patches get
 // the position table resized to (h_b, w_b) on the fly; invalid canvas patches become zero rows and are masked in key_bias
 // (the reference keeps max_b(h*w) randomly ordered rows instead -- same pooled output, see oracle.visual_embed_general).
+// compact != 0 (needs dims): the valid patches of sample b are packed, raster order over ITS OWN h_b x w_b grid, into rows
+// T+1 .. T+h_b*w_b; the canvas only addresses `proj`.  A batch that mixes portrait and landscape images has a 20 x 20 canvas (400
+// patches) but never more than 240 valid patches per image (processor rule: shorter edge 384, longer <= 640), so its sequences
+// stay within the 288 rows the attention tiles are sized for -- like the reference, which keeps max_b(h_b*w_b) patch rows.
 __global__ void assemble_image_kernel(const float* __restrict__ proj, const float* __restrict__ cls, const float* __restrict__ pos,
                                       const float* __restrict__ mod, const int* __restrict__ img_type, const int* __restrict__ dims,
-                                      float* __restrict__ x, float* __restrict__ key_bias, int B, int T, int NP, int gw, int g0, int S_pad, int H) {
+                                      float* __restrict__ x, float* __restrict__ key_bias, int B, int T, int NP, int gw, int g0, int S_pad, int H,
+                                      int compact) {
   const int rows = S_pad - T;
   const long n4 = (long)B * rows * H / 4;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
@@ -508,16 +513,19 @@ __global__ void assemble_image_kernel(const float* __restrict__ proj, const floa
     int c = (int)(e % H); long r = e / H;
     int rr = (int)(r % rows); int b = (int)(r / rows);
     float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-    bool valid = rr <= NP;
+    bool valid = compact ? true : rr <= NP;
+    int prow = rr - 1;                                   // canvas index of this row's patch (row of `proj`)
     if (rr == 0) {
       float4 p = ld4(pos + c), m = ld4(mod + (long)img_type[b] * H + c), v = ld4(cls + c);
       o = make_float4(v.x + p.x + m.x, v.y + p.y + m.y, v.z + p.z + m.z, v.w + p.w + m.w);
-    } else if (rr <= NP) {
+    } else if (compact || rr <= NP) {
       float4 p;
       if (dims) {
         const int hb = dims[2 * b], wb = dims[2 * b + 1];
-        const int py = (rr - 1) / gw, px = (rr - 1) - py * gw;
+        const int sw = compact ? wb : gw;                // row stride of the patch raster inside the sequence
+        const int py = (rr - 1) / sw, px = (rr - 1) - py * sw;
         valid = py < hb && px < wb;
+        prow = py * gw + px;
         if (valid) {
           int y0, y1, x0, x1; float ly, lx;
           bilinear_tap(py, hb, g0, y0, y1, ly);
@@ -532,7 +540,7 @@ __global__ void assemble_image_kernel(const float* __restrict__ proj, const floa
         p = ld4(pos + (long)rr * H + c);
       }
       if (valid) {
-        float4 m = ld4(mod + (long)img_type[b] * H + c), v = ld4(proj + ((long)b * NP + rr - 1) * H + c);
+        float4 m = ld4(mod + (long)img_type[b] * H + c), v = ld4(proj + ((long)b * NP + prow) * H + c);
         o = make_float4(v.x + p.x + m.x, v.y + p.y + m.y, v.z + p.z + m.z, v.w + p.w + m.w);
       }
     }
@@ -541,12 +549,13 @@ __global__ void assemble_image_kernel(const float* __restrict__ proj, const floa
   }
 }
 extern "C" int climb_assemble_image(const float* proj, const float* cls, const float* pos, const float* mod, const int* img_type, const int* dims,
-                                    float* x, float* key_bias, int B, int T, int NP, int gw, int g0, int S_pad, int H, void* stream) {
-  if (H % 4 || T + 1 + NP > S_pad || (dims == nullptr && NP != g0 * g0) || (dims && !key_bias) || NP % gw) return CLIMB_EINVAL;
+                                    float* x, float* key_bias, int B, int T, int NP, int gw, int g0, int S_pad, int H, int compact, void* stream) {
+  if (H % 4 || (!compact && T + 1 + NP > S_pad) || (dims == nullptr && (NP != g0 * g0 || compact)) || (dims && !key_bias) || NP % gw || T + 1 > S_pad)
+    return CLIMB_EINVAL;
   long n4 = (long)B * (S_pad - T) * H / 4;
   int grid = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
   hipLaunchKernelGGL(assemble_image_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, proj, cls, pos, mod, img_type, dims, x, key_bias, B, T, NP,
-                     gw, g0, S_pad, H);
+                     gw, g0, S_pad, H, compact);
   LAUNCH_CHECK();
   return CLIMB_OK;
 }
@@ -559,7 +568,7 @@ extern "C" int climb_assemble_image(const float* proj, const float* cls, const f
 template <typename TO>
 __global__ void image_embed_bwd_kernel(const float* __restrict__ dres, const int* __restrict__ img_type, const int* __restrict__ dims,
                                        TO* __restrict__ dproj, float* dpos, float* dcls, float* __restrict__ part, int B, int T, int NP, int gw,
-                                       int S_pad, int H, int ntypes) {
+                                       int S_pad, int H, int ntypes, int compact) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int per_row = H / 4;
   if (i >= (NP + 1) * per_row) return;
@@ -570,7 +579,8 @@ __global__ void image_embed_bwd_kernel(const float* __restrict__ dres, const int
   pt[0] = pt[1] = pt[2] = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int b = 0; b < B; ++b) {
     const bool valid = rr == 0 || dims == nullptr || (py < dims[2 * b] && px < dims[2 * b + 1]);
-    float4 v = valid ? ld4(dres + ((long)b * S_pad + T + rr) * H + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int srow = (rr > 0 && compact) ? 1 + py * dims[2 * b + 1] + px : rr;       // row of this canvas patch inside the sequence
+    float4 v = valid ? ld4(dres + ((long)b * S_pad + T + srow) * H + c) : make_float4(0.f, 0.f, 0.f, 0.f);
     tot.x += v.x; tot.y += v.y; tot.z += v.z; tot.w += v.w;
     int ty = img_type[b];
 #pragma unroll
@@ -593,7 +603,7 @@ __global__ void image_embed_bwd_kernel(const float* __restrict__ dres, const int
 // in registers and walks only the output rows whose taps touch ty; batch chunks (blockIdx.y) are combined with atomics.
 #define PIB_G0 12
 __global__ __launch_bounds__(192) void pos_interp_bwd_kernel(const float* __restrict__ dres, const int* __restrict__ dims, float* dpos, int B, int T,
-                                                             int gw, int S_pad, int H, int bchunk) {
+                                                             int gw, int S_pad, int H, int bchunk, int compact) {
   const int ty = blockIdx.x, c = threadIdx.x * 4;
   if (c >= H) return;
   float4 acc[PIB_G0];
@@ -607,7 +617,7 @@ __global__ __launch_bounds__(192) void pos_interp_bwd_kernel(const float* __rest
       bilinear_tap(py, hb, PIB_G0, y0, y1, ly);
       const float wy = (y0 == ty ? 1.f - ly : 0.f) + (y1 == ty ? ly : 0.f);
       if (wy == 0.f) continue;
-      const float* row = dres + ((long)b * S_pad + T + 1 + (long)py * gw) * H + c;
+      const float* row = dres + ((long)b * S_pad + T + 1 + (long)py * (compact ? wb : gw)) * H + c;
       for (int px = 0; px < wb; ++px) {
         int x0, x1; float lx;
         bilinear_tap(px, wb, PIB_G0, x0, x1, lx);
@@ -629,19 +639,19 @@ __global__ __launch_bounds__(192) void pos_interp_bwd_kernel(const float* __rest
 }
 // part: (NP+1)*ntypes*H floats
 extern "C" int climb_image_embed_bwd(const float* dres, const int* img_type, const int* dims, void* dproj, int dproj_dtype, float* dpos, float* dcls,
-                                     float* part, int B, int T, int NP, int gw, int g0, int S_pad, int H, int ntypes, void* stream) {
-  if (H % 4 || ntypes > 3 || NP % gw || (dims && g0 != PIB_G0) || H > 768) return CLIMB_EINVAL;
+                                     float* part, int B, int T, int NP, int gw, int g0, int S_pad, int H, int ntypes, int compact, void* stream) {
+  if (H % 4 || ntypes > 3 || NP % gw || (dims && g0 != PIB_G0) || H > 768 || (compact && !dims)) return CLIMB_EINVAL;
   int n = (NP + 1) * (H / 4);
   hipStream_t st = (hipStream_t)stream;
   if (dproj_dtype == CLIMB_DT_F32)
-    hipLaunchKernelGGL((image_embed_bwd_kernel<float>), dim3((n + 127) / 128), dim3(128), 0, st, dres, img_type, dims, (float*)dproj, dpos, dcls, part, B, T, NP, gw, S_pad, H, ntypes);
+    hipLaunchKernelGGL((image_embed_bwd_kernel<float>), dim3((n + 127) / 128), dim3(128), 0, st, dres, img_type, dims, (float*)dproj, dpos, dcls, part, B, T, NP, gw, S_pad, H, ntypes, compact);
   else if (dproj_dtype == CLIMB_DT_BF16)
-    hipLaunchKernelGGL((image_embed_bwd_kernel<bf16_t>), dim3((n + 127) / 128), dim3(128), 0, st, dres, img_type, dims, (bf16_t*)dproj, dpos, dcls, part, B, T, NP, gw, S_pad, H, ntypes);
+    hipLaunchKernelGGL((image_embed_bwd_kernel<bf16_t>), dim3((n + 127) / 128), dim3(128), 0, st, dres, img_type, dims, (bf16_t*)dproj, dpos, dcls, part, B, T, NP, gw, S_pad, H, ntypes, compact);
   else return CLIMB_EINVAL;
   LAUNCH_CHECK();
   if (dims && dpos) {
     const int bchunk = 8;
-    hipLaunchKernelGGL(pos_interp_bwd_kernel, dim3(PIB_G0, (B + bchunk - 1) / bchunk), dim3(192), 0, st, dres, dims, dpos, B, T, gw, S_pad, H, bchunk);
+    hipLaunchKernelGGL(pos_interp_bwd_kernel, dim3(PIB_G0, (B + bchunk - 1) / bchunk), dim3(192), 0, st, dres, dims, dpos, B, T, gw, S_pad, H, bchunk, compact);
     LAUNCH_CHECK();
   }
   return CLIMB_OK;

@@ -161,4 +161,6 @@ class DeviceImagePipeline:
         st = torch.cuda.current_stream().cuda_stream
         _lib.call("climb_image_resample", src, tmp, dst, coef_d, table_d, B, max_elems, st)
         _lib.call("climb_image_normalize_pad", dst, table_d, self.lut, pixel_values, pixel_mask, B, Hc, Wc, st)
+        # largest number of valid patches of any image (known on the host): lets the engine size packed sequences without a sync
+        pixel_mask._climb_max_patches = int(((table[:, 5] // 32) * (table[:, 6] // 32)).max())
         return {"pixel_values": pixel_values, "pixel_mask": pixel_mask}

@@ -34,15 +34,17 @@ def _round_up(x, m):
 class Workspace:
     """Activation + scratch buffers for one (B, T) shape; allocated once, reused every step."""
 
-    def __init__(self, eng: "ViltEngine", B: int, T: int, gh: int = None, gw: int = None):
+    def __init__(self, eng: "ViltEngine", B: int, T: int, gh: int = None, gw: int = None, nseq: int = None):
         cfg = eng.cfg
         dev = eng.device
         H, Fd, L, nh = cfg["hidden"], cfg["ffn"], cfg["layers"], cfg["heads"]
         self.B, self.T = B, T
         g0 = cfg["image"] // cfg["patch"]
         self.gh, self.gw = gh or g0, gw or g0         # patch canvas of the (padded) batch
-        self.NP = self.gh * self.gw
-        self.S = T + 1 + self.NP
+        self.NP = self.gh * self.gw                   # canvas patches (rows of the patch projection)
+        self.NS = nseq or self.NP                     # patch rows of a SEQUENCE: the canvas, or (compact) the largest valid count of a sample
+        self.compact = self.NS != self.NP
+        self.S = T + 1 + self.NS
         self.S_pad = _round_up(self.S, 32)
         self.M = B * self.S_pad
         M = self.M
@@ -172,14 +174,14 @@ class ViltEngine:
                 return True
         return False
 
-    def workspace(self, B: int, T: int, gh: int = None, gw: int = None) -> Workspace:
+    def workspace(self, B: int, T: int, gh: int = None, gw: int = None, nseq: int = None) -> Workspace:
         g0 = self.cfg["image"] // self.cfg["patch"]
-        key = (B, T, gh or g0, gw or g0)
+        key = (B, T, gh or g0, gw or g0, nseq)
         ws = self._ws.get(key)
         if ws is None:
             if len(self._ws) >= 3:      # bound HBM use when batch shapes vary (last partial batch, replay batches, canvases)
                 self._ws.pop(next(iter(self._ws)))
-            ws = self._ws[key] = Workspace(self, B, T, gh, gw)
+            ws = self._ws[key] = Workspace(self, B, T, gh, gw, nseq)
         return ws
 
     # ------------------------------------------------------------------ GEMM dispatch
@@ -367,10 +369,19 @@ class ViltEngine:
         if pixel_mask is None and (Hc, Wc) != (cfg["image"], cfg["image"]):
             raise ValueError("a canvas other than 384x384 needs its pixel_mask (variable-resolution path)")
         gh, gw = Hc // P_, Wc // P_
-        if T + 1 + gh * gw > 288:
-            raise NotImplementedError(f"sequence of {T + 1 + gh * gw} tokens exceeds the 288 this build sizes its attention tiles for")
-        ws = self.workspace(B, T, gh, gw)
         var = pixel_mask is not None
+        nseq = None
+        if T + 1 + gh * gw > 288:
+            # A padded batch that mixes portrait and landscape images: the canvas is up to 20 x 20 patches, yet no image has more
+            # than 12 x 20 valid ones (processor rule).  Pack every sample's valid patches (HF:136-159 keeps max_b(h_b*w_b) rows too).
+            nseq = getattr(pixel_mask, "_climb_max_patches", None) if var else None     # set by DeviceImagePipeline: no host sync
+            if var and nseq is None:
+                hv = (pixel_mask[:, ::P_, 0] != 0).sum(1)
+                wv = (pixel_mask[:, 0, ::P_] != 0).sum(1)
+                nseq = int((hv * wv).max().item())
+            if nseq is None or T + 1 + nseq > 288:
+                raise NotImplementedError(f"sequence of {T + 1 + (nseq or gh * gw)} tokens exceeds the 288 this build sizes its attention tiles for")
+        ws = self.workspace(B, T, gh, gw, nseq)
         st = _stream()
         adt = self.adt
         self.refresh_shadow()
@@ -390,7 +401,7 @@ class ViltEngine:
                                B * ws.NP, H, Kp)
         _lib.call("climb_assemble_image", ws.proj, self.p(e + "cls_token"), self.p(e + "position_embeddings"),
                   self.p(e + "token_type_embeddings.weight"), ws.img_type, ws.dims if var else None, x0, ws.key_bias, B, T, ws.NP, gw, g0,
-                  ws.S_pad, H, st)
+                  ws.S_pad, H, 1 if ws.compact else 0, st)
         M = ws.M
         ad = self.active_adapter
         r = self.layout.adapters[ad] if ad is not None else 0
@@ -566,7 +577,8 @@ class ViltEngine:
         g0 = cfg["image"] // cfg["patch"]
         _lib.call("climb_image_embed_bwd", ws.dres, ws.img_type, ws.dims if sv.get("var") else None, ws.dproj, self.adt,
                   self.g(e + "position_embeddings") if rg[e + "position_embeddings"] else None,
-                  self.g(e + "cls_token") if rg[e + "cls_token"] else None, ws.part, B, T, ws.NP, ws.gw, g0, ws.S_pad, H, ntypes, st)
+                  self.g(e + "cls_token") if rg[e + "cls_token"] else None, ws.part, B, T, ws.NP, ws.gw, g0, ws.S_pad, H, ntypes,
+                  1 if ws.compact else 0, st)
         self.bias_grad_from_part(ws.part.data_ptr(), ntypes * H, ws.NP + 1, e + "token_type_embeddings.weight", ntypes * H)
         Kp = cfg["channels"] * cfg["patch"] ** 2
         self.linear_dw(ws.dproj, ws.a_patch, e + "patch_embeddings.projection.weight", B * ws.NP, H, Kp, e + "patch_embeddings.projection.bias", ws)

@@ -458,7 +458,10 @@ class ViltContinualLearner(ContinualLearner):
             enc = dict(enc)
             enc["pixel_values"] = enc["pixel_values"].repeat_interleave(nc, dim=0)     # choice j of example i at row nc*i+j (REF:331-334)
             if "pixel_mask" in enc:
+                hint = getattr(enc["pixel_mask"], "_climb_max_patches", None)
                 enc["pixel_mask"] = enc["pixel_mask"].repeat_interleave(nc, dim=0)
+                if hint is not None:
+                    enc["pixel_mask"]._climb_max_patches = hint
             enc["image_token_type_idx"] = 1
             return enc, ("choice", nc)
         n = tc["num_images"]
@@ -633,13 +636,37 @@ def _load_encoder_state(vilt_encoder: ViltEncoderWrapper, path: str):
     vilt_encoder.load_state_dict(picked)
 
 
+def _offline_processor():
+    """A ViltProcessor built from local pieces when the hub is unreachable: `CLIMB_AMD_TOKENIZER_VOCAB` names a BERT word-piece
+    vocabulary file; the image half is transformers' own PIL ViLT image processor (defaults = dandelin/vilt-b32-mlm's)."""
+    vocab = os.environ.get("CLIMB_AMD_TOKENIZER_VOCAB")
+    if not vocab:
+        return None
+    import transformers
+    try:
+        from transformers.models.vilt.image_processing_pil_vilt import ViltImageProcessorPil as ImageProcessor
+    except Exception:      # noqa: BLE001  (older transformers: one image processor class)
+        from transformers import ViltImageProcessor as ImageProcessor
+    words = [w.strip() for w in open(vocab) if w.strip()]
+    for kw in ({"vocab": vocab}, {"vocab_file": vocab}):         # transformers 5.x / 4.x spelling
+        try:
+            tok = transformers.BertTokenizerFast(do_lower_case=True, **kw)
+        except Exception:      # noqa: BLE001
+            continue
+        if len(words) > 5 and tok.convert_tokens_to_ids(words[5]) == 5:
+            return transformers.ViltProcessor(image_processor=ImageProcessor(), tokenizer=tok)
+    raise RuntimeError(f"could not build a tokenizer from CLIMB_AMD_TOKENIZER_VOCAB={vocab}")
+
+
 def _make_processor(pretrained_vilt_name: str):
     try:
         from transformers import ViltProcessor
         return ViltProcessor.from_pretrained(pretrained_vilt_name)
     except Exception as e:   # offline container: tensor encodings still work (bench / tests / pre-processed pipelines)
-        logger.warning("ViltProcessor.from_pretrained(%s) unavailable (%s); only tensor encodings are accepted", pretrained_vilt_name, type(e).__name__)
-        return None
+        proc = _offline_processor()
+        if proc is None:
+            logger.warning("ViltProcessor.from_pretrained(%s) unavailable (%s); only tensor encodings are accepted", pretrained_vilt_name, type(e).__name__)
+        return proc
 
 
 def load_vilt_encoder(checkpoint_name: str, device: torch.device, pretrained_vilt_name: str, precision: Optional[str] = None) -> ViltEncoderWrapper:
@@ -651,7 +678,7 @@ def load_vilt_encoder(checkpoint_name: str, device: torch.device, pretrained_vil
         seed = int(checkpoint_name.split(":")[1]) if ":" in checkpoint_name else None
         vilt = ViltModelParams(2)
         init_like_hf(vilt, seed)
-        enc = ViltEncoderWrapper(None, vilt.to(device), device, precision)
+        enc = ViltEncoderWrapper(_offline_processor(), vilt.to(device), device, precision)
         return enc
     processor = _make_processor(pretrained_vilt_name)
     rows = 3 if (checkpoint_name != pretrained_vilt_name and "nlvr2" in checkpoint_name) else 2      # REF:507-508

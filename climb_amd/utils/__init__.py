@@ -22,9 +22,12 @@ class WandBLogger:
 
     def initialize(self, wandb_config=None, experiment_name=None):
         try:
+            import os
             import wandb
-            wandb.init(config=wandb_config, name=experiment_name)
+            os.environ["WANDB_API_KEY"] = wandb_config["api_key"]
+            wandb.init(entity=wandb_config["entity"], project=wandb_config["project_name"], name=experiment_name)
             self.is_initialized = True
+            self.log_freq = wandb_config["log_freq"]
         except Exception as e:   # wandb is absent in the offline image
             logging.getLogger(__name__).warning("wandb unavailable: %s", e)
 

@@ -44,11 +44,13 @@ int climb_patch_grid_dims(const long* pixel_mask, int B, int H, int W, int P, in
 /* HF:168-173, :211-216 (+ HF:92-166 when dims != NULL): image rows of the embedding = proj/cls + position + modality[img_type[b]].
  * Canvas of NP = gh*gw patches in raster order; dims == NULL: all patches valid and gh = gw = g0 (position table used as is);
  * dims != NULL: patch (py,px) valid iff py < h_b && px < w_b, position table resized bilinearly (align_corners) to (h_b,w_b) on the
- * fly, invalid patches written as zero rows and masked in key_bias.  Padding rows zeroed. */
-int climb_assemble_image(const float* proj, const float* cls, const float* pos, const float* mod, const int* img_type, const int* dims, float* x, float* key_bias, int B, int T, int NP, int gw, int g0, int S_pad, int H, void* stream);
+ * fly, invalid patches written as zero rows and masked in key_bias.  Padding rows zeroed.
+ * compact != 0 (with dims): sample b's valid patches are packed in raster order of its own h_b x w_b grid into rows T+1..T+h_b*w_b
+ * (the canvas only addresses `proj`): S_pad >= T + 1 + max_b h_b*w_b suffices, as in the reference (HF:136-159 keeps max_b(h*w) rows). */
+int climb_assemble_image(const float* proj, const float* cls, const float* pos, const float* mod, const int* img_type, const int* dims, float* x, float* key_bias, int B, int T, int NP, int gw, int g0, int S_pad, int H, int compact, void* stream);
 /* backward of the image rows; part[(NP+1)][ntypes][H] modality partials (reduce with climb_colreduce, stride ntypes*H);
  * with dims the position-table gradient is the transpose of the bilinear resize (gather kernel, g0 = 12) */
-int climb_image_embed_bwd(const float* dres, const int* img_type, const int* dims, void* dproj, int dproj_dtype, float* dpos, float* dcls, float* part, int B, int T, int NP, int gw, int g0, int S_pad, int H, int ntypes, void* stream);
+int climb_image_embed_bwd(const float* dres, const int* img_type, const int* dims, void* dproj, int dproj_dtype, float* dpos, float* dcls, float* part, int B, int T, int NP, int gw, int g0, int S_pad, int H, int ntypes, int compact, void* stream);
 /* HF:623-627 additive key mask as a [B,S_pad] vector: 0 keep, -3e38 masked text token or padding row */
 int climb_key_bias(const long* attn_mask, float* bias, int B, int T, int S, int S_pad, void* stream);
 

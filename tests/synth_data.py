@@ -33,7 +33,9 @@ def _size(rng, i):
     return [(500, 400), (420, 900)][(i // 4) % 2] if i % 4 == 3 else (int(rng.integers(40, 120)), int(rng.integers(40, 120)))
 
 
-def make_climb_data_tree(root, n_train=8, n_val=4, seed=0, num_answers=3129):
+def make_climb_data_tree(root, n_train=8, n_val=4, seed=0, num_answers=3129, easy_answer=None):
+    """easy_answer=k: two extra annotators of EVERY VQA question answer `ans<k>` (soft score 0.6), so that a model that always predicts k
+    scores above the random baseline of 0 -- the forgetting metric divides by that margin."""
     rng = np.random.default_rng(seed)
     os.makedirs(root, exist_ok=True)
     # ---- MS-COCO images + VQAv2
@@ -58,6 +60,8 @@ def make_climb_data_tree(root, n_train=8, n_val=4, seed=0, num_answers=3129):
             other = f"ans{int(rng.integers(0, num_answers))}"
             k = int(rng.integers(1, 11))                     # k annotators gave `main`, the rest `other` / an out-of-vocabulary answer
             answers = [{"answer": main}] * k + [{"answer": other}] * ((10 - k) // 2) + [{"answer": "not in vocabulary"}] * (10 - k - (10 - k) // 2)
+            if easy_answer is not None:
+                answers = answers + [{"answer": f"ans{easy_answer}"}] * 2
             annotations.append({"question_id": qid, "image_id": image_id, "multiple_choice_answer": main, "answers": answers})
         json.dump({"questions": questions}, open(os.path.join(vqa, f"v2_OpenEnded_mscoco_{split}2014_questions.json"), "w"))
         json.dump({"annotations": annotations}, open(os.path.join(vqa, f"v2_mscoco_{split}2014_annotations.json"), "w"))

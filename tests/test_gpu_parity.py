@@ -684,6 +684,38 @@ def test_maximum_sequence_384x640_vs_oracle():
                                      vo.synthetic_vqa_targets(1, seed=5))
 
 
+@pytest.mark.parametrize("precision,tol", [("fp32", TOL), ("bf16", BF16_TOL)])
+def test_mixed_orientation_batch_packs_valid_patches(precision, tol):
+    """A portrait image next to a landscape one pads to a 640 x 640 canvas = 400 patches, more than the 288-row sequences the
+    attention tiles are sized for; no image has more than 240 valid patches, so the engine packs each sample's valid patches
+    (the reference keeps max_b(h*w) patch rows: HF:136-159).  Real VQA / NLVR2 batches are of this kind.  Output and every
+    gradient against the oracle, which pads and masks the whole canvas."""
+    sizes = [(384, 640), (640, 384), (352, 480), (608, 384)]
+    model, P = make_model(["vqa"], 11, precision=precision)
+    enc = vo.synthetic_varres_encodings(sizes, seed=6)
+    assert tuple(enc["pixel_values"].shape[-2:]) == (640, 640)
+    target = vo.synthetic_vqa_targets(len(sizes), seed=6)
+    texts = dict(input_ids=enc["input_ids"], token_type_ids=enc["token_type_ids"], attention_mask=enc["attention_mask"])
+    images = dict(pixel_values=enc["pixel_values"], pixel_mask=enc["pixel_mask"])
+    model.train()
+    loss, (pooled, logits), _, _ = model.fused_forward_backward("vqa", images, texts, target)
+    ws = model._host._engine.saved["ws"]
+    assert ws.compact and ws.NP == 400 and ws.NS == 240 and ws.S_pad == 288
+    oloss, (opooled, ologits), _, oG = vo.train_step(P, "vqa", enc, target)
+    _close(pooled, opooled, tol, "pooled")
+    _close(logits, ologits, tol, "logits")
+    _close(loss, oloss, tol, "loss")
+    G = grads_of(model)
+    if precision == "fp32":
+        assert torch.equal(logits.argmax(-1).cpu(), ologits.argmax(-1))
+        for n, g in oG.items():
+            if n in G and not n.endswith("attention.key.bias"):
+                _close(G[n], g, tol, n)          # incl. position_embeddings (transpose of the per-sample bilinear resize) and the patch projection
+    else:
+        for n in (vo.ENC + "embeddings.patch_embeddings.projection.weight", vo.ENC + "embeddings.position_embeddings"):
+            assert abs(float(G[n].double().norm()) - float(oG[n].double().norm())) <= 6e-2 * float(oG[n].double().norm()), n
+
+
 def test_hipgraph_replay_matches_eager():
     """The captured step (one hipGraph launch) must reproduce the eager launches bit for bit, across optimizer steps and new inputs."""
     dev = _dev()
