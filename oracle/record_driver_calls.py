@@ -91,8 +91,7 @@ def main():
         rec = [dict(c) for c in calls]
         driver_trace.uninstall()
         ns = sc.namespace(name, data, out_dir)
-        exp = "vilt-" + ns.cl_algorithm
-        run_dirs = [d for d in os.listdir(out_dir) if d.startswith(exp) and "singletask" not in d]
+        run_dirs = [d for d in os.listdir(out_dir) if "singletask" not in d]
         assert len(run_dirs) == 1, run_dirs
         results = json.load(open(os.path.join(out_dir, run_dirs[0], "results.json")))
         golden["scenarios"][name] = {"experiment_dir": run_dirs[0], "calls": rec, "results": results,

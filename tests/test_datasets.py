@@ -98,3 +98,33 @@ def test_trainers_are_constructible_the_way_the_upstream_driver_constructs_them(
         assert callable(trainer.get_collate_fn())
     with pytest.raises(RuntimeError):
         task_configs["vqa"]["task_trainer"](types.SimpleNamespace(batch_size=4), task_configs, model_configs["vilt"], torch.device("cpu"))
+
+
+def test_recorded_calls_bind_to_this_packages_signatures(golden_dir):
+    """CPU-checkable half (also run on the GPU box): every recorded call's positional count and keyword set binds to the callable of
+    the same name in this package."""
+    import inspect
+    import climb_amd.cl_algorithms as cl
+    import climb_amd.cl_evaluation.evaluate_cl_algorithm as ev
+    import climb_amd.train.task_trainer as tt
+    import climb_amd.utils as ut
+    from climb_amd.modeling import create_continual_learner_map
+    from climb_amd.modeling.vilt import ViltContinualLearner, ViltEncoderWrapper
+    table = {"create_continual_learner_map[vilt]": (create_continual_learner_map["vilt"], 0), "TaskTrainer": (tt.VLTaskTrainer.__init__, 1), "EWC": (cl.EWC.__init__, 1),
+             "ExperienceReplayMemory": (cl.ExperienceReplayMemory.__init__, 1), "AdapterHandler": (cl.AdapterHandler.__init__, 1),
+             "upstream_knowledge_transfer_eval": (ev.upstream_knowledge_transfer_eval, 0), "catastrophic_forgetting_eval": (ev.catastrophic_forgetting_eval, 0),
+             "set_seed": (ut.set_seed, 0)}
+    classes = {"TaskTrainer": tt.VLTaskTrainer, "EWC": cl.EWC, "ExperienceReplayMemory": cl.ExperienceReplayMemory, "AdapterHandler": cl.AdapterHandler,
+               "ViltContinualLearner": ViltContinualLearner, "ViltEncoderWrapper": ViltEncoderWrapper}
+    g = json.load(open(os.path.join(golden_dir, "driver_calls.json")))
+    seen = set()
+    for scen in g["scenarios"].values():
+        for c in scen["calls"]:
+            if "." in c["name"]:
+                fn, skip = getattr(classes[c["name"].split(".")[0]], c["name"].split(".")[1]), 1
+            else:
+                fn, skip = table[c["name"]]
+            inspect.signature(fn).bind(*([None] * (c["nargs"] + skip)), **{k: None for k in c["kwargs"]})
+            seen.add(c["name"])
+    assert {"TaskTrainer.train", "EWC.save_task_parameters", "ExperienceReplayMemory.add_task_memory_buffer",
+            "AdapterHandler.activate_adapter_for_training", "catastrophic_forgetting_eval"} <= seen

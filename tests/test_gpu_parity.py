@@ -419,6 +419,49 @@ def test_bf16_shadows_follow_torch_side_parameter_writes(tmp_path):
 
 # ------------------------------------------------------------------------------------------------ Houlsby adapters (unpinned)
 @pytest.mark.parametrize("precision,tol", [("fp32", TOL), ("bf16", 4e-2)])
+def test_houlsby_adapter_nlvr2_step_vs_oracle_restatement(precision, tol):
+    """The NLVR2 half of BASELINE.json configs[2]: two images per example (image_token_type_idx 1 / 2, REF/modeling/vilt.py:292-303)
+    under an ACTIVE adapter, base frozen -- the step the VQA -> NLVR2 adapter sequence runs for its second task."""
+    from climb_amd.cl_algorithms import AdapterHandler
+    tasks = ["vqa", "nlvr2"]
+    model, _ = make_model(tasks, 42, precision=precision)
+    args = types.SimpleNamespace(adapter_config="houlsby", adapter_reduction_factor=16, ordered_cl_tasks=tasks)
+    handler = AdapterHandler("vanilla", args)
+    handler.add_adapters_to_model(model)
+    handler.activate_adapter_for_training(task_key="nlvr2", model=model)
+    g = torch.Generator().manual_seed(9)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if ".adapters." in n:
+                p.copy_((torch.randn(p.shape, generator=g) * (0.05 if n.endswith("weight") else 0.02)).to(p.device))
+    P = {n: p.detach().cpu().clone() for n, p in model.named_parameters()}
+    trainable = {n for n, p in model.named_parameters() if p.requires_grad}
+    assert all((".adapters.nlvr2." in n) or n.startswith("task_layer.") for n in trainable)
+    b = 3
+    e1 = vo.synthetic_encodings(2 * b, seed=12)
+    enc = dict(input_ids=e1["input_ids"][:b], token_type_ids=e1["token_type_ids"][:b], attention_mask=e1["attention_mask"][:b],
+               pixel_values=e1["pixel_values"], pixel_mask=e1["pixel_mask"])
+    texts = dict(input_ids=enc["input_ids"], token_type_ids=enc["token_type_ids"], attention_mask=enc["attention_mask"])
+    labels = torch.tensor([1, 0, 1])
+    model.train()
+    loss, (pooled, logits), _, _ = model.fused_forward_backward("nlvr2", e1["pixel_values"], texts, labels)
+    o_loss, (o_pooled, o_logits), _, oG = vo.train_step(P, "nlvr2", enc, labels, trainable=trainable, adapter="nlvr2")
+    _close(pooled, o_pooled, tol, "pooled")
+    _close(logits, o_logits, tol, "logits")
+    _close(loss, o_loss, tol, "loss")
+    G = grads_of(model)
+    assert set(G) == set(oG), set(G) ^ set(oG)
+    worst = 0.0
+    for n in oG:
+        if precision == "fp32":
+            worst = max(worst, _close(G[n], oG[n], tol, n))
+        else:
+            worst = max(worst, abs(float(G[n].double().norm()) - float(oG[n].double().norm())) / (float(oG[n].double().norm()) + 1e-30))
+    print(f"adapters nlvr2 [{precision}]: worst gradient error {worst:.2e}")
+    assert worst < (tol if precision == "fp32" else 6e-2)
+
+
+@pytest.mark.parametrize("precision,tol", [("fp32", TOL), ("bf16", 4e-2)])
 def test_houlsby_adapters_vs_oracle_restatement(precision, tol):
     """BASELINE.json configs[2] arithmetic.  The GLAMOR adapter fork is absent, so this pins the HIP path to the oracle's
     restatement of public adapter-transformers semantics (out = y + up(swish(down(y)))), not to the reference."""
