@@ -105,15 +105,36 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]      # step boundaries on the compute stream (median step time)
     fence()
     t0 = time.perf_counter()
+    marks[0].record()
     for i in range(args.steps):
         sampled = i % prof_every == 0          # event-instrumented steps launch eagerly (graph nodes cannot carry per-kernel events)
         eng.prof = prof if sampled else None
         loss = step(eager=sampled)
+        marks[i + 1].record()
     eng.prof = None
     fence()
     dt = time.perf_counter() - t0
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    # data parallel: the same K steps again with the collectives deferred to after the backward (or overlapped, if the default was
+    # deferred), so that one multi-GPU run answers whether overlap pays on this fabric
+    dp_ab = None
+    if ddp is not None and world > 1:
+        first = ddp.overlap
+        ddp.overlap = not first
+        for _ in range(2):
+            step()
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        other = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
+        dist.all_reduce(other, op=dist.ReduceOp.MAX)
+        ddp.overlap = first
+        dp_ab = {("overlap" if not first else "deferred") + "_ms_per_step": round(float(other.item()) / args.steps * 1e3, 3)}
     final_loss = float(loss.item())
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
@@ -133,9 +154,11 @@ def main():
         k_time = sum(k_ms) * 1e-3
         achieved = k_flops / k_time / 1e12 if k_time > 0 else 0.0
         traffic = None
-        try:        # HBM bytes per launch from the committed PMC passes (rocprofv3 cannot be driven from inside the timed run)
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-            traffic = tj[dominant]["hbm_bytes_per_launch"] if args.precision == "bf16" and B == 64 else None
+        try:        # HBM bytes per launch from the committed PMC passes (rocprofv3 cannot be driven from inside the timed run);
+            # the file names the hash of the kernel sources it was measured on: a stale figure is reported as null, not repeated
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
+            if tj.get("csrc_sha16") == csrc_hash() and args.precision == "bf16" and B == 64:
+                traffic = tj[dominant]["hbm_bytes_per_launch"]
         except Exception:
             traffic = None
         roof = {"bound": "mfma", "kernel": dominant, "achieved": round(achieved, 2), "peak": PEAK[args.precision], "unit": "TFLOP/s",
@@ -145,7 +168,8 @@ def main():
                 "whole_step_tflops": round(FLOP_PER_SAMPLE * B * args.steps / dt / 1e12, 2),
                 "whole_step_frac": round(FLOP_PER_SAMPLE * B * args.steps / dt / 1e12 / PEAK[args.precision], 4)}
         out = {"metric": "image-text pairs/sec on ViLT VQAv2 fine-tune step", "value": round(value, 2), "unit": "samples/s", "n_gpus": world,
-               "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "median_ms_per_step": round(step_ms[len(step_ms) // 2], 3),
+               "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": args.precision, "data": "synthetic", "hip_graph": use_graph,
                "config": {"workload": "BASELINE.json configs[1]: ViLT sequential-FT VQAv2 step (fwd+BCE+bwd+AdamW), 384x384 image + 40 tokens, "
                                       "12-layer ViLT-B/32 random-init + VQA head", "batch_per_gpu": B, "global_batch": B * world, "seq_len": ws.S,
@@ -153,8 +177,13 @@ def main():
                "roofline": roof}
         if ddp is not None:
             out["replicas_in_sync"] = in_sync
-            out["allreduce_MB_per_step"] = round(ddp.bytes_reduced / 1e6 / (args.steps + args.warmup), 1)
+            out["dp_overlap"] = bool(ddp.overlap)
+            out["dp_payload"] = ddp.compress
+            out["allreduce_MB_per_step"] = round(ddp.bytes_reduced / 1e6 / (args.steps + args.warmup + (args.steps + 2 if dp_ab else 0)), 1)
+            if dp_ab:
+                out["dp_overlap_ab"] = dict(dp_ab, **{("overlap" if ddp.overlap else "deferred") + "_ms_per_step": round(ms, 3)})
         if world == 1 and not args.no_cpu_baseline:
+            out["bf16_vs_ref"] = bf16_vs_reference(dev) if args.precision == "bf16" else None
             out["cpu_baseline"] = cpu_baseline(args.cpu_steps)
         print(json.dumps(out), flush=True)
     if dist.is_initialized():
@@ -162,9 +191,57 @@ def main():
         dist.destroy_process_group()
 
 
+def csrc_hash():
+    """sha256 over the kernel sources: the key profiles/rNN_traffic.json is valid for"""
+    import hashlib
+    d = os.path.join(ROOT, "climb_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def bf16_vs_reference(dev):
+    """CHECKER leg (rank 0, N = 1, after the timed region; the only place besides cpu_baseline that touches oracle/): one step of the
+    timed arithmetic mode on tests/golden/vqa_b64.npz -- the REFERENCE's own outputs for 64 seeded sequences (oracle/gen_golden.py) --
+    and its errors against them (max|d| / max|ref|), plus the share of the 64 rows whose argmax answer equals the reference's."""
+    import numpy as np
+    import torch
+    from oracle import vilt_oracle as vo
+    from climb_amd.modeling import create_continual_learner_map
+    from climb_amd.configs.task_configs import task_configs
+    from climb_amd.configs.model_configs import model_configs
+    z = np.load(os.path.join(ROOT, "tests", "golden", "vqa_b64.npz"))
+    m = dict(kv.split("=", 1) for kv in str(z["meta"][0]).split(";"))
+    tasks, B = m["tasks"].split(","), int(m["B"])
+    model = create_continual_learner_map["vilt"](model_name_or_path="random-init:0", ordered_cl_tasks=tasks, model_config=model_configs["vilt"],
+                                                 task_configs=task_configs, device=dev, precision="bf16")
+    model.load_state_dict(vo.init_params(tasks, int(m["wseed"])), strict=True)
+    model.to(dev)
+    model.train()
+    enc = vo.synthetic_encodings(B, seed=int(m["dseed"]))
+    texts = dict(input_ids=enc["input_ids"], token_type_ids=enc["token_type_ids"], attention_mask=enc["attention_mask"])
+    loss, (pooled, logits), _, _ = model.fused_forward_backward("vqa", enc["pixel_values"], texts, vo.synthetic_vqa_targets(B, seed=int(m["dseed"])))
+
+    def rel(a, b):
+        a, b = a.detach().double().cpu(), torch.as_tensor(np.asarray(b)).double()
+        return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+    G = {n: p.grad.detach().double().cpu() for n, p in model.named_parameters() if p.grad is not None}
+    names = [str(n) for n in z["grad_names"]]
+    norms = np.array([float(G[n].norm()) for n in names])
+    big = z["grad_norms"] > 1e-3 * z["grad_norms"].max()
+    gerr = np.abs(norms - z["grad_norms"])[big] / z["grad_norms"][big]
+    return {"fixture": "tests/golden/vqa_b64.npz (reference train_step, B=64)", "pooled": round(rel(pooled, z["pooled"]), 6),
+            "logits": round(rel(logits, z["logits"]), 6), "loss": round(rel(loss, z["loss"]), 8),
+            "argmax_agreement": float((logits.argmax(-1).cpu().numpy() == z["logits"].argmax(-1)).mean()),
+            "grad_norm_rel_err_median": round(float(np.median(gerr)), 6), "grad_norm_rel_err_max": round(float(gerr.max()), 6)}
+
+
 def cpu_baseline(steps: int):
     """The CPU oracle (oracle/vilt_oracle.py: a plain-PyTorch fp32 port of the reference path, pinned to the reference by
-    tests/golden) timed on this node's host cores: B=2 (BASELINE.json configs[0]) training steps, 1 warm-up excluded."""
+    tests/golden) timed on this node's host cores: B=2 (BASELINE.json configs[0]) training steps, 1 warm-up excluded, and ONE
+    training step at B=64 -- the batch the GPU line is quoted on."""
     import torch
     from oracle import vilt_oracle as vo
     # torch's default intra-op thread count already honours the cgroup / affinity limits of this container
@@ -183,13 +260,21 @@ def cpu_baseline(steps: int):
         times.append(time.perf_counter() - t0)
     times = sorted(times[1:])
     med = times[len(times) // 2]
+    # the benchmark's own batch size: one timed step (a second B=64 step would add ~15 s for no information)
+    B64 = 64
+    enc = vo.synthetic_encodings(B64, seed=7)
+    tgt = vo.synthetic_vqa_targets(B64, seed=7)
+    t0 = time.perf_counter()
+    vo.train_step(P, "vqa", enc, tgt, opt_state=state, lr=1e-4)
+    t64 = time.perf_counter() - t0
     try:
         model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
     except Exception:
         model = "unknown"
-    return {"value": round(B / med, 3), "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{steps} fp32 training steps (fwd+BCE+bwd+AdamW) at batch {B}, 384x384 + 40 tokens, median step {med:.3f}s, 1 warm-up excluded",
-            "cpu": model}
+    return {"value": round(B64 / t64, 3), "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"1 fp32 training step (fwd+BCE+bwd+AdamW) at batch {B64} = the GPU line's batch, 384x384 + 40 tokens, {t64:.2f}s; "
+                      f"and {steps} steps at batch {B} (BASELINE configs[0]), median step {med:.3f}s, 1 warm-up excluded",
+            "value_b2": round(B / med, 3), "cpu": model}
 
 
 if __name__ == "__main__":

@@ -148,6 +148,35 @@ extern "C" int climb_cast_bf16(const float* x, void* y, long n, void* stream) {
   return CLIMB_OK;
 }
 
+// gradient-payload helpers of the data-parallel path: y = scale * float(x) for a bf16 payload coming back from the wire, and an
+// in-place scale for backends without an averaging reduction
+__global__ void uncast_bf16_scale_kernel(const bf16_t* __restrict__ x, float* __restrict__ y, long n, float s) {
+  for (long e = ((long)blockIdx.x * 256 + threadIdx.x) * 4; e < n; e += (long)gridDim.x * 1024) {
+    float4 v = ld4(x + e);
+    st4(y + e, make_float4(v.x * s, v.y * s, v.z * s, v.w * s));
+  }
+}
+extern "C" int climb_uncast_bf16_scale(const void* x, float* y, long n, float scale, void* stream) {
+  if (n <= 0 || n % 4) return CLIMB_EINVAL;
+  long nb = (n / 4 + 255) / 256;
+  hipLaunchKernelGGL(uncast_bf16_scale_kernel, dim3((unsigned)(nb < 16384 ? nb : 16384)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, y, n, scale);
+  LAUNCH_CHECK();
+  return CLIMB_OK;
+}
+__global__ void scale_f32_kernel(float* __restrict__ x, long n, float s) {
+  for (long e = ((long)blockIdx.x * 256 + threadIdx.x) * 4; e < n; e += (long)gridDim.x * 1024) {
+    float4 v = ld4(x + e);
+    st4(x + e, make_float4(v.x * s, v.y * s, v.z * s, v.w * s));
+  }
+}
+extern "C" int climb_scale_f32(float* x, long n, float scale, void* stream) {
+  if (n <= 0 || n % 4) return CLIMB_EINVAL;
+  long nb = (n / 4 + 255) / 256;
+  hipLaunchKernelGGL(scale_f32_kernel, dim3((unsigned)(nb < 16384 ? nb : 16384)), dim3(256), 0, (hipStream_t)stream, x, n, scale);
+  LAUNCH_CHECK();
+  return CLIMB_OK;
+}
+
 // bf16 [R, C] -> [C, R] (weight shadows for the dX GEMMs), 64x64 tiles through LDS
 __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out, int R, int C) {
   __shared__ bf16_t tile[64][66];

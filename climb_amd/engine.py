@@ -475,10 +475,27 @@ class ViltEngine:
             _lib.call("climb_attn_bwd_bf16", qkv, key_bias, dctx, ctx, lse, delta, dqkv, B, S_pad, cfg["heads"], cfg["head_dim"], st)
 
     # ------------------------------------------------------------------ encoder backward
+    def _trainable_runs(self, lo, hi):
+        """maximal runs of TRAINABLE tensors inside the flat range [lo, hi): what a data-parallel reducer has to carry (a frozen base
+        under adapters, or frozen heads, contribute nothing) and what the optimizer may touch"""
+        segs = getattr(self, "_segs", None)
+        if segs is None:
+            segs = self._segs = self.layout.segments()
+        runs = []
+        for name, start, length in segs:
+            if start < lo or start >= hi or not self.requires_grad[name]:
+                continue
+            if runs and runs[-1][1] == start:
+                runs[-1][1] = start + length
+            else:
+                runs.append([start, start + length])
+        return runs
+
     def _ready(self, lo, hi):
-        self.touched.append((lo, hi))
-        if self.grad_ready_hook is not None:
-            self.grad_ready_hook(lo, hi)
+        for a, b in self._trainable_runs(lo, hi):
+            self.touched.append((a, b))
+            if self.grad_ready_hook is not None:
+                self.grad_ready_hook(a, b)
 
     def encoder_backward(self, dpooled: torch.Tensor, first_layer: int = 0, embeddings: bool = True):
         """Accumulates parameter gradients into the flat grad buffer.  `first_layer` / `embeddings` let frozen prefixes

@@ -51,6 +51,8 @@ class FusedAdamW(torch.optim.Optimizer):
     def step(self, closure=None):
         loss = closure() if closure is not None else None
         eng = self._prepare()
+        if self._host.ddp is not None:      # backstop: paths that never ran the encoder backward (frozen encoder + autograd heads)
+            self._host.ddp.finish()
         params = self._host._params
         combos = {}             # (param group, step count) -> kernel group slot
         seg_group = np.full((len(self._seg_names),), -1, dtype=np.int8)

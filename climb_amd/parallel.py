@@ -6,16 +6,27 @@ Why it is shaped like this on MI355X
     many small ones.  The flat gradient buffer is laid out in forward order, so every encoder layer is ONE contiguous
     28 MB fp32 range: the engine reports `(lo, hi)` the moment a layer's weight gradients are final and that range is
     all-reduced in place -- no bucket copy-in/copy-out, no per-tensor calls.
+  * Only TRAINABLE ranges are reported (frozen layers, a frozen base under adapters: nothing on the wire).  Fragments smaller
+    than a bucket that are not contiguous (the 24 adapter blocks of a step: 7 MB in all) are PACKED into one staging buffer and
+    travel as one collective instead of 24 latency-bound ones.
   * The collective is enqueued with `async_op=True`: torch's RCCL process group runs it on its own HIP stream after an
-    event on the compute stream, so layer i's all-reduce rides under layer i-1's backward GEMMs.
+    event on the compute stream, so layer i's all-reduce rides under layer i-1's backward GEMMs.  `CLIMB_AMD_DP_OVERLAP=0`
+    defers every collective to `finish()` (after the backward): the measurement knob for the question DESIGN.md §8 leaves open --
+    a concurrent HBM stream slows the latency-bound GEMM k-loops, so overlap is not automatically a win on this chip.
   * `finish()` makes the compute stream wait for every outstanding collective; only then are the EWC penalty gradient
-    (identical on every rank, so it must NOT be summed) and the fused AdamW enqueued.
+    (identical on every rank, so it must NOT be summed) and the fused AdamW enqueued.  The fused optimizer calls `finish()` itself
+    as a backstop, so paths that never reach the encoder backward (frozen encoder on the reference-style autograd path) are reduced too.
   * ReduceOp.AVG on RCCL; SUM followed by a scale on backends without AVG (gloo, used by the CPU tests).
   * Payload: fp32 (bit-faithful averaging, the parity default) or bf16 (`compress="bf16"`, the default of the bf16 throughput
     mode; SURVEY.md §8(e) "prefer bf16 payload"): the range is cast into a persistent bf16 staging buffer laid out like the
-    gradient buffer, reduced there, and cast back in `finish()`.  Halves the bytes every xGMI link carries (480 -> 240 MB per
-    step) for two extra streaming passes over the gradients; the rounding (2^-9 relative per element, once) is below the bf16
-    GEMM noise already in those gradients.  `CLIMB_AMD_DP_COMPRESS=none|bf16` overrides.
+    gradient buffer (`climb_cast_bf16`), reduced there, and cast back with the averaging scale folded in
+    (`climb_uncast_bf16_scale`).  Halves the bytes every xGMI link carries (480 -> 240 MB per step) for two extra streaming
+    passes over the gradients; the rounding (2^-9 relative per element, once) is below the bf16 GEMM noise already in those
+    gradients.  `CLIMB_AMD_DP_COMPRESS=none|bf16` overrides.
+  * Learning-rate / schedule rule under N ranks: the reference's hyper-parameters are tuned for ITS batch size, so a
+    data-parallel run keeps the GLOBAL batch equal to the reference's (`--batch_size` is the global batch, each rank loads
+    batch_size / N), leaves lr, warm-up ratio and steps per epoch unchanged, and averages (not sums) gradients.  `bench.py` instead
+    holds the per-GPU batch fixed (weak scaling, as the driver's contract asks) and says so in its JSON line.
 """
 from __future__ import annotations
 
@@ -25,20 +36,55 @@ from typing import List, Optional, Tuple
 import torch
 import torch.distributed as dist
 
+from . import _lib
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _cast_to_bf16(dst: torch.Tensor, src: torch.Tensor):
+    if src.is_cuda:
+        _lib.call("climb_cast_bf16", src, dst, src.numel(), _stream())
+    else:                      # CPU tensors exist only in the gloo tests of this module
+        dst.copy_(src)
+
+
+def _uncast_scaled(dst: torch.Tensor, src: torch.Tensor, scale: float):
+    if src.is_cuda:
+        _lib.call("climb_uncast_bf16_scale", src, dst, src.numel(), scale, _stream())
+    else:
+        dst.copy_(src)
+        if scale != 1.0:
+            dst.mul_(scale)
+
+
+def _scale(x: torch.Tensor, scale: float):
+    if scale == 1.0:
+        return
+    if x.is_cuda:
+        _lib.call("climb_scale_f32", x, x.numel(), scale, _stream())
+    else:
+        x.mul_(scale)
+
 
 class GradientAllReducer:
     def __init__(self, model=None, process_group=None, min_bucket_elems: int = 4 * 1024 * 1024, broadcast: bool = True,
-                 compress: Optional[str] = None):
+                 compress: Optional[str] = None, overlap: Optional[bool] = None):
         self.pg = process_group
         self.compress = compress            # None = decide at attach() from the engine's precision
-        self._stage = None
+        self._stage = None                  # bf16 payload staging, laid out like the gradient buffer
+        self._pack = None                   # packed payload of non-contiguous small fragments (payload dtype)
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.min_bucket = min_bucket_elems
         self.eng = None
-        self._works: List[Tuple[object, int, int]] = []
-        self._pending: Optional[Tuple[int, int]] = None
+        self.overlap = (os.environ.get("CLIMB_AMD_DP_OVERLAP", "1") != "0") if overlap is None else bool(overlap)
+        self._works: List[Tuple[object, List[Tuple[int, int]], Optional[torch.Tensor]]] = []
+        self._small: List[Tuple[int, int]] = []
+        self._deferred: List[Tuple[int, int]] = []
         self._avg = dist.is_initialized() and dist.get_backend(process_group) == "nccl"
         self.bytes_reduced = 0
+        self.collectives = 0
         if model is not None:
             host = model._host
             host.ddp = self
@@ -57,55 +103,116 @@ class GradientAllReducer:
         if mode not in ("none", "bf16"):
             raise ValueError(f"unknown gradient compression {mode!r}")
         self.compress = mode
-        self._stage = None
+        self._stage = self._pack = None
 
     def begin(self):
         self._works.clear()
-        self._pending = None
+        self._small.clear()
+        self._deferred.clear()
+
+    # ------------------------------------------------------------------ collectives
+    def _reduce(self, payload: torch.Tensor, ranges, packed):
+        op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
+        work = dist.all_reduce(payload, op=op, group=self.pg, async_op=True)
+        self._works.append((work, ranges, packed))
+        self.bytes_reduced += payload.numel() * payload.element_size()
+        self.collectives += 1
 
     def _launch(self, lo: int, hi: int):
+        """one contiguous range, reduced in place (fp32) or through the like-shaped bf16 staging buffer"""
         if self.world == 1:
             return
         chunk = self.eng.grad[lo:hi]
         if self.compress == "bf16":
             if self._stage is None:
                 self._stage = torch.empty(self.eng.grad.numel(), dtype=torch.bfloat16, device=self.eng.grad.device)
-            stage = self._stage[lo:hi]
-            stage.copy_(chunk)                 # fp32 -> bf16 (round to nearest even) on the compute stream
-            chunk = stage
-        op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
-        work = dist.all_reduce(chunk, op=op, group=self.pg, async_op=True)
-        self._works.append((work, lo, hi))
-        self.bytes_reduced += (hi - lo) * chunk.element_size()
+            _cast_to_bf16(self._stage[lo:hi], chunk)
+            chunk = self._stage[lo:hi]
+        self._reduce(chunk, [(lo, hi)], None)
+
+    def _launch_packed(self, ranges: List[Tuple[int, int]]):
+        """several non-contiguous small ranges as ONE collective over a packed copy"""
+        if self.world == 1:
+            return
+        n = sum(hi - lo for lo, hi in ranges)
+        dt = torch.bfloat16 if self.compress == "bf16" else torch.float32
+        if self._pack is None or self._pack.numel() < n or self._pack.dtype != dt:
+            self._pack = torch.empty(max(n, self.min_bucket), dtype=dt, device=self.eng.grad.device)
+        buf = self._pack[:n]
+        at = 0
+        for lo, hi in ranges:
+            if dt == torch.bfloat16:
+                _cast_to_bf16(buf[at:at + hi - lo], self.eng.grad[lo:hi])
+            else:
+                buf[at:at + hi - lo].copy_(self.eng.grad[lo:hi])
+            at += hi - lo
+        self._reduce(buf, list(ranges), buf)
+        self._pack = None            # in flight until finish(); the next packed bucket of this step gets its own buffer
+
+    def _flush_small(self):
+        if not self._small:
+            return
+        merged: List[List[int]] = []
+        for lo, hi in sorted(self._small):
+            if merged and merged[-1][1] == lo:
+                merged[-1][1] = hi
+            else:
+                merged.append([lo, hi])
+        self._small.clear()
+        if len(merged) == 1:
+            self._launch(merged[0][0], merged[0][1])
+        else:
+            self._launch_packed([(a, b) for a, b in merged])
 
     def on_ready(self, lo: int, hi: int):
-        """Ranges arrive in backward order (head, final norm + pooler, layer 11 ... layer 0, embeddings).  Adjacent small
-        ranges are merged until a bucket is worth a collective."""
-        if self._pending is not None:
-            plo, phi = self._pending
-            if hi == plo:                      # contiguous with the pending range (walking down the buffer)
-                lo, hi = lo, phi
-            elif lo == phi:
-                lo, hi = plo, hi
-            else:
-                self._launch(plo, phi)
-            self._pending = None
+        """Ranges arrive in backward order (head, final norm + pooler, layer 11 ... layer 0, embeddings; only trainable sub-ranges).
+        A range worth a collective goes at once, in place; smaller ones wait for neighbours and go together."""
+        if hi <= lo:
+            return
+        if not self.overlap:
+            self._deferred.append((lo, hi))
+            return
+        self._dispatch(lo, hi)
+
+    def _dispatch(self, lo: int, hi: int):
         if hi - lo >= self.min_bucket:
+            # a pending small neighbour that touches this range rides with it
+            for k, (slo, shi) in enumerate(self._small):
+                if shi == lo or slo == hi:
+                    lo, hi = min(lo, slo), max(hi, shi)
+                    self._small.pop(k)
+                    break
             self._launch(lo, hi)
         else:
-            self._pending = (lo, hi)
+            self._small.append((lo, hi))
+            if sum(b - a for a, b in self._small) >= self.min_bucket:
+                self._flush_small()
 
     def finish(self):
-        """Block the compute stream on every outstanding collective (no host sync on RCCL)."""
-        if self._pending is not None:
-            self._launch(*self._pending)
-            self._pending = None
-        for work, lo, hi in self._works:
+        """Block the compute stream on every outstanding collective (no host sync on RCCL) and put the averaged gradients back."""
+        for lo, hi in self._deferred:
+            self._dispatch(lo, hi)
+        self._deferred.clear()
+        self._flush_small()
+        scale = 1.0 if (self._avg or self.world == 1) else 1.0 / self.world
+        for work, ranges, packed in self._works:
             work.wait()
-            if self.compress == "bf16":
-                self.eng.grad[lo:hi].copy_(self._stage[lo:hi])
-            if not self._avg and self.world > 1:
-                self.eng.grad[lo:hi].div_(self.world)
+            if packed is not None:
+                at = 0
+                for lo, hi in ranges:
+                    src = packed[at:at + hi - lo]
+                    if packed.dtype == torch.bfloat16:
+                        _uncast_scaled(self.eng.grad[lo:hi], src, scale)
+                    else:
+                        self.eng.grad[lo:hi].copy_(src)
+                        _scale(self.eng.grad[lo:hi], scale)
+                    at += hi - lo
+            else:
+                lo, hi = ranges[0]
+                if self.compress == "bf16":
+                    _uncast_scaled(self.eng.grad[lo:hi], self._stage[lo:hi], scale)
+                else:
+                    _scale(self.eng.grad[lo:hi], scale)
         self._works.clear()
 
     def replicas_in_sync(self) -> bool:

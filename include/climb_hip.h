@@ -105,6 +105,9 @@ int climb_ewc_workspace_floats(void);
 int climb_fisher_accum(float* fisher, const float* grad, long n, void* stream);
 int climb_scale(float* x, long n, float s, void* stream);
 int climb_cast_bf16(const float* x, void* y, long n, void* stream);
+/* data-parallel payload helpers: y[n] (f32) = scale * x[n] (bf16), and x[n] *= scale in place; n % 4 == 0, 16-byte aligned */
+int climb_uncast_bf16_scale(const void* x, float* y, long n, float scale, void* stream);
+int climb_scale_f32(float* x, long n, float scale, void* stream);
 int climb_transpose_bf16(const void* in, void* out, int R, int C, void* stream);
 /* n transposes in one launch: table[i] = {src_off, dst_off, R, C} in elements (int64, device); grid = (tiles_per_matrix, n) */
 int climb_transpose_bf16_batched(const void* src, void* dst, const long* table, int n, int tiles_per_matrix, void* stream);

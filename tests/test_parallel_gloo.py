@@ -109,10 +109,79 @@ def test_bucket_merging_single_process():
     red.begin()
     for lo, hi in eng.backward_order("vqa"):
         red.on_ready(lo, hi)
-    if red._pending:
-        launched.append(red._pending)
+    assert not red._small, "nothing small is left waiting: the final norm + pooler rode with layer 11"
     assert sum(hi - lo for lo, hi in launched) == layout.total
     assert len(launched) == 1 + 12 + 1                       # head | layer 11 (+ final norm/pooler) .. layer 0 | embeddings
     assert all(hi - lo >= red.min_bucket for lo, hi in launched)
     srt = sorted(launched)
     assert all(a[1] == b[0] for a, b in zip(srt, srt[1:])), "buckets tile the buffer without gaps or overlap"
+
+
+def _payload_worker(rank, world, port, q, scenario, compress, overlap):
+    """Frozen-prefix / adapter-only steps: only trainable sub-ranges are reported, fragments travel packed."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from climb_amd.engine import ViltEngine
+        from climb_amd.parallel import GradientAllReducer
+        adapters = {"vqa": 48} if scenario == "adapter" else {}
+        layout = FlatLayout(["vqa"], TASK_ARITH, adapters=adapters)
+        eng = ViltEngine(layout, torch.device("cpu"), "fp32")           # host bookkeeping only: no kernels are launched
+        g = torch.Generator().manual_seed(100 + rank)
+        eng.grad = torch.randn(layout.total, generator=g)
+        eng.flat = torch.zeros(layout.total)
+        mine = eng.grad.clone()
+        if scenario == "adapter":           # base frozen, adapter + head trainable
+            first = 0
+            for n in layout.shapes:
+                eng.requires_grad[n] = (".adapters.vqa." in n) or n.startswith("task_layer.")
+        else:                               # bottom 9 layers + embeddings frozen
+            first = 9
+            for n in layout.shapes:
+                eng.requires_grad[n] = not (n.startswith("vilt_encoder.vilt.embeddings") or any(f".layer.{i}." in n for i in range(9)))
+        red = GradientAllReducer(None, compress=compress, overlap=overlap)
+        red.attach(eng)
+        red.begin()
+        eng._ready(*layout.head_range["vqa"])                          # the order encoder_backward reports ranges in
+        eng._ready(*layout.top_range)
+        for i in range(layout.cfg["layers"] - 1, first - 1, -1):
+            eng._ready(*layout.layer_range[i])
+        red.finish()
+        trainable = torch.zeros(layout.total, dtype=torch.bool)
+        for n, start, length in layout.segments():
+            if eng.requires_grad[n] and (scenario == "adapter" or True):
+                trainable[start:start + length] = True
+        grads = [torch.randn(layout.total, generator=torch.Generator().manual_seed(100 + r)) for r in range(world)]
+        expect = (sum(x.bfloat16() for x in grads).float() if compress == "bf16" else sum(grads)) / world
+        tol = 2e-2 if compress == "bf16" else 1e-6
+        ok_avg = torch.allclose(eng.grad[trainable], expect[trainable], rtol=0, atol=tol)
+        ok_frozen = torch.equal(eng.grad[~trainable], mine[~trainable])
+        q.put((rank, ok_avg, ok_frozen, red.bytes_reduced, int(trainable.sum()), red.collectives))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("scenario,compress,overlap", [("adapter", "none", True), ("adapter", "bf16", False), ("bottom9", "bf16", True), ("bottom9", "none", False)])
+def test_payload_shrinks_to_trainable_ranges_world2(scenario, compress, overlap):
+    """with a frozen base (adapters) or a frozen prefix (freeze_bottom_k_layers) only the trainable ranges cross the
+    wire -- 1.8 M adapter + 6 M head parameters instead of 120 M -- and the 24 adapter fragments of a step travel as a handful of
+    packed collectives, with and without overlap."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_payload_worker, args=(r, world, port, q, scenario, compress, overlap)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok_avg, ok_frozen, nbytes, ntrain, ncoll in res:
+        assert ok_avg and ok_frozen, (rank, ok_avg, ok_frozen)
+        assert nbytes == (2 if compress == "bf16" else 4) * ntrain, "exactly the trainable elements are reduced, once"
+        if scenario == "adapter":
+            assert ntrain < 9_000_000 and ncoll <= 3, (ntrain, ncoll)          # head in place + the adapter fragments packed
+        else:
+            assert 25_000_000 < ntrain < 40_000_000 and ncoll <= 5, (ntrain, ncoll)
