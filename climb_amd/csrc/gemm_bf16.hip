@@ -330,6 +330,7 @@ static int g_nt_waves = 8;     // measured on MI355X (r01): 8 waves 537 TF vs 4 
 static int g_nt_96 = 1;        // 96x192 tiles when they tile the problem into full rounds
 static int g_nt_192 = 1;       // 192x192 deep-prefetch tiles for large problems with N % 192 == 0
 static int g_nt_256 = 1;       // persistent 256-row tiles (gemm_bf16_ntp.hip): 0 never, 1 auto (large problems), 2 / 3 force 256 / 192 columns
+static int g_tn_p = 1;         // weight gradients on the persistent 256-row-tile kernel (gemm_bf16_tnp.hip) when the shape allows
 static int g_nt_small_m = 1;   // 64x128 tiles for shapes whose 128x128 tiling quantises badly on 512 workgroup slots
 extern "C" int climb_set_option(int key, int value) {
   if (key == 1 && (value == 4 || value == 8)) { g_nt_waves = value; return CLIMB_OK; }
@@ -338,6 +339,7 @@ extern "C" int climb_set_option(int key, int value) {
   if (key == 5) { g_nt_192 = value; return CLIMB_OK; }
   if (key == 7 && value >= 0 && value <= 3) { g_nt_256 = value; return CLIMB_OK; }
   if (key == 8) { climb_nt256_set_probe(value != 0); return CLIMB_OK; }
+  if (key == 10 && (value == 0 || value == 1)) { g_tn_p = value; return CLIMB_OK; }
   if (key == 9 && value >= 0) { climb_nt256_set_grid(value); return CLIMB_OK; }
   if (key == 6 && (value == 4 || value == 8)) { g_tn_waves = value; return CLIMB_OK; }
   if (key == 3 && value > 0) { g_tn_target = value; return CLIMB_OK; }
@@ -608,12 +610,25 @@ __global__ __launch_bounds__(512 / NI) void gemm_bf16_tn_kernel(const bf16_t* __
 }
 
 
+// Registers (ptr, bytes) as the scratch the persistent weight-gradient kernel writes its split partial sums to (NULL / 0 unregisters).
+// The buffer is the caller's, must outlive every later climb_gemm_bf16_tn launch that uses it, and is used in stream order only.
+extern "C" int climb_set_tn_workspace(void* ptr, long bytes) {
+  if (bytes < 0 || (((uintptr_t)ptr) & 15)) return CLIMB_EINVAL;
+  climb_tnp_set_workspace(ptr, bytes);
+  return CLIMB_OK;
+}
+
 // C[N,K] (fp32, ldc) += A[M,N]^T B[M,K]; A, B bf16 row-major (lda, ldb).  N % 8 == 0, K % 8 == 0.
 // dbias (optional, fp32 [N]) += column sums of A  (the bias gradient of the same linear layer, fused)
 extern "C" int climb_gemm_bf16_tn(const void* A, long lda, const void* B, long ldb, float* C, long ldc, int M, int N, int K, float* dbias,
                                   void* stream) {
   if (M <= 0 || N <= 0 || K <= 0 || (N % 8) || (K % 8) || (lda % 8) || (ldb % 8) || !al16p(A) || !al16p(B)) return CLIMB_EINVAL;
   hipStream_t st = (hipStream_t)stream;
+  if (g_tn_p == 1 && (long)N * K >= 256L * 192 && M >= 2048 && (((uintptr_t)C) & 3) == 0) {
+    int rc = climb_tnp_launch((const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc, M, N, K, dbias, st);
+    if (rc == CLIMB_OK) { LAUNCH_CHECK(); return CLIMB_OK; }
+    if (rc != CLIMB_EUNSUPPORTED) return rc;
+  }
   const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
   // small outputs (768 x 768: 36 tiles) are atomics-bound: fewer, longer splits (measured 37 vs 44 us at 360 vs 504 workgroups)
   // ... and sliver outputs (the adapters' 48 x 768 / 768 x 48: 6 tiles) want ~96 workgroups (measured 29 / 16 us against 58 / 22 at 384)

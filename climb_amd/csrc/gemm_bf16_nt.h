@@ -182,3 +182,7 @@ int climb_nt256_launch(int bn, const bf16_t* A, long lda, const bf16_t* B, long 
                        int epi, const void* aux, long ldaux, bf16_t* aux_out, long ldauxo, const bf16_t* aux2, long ldaux2, hipStream_t st);
 void climb_nt256_set_probe(int v);      // measurement aid: 1 = run the k-loop only (no epilogue, nothing stored)
 void climb_nt256_set_grid(int v);       // workgroups launched at most (0 = one per tile; default 256 = persistent, one per CU)
+// gemm_bf16_tnp.hip: the weight-gradient GEMM C[N,K] += A[M,N]^T B[M,K] on the same persistent phase structure; CLIMB_EUNSUPPORTED for
+// shapes it does not take (the caller then uses the 128 x 128 kernel)
+int climb_tnp_launch(const bf16_t* A, long lda, const bf16_t* B, long ldb, float* C, long ldc, int M, int N, int K, float* dbias, hipStream_t st);
+void climb_tnp_set_workspace(void* ptr, long bytes);

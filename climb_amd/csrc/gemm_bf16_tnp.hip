@@ -1,0 +1,325 @@
+// bf16 TN GEMM (weight gradients): C[N,K] += A[M,N]^T . B[M,K], reduction over the token dimension M, on the phase structure of
+// gemm_bf16_ntp.hip: 256 (n) x 64 NI (k) output tiles, one workgroup of 8 waves per CU, NI phases per 64-token reduction tile with
+// the staging schedule and the compile-time-derived vmcnt counts of gemm_bf16_phase.h.
+//
+// What differs from the NT kernel is only how the operands sit in memory: both are token-major, so an LDS image is [64 tokens][cols]
+// and the MFMA fragments (output index x 8 consecutive tokens) are gathered with ds_read_b64_tr_b16, the gfx950 LDS transpose read
+// (two reads per fragment), exactly as in the 128 x 128 weight-gradient kernel of gemm_bf16.hip.
+//   A image  [64 tokens][256 n]  512-B rows = 32 KB; staging units A0 / A1 = tokens 0..31 / 32..63 (2 DMA instructions per lane each);
+//            16-B chunks XOR-swizzled by (token & 3) << 2: the 4 token rows a transpose read touches sit in 4 different bank quarters.
+//   B unit p [64 tokens][2 x 32 k] 128-B rows = 8 KB: the columns of k-block p of both wave columns (1 DMA instruction per lane);
+//            chunks XOR-swizzled by ((token >> 1) & 1) << 2 for the same reason at this pitch.
+// Waves 4 (n) x 2 (k); wave (wr, wc) owns n rows wr*64..+64 (2 n-blocks) x k columns wc*32 NI..+32 NI (NI k-blocks); phase p multiplies
+// the A fragments of the whole reduction tile (read in phase 0, kept) with the fragments of k-block p.
+//
+// Work decomposition: (output tile, token-range split) pairs, splits chosen so that the pairs fill ONE round of 256 CUs; the partial
+// sums of a tile's splits meet in C through fp32 atomics (global_atomic_add_f32), as before -- but 7 - 9 splits of 256-wide tiles move
+// half the atomic traffic of the 12 - 18 splits the 128 x 128 kernel needs.
+// The bias gradient db[n] = sum_m A[m][n] rides along on the VALU: the A fragments a lane holds ARE 8 tokens of one column n, so the
+// lanes of wave column 0 add them up during the reduction tiles dealt to their workgroup (round-robin over the k-tiles of an n-row
+// of tiles, so every workgroup carries the same small share).
+#include "gemm_bf16_phase.h"
+
+__device__ __forceinline__ int tnp_aswz(int row) { return (row & 3) << 2; }
+__device__ __forceinline__ int tnp_bswz(int row) { return ((row >> 1) & 1) << 2; }
+
+template <int NI>
+struct TnpStage {
+  unsigned a_off[4];       // per lane: byte offset (from A + first token row of the split) of its 4 DMA sources of the A image
+  unsigned b_off[NI];      // per lane: byte offset (from B + first token row of the split) of its DMA source of B unit p
+  unsigned wid;
+};
+
+template <int NI, int P, bool D1, bool D2, int K_ = 0>
+__device__ __forceinline__ void tnp_issue(const TnpStage<NI>& sg, const unsigned char* __restrict__ A, long a_tile, const unsigned char* __restrict__ B,
+                                          long b_tile, unsigned char* __restrict__ smem, int T) {
+  if constexpr (K_ < NTP_MAXI) {
+    constexpr int BUF = NTP_A_BYTES + NI * NTP_B_UNIT;
+    constexpr int e = ntp_sched(NI, P, K_);
+    if constexpr (e >= 0) {
+      constexpr int unit = e / 4, d = e % 4;
+      if constexpr ((d == 1 && D1) || (d == 2 && D2)) {
+        const int t = T + d;
+        unsigned char* buf = smem + (t & 1) * BUF;
+        if constexpr (unit < 2) {
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)(A + (long)t * a_tile + sg.a_off[unit * 2 + i]),
+                                             (lds_void_t*)(buf + unit * (NTP_A_BYTES / 2) + (sg.wid * 2 + i) * 1024), 16, 0, 0);
+        } else {
+          __builtin_amdgcn_global_load_lds((gbl_void_t*)(B + (long)t * b_tile + sg.b_off[unit - 2]),
+                                           (lds_void_t*)(buf + NTP_A_BYTES + (unit - 2) * NTP_B_UNIT + sg.wid * 1024), 16, 0, 0);
+        }
+      }
+    }
+    tnp_issue<NI, P, D1, D2, K_ + 1>(sg, A, a_tile, B, b_tile, smem, T);
+  }
+}
+
+// 8-token MFMA operand: two transpose reads (token rows r..r+3 and r+4..r+7 of the lane's 16-lane block)
+template <int PITCH>
+__device__ __forceinline__ bf16x8 tnp_frag(const unsigned char* __restrict__ p) {
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
+  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 4 * PITCH));
+  union { s16x4 h[2]; bf16x8 b; } c;
+  c.h[0] = lo;
+  c.h[1] = hi;
+  return c.b;
+}
+__device__ __forceinline__ float tnp_sum8(bf16x8 v) {
+  union { bf16x8 b; unsigned u[4]; } c;
+  c.b = v;
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) s += __uint_as_float(c.u[i] << 16) + __uint_as_float(c.u[i] & 0xffff0000u);
+  return s;
+}
+
+template <int NI, int P, bool D1, bool D2, int W>
+__device__ __forceinline__ void tnp_phase(f32x16 (&acc)[NI][2], bf16x8 (&a)[2][4], float (&bsum)[2], bool bias_tile, const TnpStage<NI>& sg,
+                                          const unsigned char* __restrict__ A, long a_tile, const unsigned char* __restrict__ B, long b_tile,
+                                          unsigned char* __restrict__ smem, int T, const unsigned (&aoff)[2], unsigned boff) {
+  constexpr int BUF = NTP_A_BYTES + NI * NTP_B_UNIT;
+  const unsigned char* buf = smem + (T & 1) * BUF;
+  bf16x8 b[4];
+#pragma unroll
+  for (int ms = 0; ms < 4; ++ms) b[ms] = tnp_frag<128>(buf + NTP_A_BYTES + P * NTP_B_UNIT + ms * (16 * 128) + boff);
+  if constexpr (P == 0) {
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int ms = 0; ms < 4; ++ms) a[j][ms] = tnp_frag<512>(buf + ms * (16 * 512) + aoff[j]);
+  }
+  tnp_issue<NI, P, D1, D2>(sg, A, a_tile, B, b_tile, smem, T);
+  if constexpr (W >= 0) wait_vmcnt<(W < 0 ? 0 : W)>();
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+  for (int ms = 0; ms < 4; ++ms)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[P][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[j][ms], b[ms], acc[P][j], 0, 0, 0);
+  __builtin_amdgcn_s_setprio(0);
+  if constexpr (P == 1) {          // bias share of this reduction tile (VALU, beside the other wave group's MFMAs)
+    if (bias_tile) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int ms = 0; ms < 4; ++ms) bsum[j] += tnp_sum8(a[j][ms]);
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int NI, int MODE, int P = 0>
+__device__ __forceinline__ void tnp_ktile(f32x16 (&acc)[NI][2], bf16x8 (&a)[2][4], float (&bsum)[2], bool bias_tile, const TnpStage<NI>& sg,
+                                          const unsigned char* __restrict__ A, long a_tile, const unsigned char* __restrict__ B, long b_tile,
+                                          unsigned char* __restrict__ smem, int T, const unsigned (&aoff)[2], unsigned boff) {
+  if constexpr (P < NI) {
+    constexpr int W = ntp_wait(NI, 6, MODE == 0 ? 2 : (MODE == 1 ? 4 : 5), P);
+    tnp_phase<NI, P, MODE <= 1, MODE == 0, W>(acc, a, bsum, bias_tile, sg, A, a_tile, B, b_tile, smem, T, aoff, boff);
+    tnp_ktile<NI, MODE, P + 1>(acc, a, bsum, bias_tile, sg, A, a_tile, B, b_tile, smem, T, aoff, boff);
+  }
+}
+template <int NI, int P = 0>
+__device__ __forceinline__ void tnp_prologue(const TnpStage<NI>& sg, const unsigned char* __restrict__ A, long a_tile, const unsigned char* __restrict__ B,
+                                             long b_tile, unsigned char* __restrict__ smem) {
+  if constexpr (P < NI) {
+    tnp_issue<NI, P, false, true>(sg, A, a_tile, B, b_tile, smem, -2);
+    tnp_prologue<NI, P + 1>(sg, A, a_tile, B, b_tile, smem);
+  } else if constexpr (P < 2 * NI) {
+    tnp_issue<NI, P - NI, true, true>(sg, A, a_tile, B, b_tile, smem, -1);
+    tnp_prologue<NI, P + 1>(sg, A, a_tile, B, b_tile, smem);
+  }
+}
+
+// grid: min(tiles * splits, 256 * k) workgroups walking (tile, split) pairs.  M % 64 == 0, rows_per_split % 64 == 0, every split >= 128 rows.
+template <int NI>
+__global__ __launch_bounds__(512) void gemm_bf16_tnp_kernel(const bf16_t* __restrict__ Ag, long lda, const bf16_t* __restrict__ Bg, long ldb,
+                                                            float* __restrict__ C, long ldc, int M, int N, int K, int rows_per_split, int splits,
+                                                            float* __restrict__ dbias, float* __restrict__ slab) {
+  constexpr int BK_ = 64 * NI;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wid >> 1, wc = wid & 1, grp = wid >> 2, half = lane >> 5, l31 = lane & 31;
+  const int nbn = (N + NTP_BM - 1) / NTP_BM, nbk = (K + BK_ - 1) / BK_, tiles = nbn * nbk, nwork = tiles * splits;
+  // transpose-read lane geometry: 16-lane block g16 reads token rows (g16>>1)*8 + (i>>2) [+4], columns (g16&1)*16 + 4*(i&3) .. +3
+  const int g16 = lane >> 4, i16 = lane & 15, trow = (g16 >> 1) * 8 + (i16 >> 2), tcol = (g16 & 1) * 16 + 4 * (i16 & 3);
+  unsigned aoff[2], boff;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int col = wr * 64 + j * 32 + tcol;
+    aoff[j] = trow * 512 + (((col >> 3) ^ tnp_aswz(trow)) << 4) + (col & 7) * 2;
+  }
+  {
+    const int col = wc * 32 + tcol;
+    boff = trow * 128 + (((col >> 3) ^ tnp_bswz(trow)) << 4) + (col & 7) * 2;
+  }
+  const long a_tile = 64 * lda * 2, b_tile = 64 * ldb * 2;          // bytes from one 64-token reduction tile to the next
+  for (int id = blockIdx.x; id < nwork; id += gridDim.x) {
+    // XCD-contiguous order: the workgroups an XCD runs together share a token range (split), so its L2 holds each dY / X panel once
+    int bid;
+    {
+      const int q = nwork / 8, rr = nwork % 8, xcd = id % 8, idx = id / 8;
+      bid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + idx;
+    }
+    const int split = bid / tiles, tile = bid - split * tiles;
+    const int tn = nbn > nbk ? tile / nbk : tile % nbn, tk = nbn > nbk ? tile % nbk : tile / nbn;
+    const int n0 = tn * NTP_BM, k0 = tk * BK_;
+    const int mbeg = split * rows_per_split, mend = min(M, mbeg + rows_per_split);
+    const int nk = (mend - mbeg) / 64;                                 // >= 2 (launcher)
+    const unsigned char* A = reinterpret_cast<const unsigned char*>(Ag) + (long)mbeg * lda * 2;
+    const unsigned char* B = reinterpret_cast<const unsigned char*>(Bg) + (long)mbeg * ldb * 2;
+    TnpStage<NI> sg;
+    sg.wid = wid;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int slot = (wid * 2 + i) * 64 + lane, r = u * 32 + (slot >> 5), c = (slot & 31) ^ tnp_aswz(r);
+        int col = n0 + c * 8;
+        col = col < N ? col : N - 8;                                   // clamped columns are computed but never stored
+        sg.a_off[u * 2 + i] = (unsigned)(((long)r * lda + col) * 2);
+      }
+#pragma unroll
+    for (int p = 0; p < NI; ++p) {
+      const int slot = wid * 64 + lane, r = slot >> 3, c = (slot & 7) ^ tnp_bswz(r);
+      int col = k0 + (c >> 2) * (32 * NI) + p * 32 + (c & 3) * 8;
+      col = col < K ? col : K - 8;
+      sg.b_off[p] = (unsigned)(((long)r * ldb + col) * 2);
+    }
+    f32x16 acc[NI][2];   // [k block][n block]
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    float bsum[2] = {0.f, 0.f};
+    const bool do_bias = dbias != nullptr && wc == 0;
+    bf16x8 a[2][4];
+    tnp_prologue<NI>(sg, A, a_tile, B, b_tile, smem);
+    wait_vmcnt<ntp_wait(NI, 6, -1, NI - 1)>();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    int T = 0;
+    for (; T + 2 < nk; ++T) tnp_ktile<NI, 0>(acc, a, bsum, do_bias && (T % nbk) == tk, sg, A, a_tile, B, b_tile, smem, T, aoff, boff);
+    tnp_ktile<NI, 1>(acc, a, bsum, do_bias && (T % nbk) == tk, sg, A, a_tile, B, b_tile, smem, T, aoff, boff);
+    tnp_ktile<NI, 2>(acc, a, bsum, do_bias && ((T + 1) % nbk) == tk, sg, A, a_tile, B, b_tile, smem, T + 1, aoff, boff);
+    if (grp == 0) __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // D layout: col = lane & 31 -> k, row = (r & 3) + 8 * (r >> 2) + 4 * half -> n: a wave-instruction adds 2 rows x 32 consecutive floats
+#pragma unroll
+    for (int p = 0; p < NI; ++p)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int k = k0 + wc * (32 * NI) + p * 32 + l31;
+        if (k >= K) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int n = n0 + wr * 64 + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          if (n >= N) continue;
+          if (slab) {                                   // this split's partial sum, plain stores: [split][N][K], reduced by tnp_reduce_kernel
+            slab[((long)split * N + n) * K + k] = acc[p][j][r];
+          } else {
+            float* cp = C + (long)n * ldc + k;
+            if (splits > 1) atomicAdd(cp, acc[p][j][r]);
+            else *cp += acc[p][j][r];
+          }
+        }
+      }
+    if (do_bias) {
+      // a lane summed the tokens 8*(lane>>5) .. +7 of every 16 for column n = lane & 31 of each n-block: fold the two lane halves
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const float s = bsum[j] + __shfl_xor(bsum[j], 32, 64);
+        const int n = n0 + wr * 64 + j * 32 + l31;
+        if (half == 0 && n < N) atomicAdd(dbias + n, s);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();       // the next work item's prologue overwrites the buffers
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// C[n][k] += sum over splits of slab[s][n][k]   (one float4 per thread-iteration; K % 4 == 0)
+__global__ __launch_bounds__(256) void tnp_reduce_kernel(const float* __restrict__ slab, float* __restrict__ C, long ldc, int N, int K, int splits) {
+  const long per = (long)N * K, n4 = per / 4;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const long e = i * 4;
+    const int n = (int)(e / K), k = (int)(e - (long)n * K);
+    float4 a = ld4(C + (long)n * ldc + k);
+    for (int s = 0; s < splits; ++s) {
+      const float4 v = ld4(slab + s * per + e);
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    st4(C + (long)n * ldc + k, a);
+  }
+}
+
+static float* g_tn_ws = nullptr;
+static long g_tn_ws_bytes = 0;
+// Scratch for the split partial sums (the library allocates nothing: the host registers a buffer once; without one, or when a launch
+// needs more than it holds, the partial sums meet in C through fp32 atomics instead -- measured 1.3 TB/s against ~5 TB/s for the slabs).
+void climb_tnp_set_workspace(void* ptr, long bytes) { g_tn_ws = (float*)ptr; g_tn_ws_bytes = ptr ? bytes : 0; }
+
+template <int NI>
+static int tnp_launch_one(int nwg, hipStream_t st, const bf16_t* A, long lda, const bf16_t* B, long ldb, float* C, long ldc, int M, int N, int K, int rows,
+                          int splits, float* dbias) {
+  constexpr int LDS = 2 * (NTP_A_BYTES + NI * NTP_B_UNIT);
+  static bool configured = false;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_tnp_kernel<NI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) return (int)e;
+    configured = true;
+  }
+  float* slab = nullptr;
+  if (splits > 1 && (K % 4) == 0 && (ldc % 4) == 0 && (((uintptr_t)C) & 15) == 0 && (long)splits * N * K * 4 <= g_tn_ws_bytes) slab = g_tn_ws;
+  hipLaunchKernelGGL((gemm_bf16_tnp_kernel<NI>), dim3(nwg), dim3(512), LDS, st, A, lda, B, ldb, C, ldc, M, N, K, rows, splits, dbias, slab);
+  if (slab) {
+    const long n4 = (long)N * K / 4;
+    const int grid = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+    hipLaunchKernelGGL(tnp_reduce_kernel, dim3(grid), dim3(256), 0, st, slab, C, ldc, N, K, splits);
+  }
+  return CLIMB_OK;
+}
+
+// C[N,K] (fp32, ldc) += A[M,N]^T B[M,K]; dbias (optional) += column sums of A.  Returns CLIMB_EUNSUPPORTED for shapes it does not take
+// (the caller falls back to the 128 x 128 kernel): M % 64, N % 8, K % 8, too few tokens per split, operands of 4 GB or more.
+int climb_tnp_launch(const bf16_t* A, long lda, const bf16_t* B, long ldb, float* C, long ldc, int M, int N, int K, float* dbias, hipStream_t st) {
+  if ((M % 64) || (N % 8) || (K % 8) || N < 8 || K < 8) return CLIMB_EUNSUPPORTED;
+  if (((long)M * lda + N) * 2 >= (1L << 32) || ((long)M * ldb + K) * 2 >= (1L << 32)) return CLIMB_EUNSUPPORTED;
+  const int nbn = (N + NTP_BM - 1) / NTP_BM;
+  // k-tile width: the one whose (tiles x splits) fills the 256 CUs better with whole 64-token reduction tiles
+  int best_ni = 0, best_splits = 0, best_rows = 0;
+  double best_cost = 1e30;
+  for (int ni = 3; ni <= 4; ++ni) {
+    const int bk = 64 * ni, tiles = nbn * ((K + bk - 1) / bk);
+    int splits = 256 / tiles;
+    if (splits < 1) splits = 1;
+    const int mt = M / 64;
+    if (splits > mt / 2) splits = mt / 2;                 // at least two reduction tiles per split (the pipeline's minimum)
+    if (splits < 1) continue;
+    const int rows = ((mt + splits - 1) / splits) * 64;
+    splits = (M + rows - 1) / rows;
+    if (M - (splits - 1) * rows < 128) continue;          // ragged last split shorter than two reduction tiles
+    // cost ~ rounds x (reduction tiles per split) x tile width, + the fixed per-work-item cost of fill and atomics
+    const int work = tiles * splits, rounds = (work + 255) / 256;
+    const double cost = rounds * ((double)(rows / 64) + 6.0) * bk * ((double)(((N + 255) / 256) * 256) / N) * ((double)(((K + bk - 1) / bk) * bk) / K);
+    if (cost < best_cost) { best_cost = cost; best_ni = ni; best_splits = splits; best_rows = rows; }
+  }
+  if (best_ni == 0) return CLIMB_EUNSUPPORTED;
+  const int bk = 64 * best_ni, tiles = nbn * ((K + bk - 1) / bk);
+  int nwg = tiles * best_splits;
+  if (nwg > 256) nwg = 256;
+  if (best_ni == 4) return tnp_launch_one<4>(nwg, st, A, lda, B, ldb, C, ldc, M, N, K, best_rows, best_splits, dbias);
+  return tnp_launch_one<3>(nwg, st, A, lda, B, ldb, C, ldc, M, N, K, best_rows, best_splits, dbias);
+}

@@ -31,6 +31,20 @@ def _round_up(x, m):
     return (x + m - 1) // m * m
 
 
+_TN_WS = {}
+
+
+def tn_workspace(device):
+    """Scratch for the weight-gradient kernel's split partial sums (plain stores + one reduce launch instead of fp32 atomics).  The
+    library keeps the registered pointer for the life of the process, so the buffer is a per-device singleton that is never freed
+    (64 MB: covers every ViLT-B weight shape at 12288 tokens); one process drives one GPU."""
+    key = str(torch.device(device))
+    if key not in _TN_WS:
+        _TN_WS[key] = torch.empty(64 * 1024 * 1024 // 4, dtype=torch.float32, device=device)
+    _lib.call("climb_set_tn_workspace", _TN_WS[key], _TN_WS[key].numel() * 4)
+    return _TN_WS[key]
+
+
 class Workspace:
     """Activation + scratch buffers for one (B, T) shape; allocated once, reused every step."""
 
@@ -149,6 +163,8 @@ class ViltEngine:
         _lib.load()
         self.flat = torch.zeros(self.layout.total, dtype=torch.float32, device=self.device)
         self.grad = torch.zeros(self.layout.total, dtype=torch.float32, device=self.device)
+        if self.precision == "bf16":
+            tn_workspace(self.device)
         self._ws.clear()
         self._shadow = None
         self._shadow_version = -1

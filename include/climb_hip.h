@@ -121,6 +121,10 @@ int climb_gemm_bf16_nt(const void* A, long lda, const void* B, long ldb, void* C
 /* weight gradient: C[N,K] (fp32) += A[M,N]^T B[M,K]; reduction over tokens via LDS transpose reads, split over M with fp32 atomics;
  * dbias (optional, fp32 [N]) += column sums of A = the bias gradient of the same layer (one extra MFMA against an all-ones operand) */
 int climb_gemm_bf16_tn(const void* A, long lda, const void* B, long ldb, float* C, long ldc, int M, int N, int K, float* dbias, void* stream);
+/* optional scratch for the split partial sums of climb_gemm_bf16_tn (the library never allocates): with a registered buffer of
+ * >= splits*N*K*4 bytes the partials are written as plain stores and summed by a second launch on the same stream; without one they
+ * are accumulated with fp32 atomics.  64 MB covers every ViLT-B shape at 12288 tokens.  Caller-owned, stream-ordered use. */
+int climb_set_tn_workspace(void* ptr, long bytes);
 /* HF:322-351 in bf16: same contract as the _f32 entry points, qkv/ctx/dctx/dqkv are bf16.  The backward takes the forward's ctx and
  * computes delta itself (its first phase); `delta` [B,heads,S_pad] is scratch it writes */
 int climb_attn_fwd_bf16(const void* qkv, const float* key_bias, void* ctx, float* lse, int B, int S_pad, int heads, int head_dim, void* stream);

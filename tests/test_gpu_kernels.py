@@ -155,6 +155,46 @@ def _attn_ref(qkv, bias, heads):
     return (p @ v).transpose(1, 2).reshape(B, S, H)
 
 
+@pytest.mark.parametrize("M,N,K", [(2048, 768, 768), (2112, 264, 200), (4096, 2304, 768), (12288, 768, 3072), (12288, 3072, 768), (12288, 768, 768)])
+def test_gemm_bf16_tn_persistent_tiles(M, N, K):
+    """The persistent 256-row-tile weight-gradient kernel (option 10 = 1, the default for M >= 2048): against float64 of the same
+    bf16-rounded operands where the host can afford it, and against the 128 x 128 kernel (itself pinned to float64 above) at the
+    benchmark's 12288 tokens; accumulating into a non-zero C, fused bias gradient, ragged last tiles (264 x 200), uneven splits."""
+    from climb_amd import _lib
+    dev = _dev()
+    g = torch.Generator(device=dev).manual_seed(M + 3 * N + K)
+    dY = _bf(torch.randn(M, N, device=dev, generator=g))
+    X = _bf(torch.randn(M, K, device=dev, generator=g))
+    C0 = torch.randn(N, K, device=dev, generator=g)
+    db0 = torch.randn(N, device=dev, generator=g)
+    from climb_amd.engine import tn_workspace
+    out = {}
+    try:
+        for mode in (2, 1, 0):                  # 2: persistent kernel, split partial sums through the registered scratch + reduce launch;
+            _lib.call("climb_set_option", 10, min(mode, 1))      # 1: the same kernel with fp32 atomics (no scratch); 0: the 128 x 128 kernel
+            if mode == 2:
+                tn_workspace(dev)
+            else:
+                _lib.call("climb_set_tn_workspace", None, 0)
+            C, db = C0.clone(), db0.clone()
+            _lib.call("climb_gemm_bf16_tn", dY, N, X, K, C, K, M, N, K, db, _st())
+            out[mode] = (C, db)
+            for _ in range(2):                      # repeat: the counted-vmcnt schedule must give the same answer every time (to atomics' order)
+                C2 = C0.clone()
+                _lib.call("climb_gemm_bf16_tn", dY, N, X, K, C2, K, M, N, K, None, _st())
+                assert _rel(C2, C) < 1e-5
+    finally:
+        _lib.call("climb_set_option", 10, 1)
+        tn_workspace(dev)
+    for mode in (2, 1):
+        assert _rel(out[mode][0], out[0][0]) < 1e-5 and _rel(out[mode][1], out[0][1]) < 1e-5, mode
+    if M * N * K <= 4096 * 2304 * 768:
+        ref = C0.double().cpu() + dY.double().cpu().t() @ X.double().cpu()
+        for mode in (2, 1):
+            assert _rel(out[mode][0], ref) < 1e-5
+            assert _rel(out[mode][1], db0.double().cpu() + dY.double().cpu().sum(0)) < 1e-5
+
+
 @pytest.mark.parametrize("S_pad,valid", [(64, 50), (192, 185), (224, 200), (288, 281)])
 def test_attention_f32_fwd_bwd(S_pad, valid):
     from climb_amd import _lib

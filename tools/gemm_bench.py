@@ -30,6 +30,8 @@ if __name__ == "__main__":
         _lib.call("climb_set_option", 7, int(os.environ["NT256"]))
     if os.environ.get("NT256_GRID") is not None:
         _lib.call("climb_set_option", 9, int(os.environ["NT256_GRID"]))
+    if os.environ.get("TNP") is not None:
+        _lib.call("climb_set_option", 10, int(os.environ["TNP"]))
     if os.environ.get("NT192") is not None:
         _lib.call("climb_set_option", 5, int(os.environ["NT192"]))
     if os.environ.get("TN_WAVES") is not None:
@@ -40,6 +42,9 @@ if __name__ == "__main__":
         _lib.call("climb_set_option", 3, int(os.environ["TN_TARGET"]))
     if os.environ.get("NT_SMALL_M") is not None:
         _lib.call("climb_set_option", 2, int(os.environ["NT_SMALL_M"]))
+    if os.environ.get("TN_WS", "1") != "0":
+        from climb_amd.engine import tn_workspace
+        tn_workspace(dev)
     tot_t = tot_f = 0.0
     for name, N, K, cdt, epi in [("qkv fwd", 2304, 768, 1, 0), ("out fwd +res", 768, 768, 0, 2), ("up fwd gelu", 3072, 768, 1, 1), ("down fwd +res", 768, 3072, 0, 2),
                                  ("du dgelu", 3072, 768, 1, 3), ("dhn", 768, 3072, 1, 0), ("dctx", 768, 768, 1, 0), ("dxn", 768, 2304, 1, 0)]:
