@@ -1,0 +1,187 @@
+"""The frozen BERT text encoder of ViLT-BERT: `BertModel(...).last_hidden_state` as
+REF/modeling/viltbert.py:115-121 (`get_bert_outputs`) computes it -- forward only, no gradient, 2 560 text rows at 64 sequences of 40
+tokens (about a fifth of one ViLT forward) -- on the same HIP kernels as the ViLT encoder, in post-LayerNorm order
+(HFB = transformers/models/bert/modeling_bert.py: embeddings :53-116, self-attention :139-220, add & norm :282-294, :340-352).
+
+`BertParams` holds exactly `BertModel`'s parameters (names, shapes, registration order: its state_dict interchanges with transformers'
+`bert-base-uncased`).  Because the weights are frozen they are PACKED once per weight version into GEMM-ready device buffers: the
+q / k / v matrices of a layer become one [2304, 768] operand (one fused QKV GEMM, as in the ViLT encoder), with bf16 copies in the
+throughput mode.  The reference leaves BERT in train mode (its dropouts perturb the "frozen" features randomly, viltbert.py:121-126);
+this encoder computes the deterministic eval-mode features -- documented in DESIGN.md, pinned by tests/golden/viltbert_vqa_b3.npz."""
+from __future__ import annotations
+
+from collections import OrderedDict
+from typing import Dict, Optional
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+F32, BF16 = 0, 1
+EPI_NONE, EPI_GELU, EPI_RESID = 0, 1, 2
+BERT_CFG = dict(hidden=768, heads=12, head_dim=64, ffn=3072, layers=12, vocab=30522, max_pos=512, type_vocab=2, ln_eps=1e-12)
+
+
+def bert_param_shapes(cfg: dict = BERT_CFG) -> "OrderedDict[str, tuple]":
+    H, Fd = cfg["hidden"], cfg["ffn"]
+    s: "OrderedDict[str, tuple]" = OrderedDict()
+    s["embeddings.word_embeddings.weight"] = (cfg["vocab"], H)
+    s["embeddings.position_embeddings.weight"] = (cfg["max_pos"], H)
+    s["embeddings.token_type_embeddings.weight"] = (cfg["type_vocab"], H)
+    s["embeddings.LayerNorm.weight"] = (H,)
+    s["embeddings.LayerNorm.bias"] = (H,)
+    for i in range(cfg["layers"]):
+        l = f"encoder.layer.{i}."
+        for n in ("query", "key", "value"):
+            s[l + f"attention.self.{n}.weight"] = (H, H)
+            s[l + f"attention.self.{n}.bias"] = (H,)
+        for n, shp in (("attention.output.dense.weight", (H, H)), ("attention.output.dense.bias", (H,)), ("attention.output.LayerNorm.weight", (H,)),
+                       ("attention.output.LayerNorm.bias", (H,)), ("intermediate.dense.weight", (Fd, H)), ("intermediate.dense.bias", (Fd,)),
+                       ("output.dense.weight", (H, Fd)), ("output.dense.bias", (H,)), ("output.LayerNorm.weight", (H,)), ("output.LayerNorm.bias", (H,))):
+            s[l + n] = shp
+    s["pooler.dense.weight"] = (H, H)
+    s["pooler.dense.bias"] = (H,)
+    return s
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+class BertParams(nn.Module):
+    """Stand-in for `transformers.BertModel` holding its parameters (frozen) and running its forward on the HIP kernels."""
+
+    def __init__(self, cfg: dict = BERT_CFG, precision: str = "bf16"):
+        super().__init__()
+        from .modeling.vilt import _build_tree, _Node
+        self.cfg, self.precision = cfg, precision
+        tree = _Node()
+        _build_tree(tree, bert_param_shapes(cfg))
+        for name, child in tree._modules.items():       # embeddings / encoder / pooler directly under this module: keys match BertModel's
+            self.add_module(name, child)
+        for p in self.parameters():
+            p.requires_grad = False
+        self._packed: Optional[Dict[str, torch.Tensor]] = None
+        self._packed_version = None
+        self._ws: Dict[tuple, Dict[str, torch.Tensor]] = {}
+
+    def __deepcopy__(self, memo):
+        new = BertParams(self.cfg, self.precision)
+        new.load_state_dict(self.state_dict())
+        return new.to(next(self.parameters()).device)
+
+    def init_like_hf(self, seed: Optional[int] = None):
+        gen = torch.Generator().manual_seed(seed) if seed is not None else None
+        with torch.no_grad():
+            for n, p in self.named_parameters():
+                if n.endswith(".bias"):
+                    p.zero_()
+                elif n.endswith("LayerNorm.weight"):
+                    p.fill_(1.0)
+                else:
+                    p.copy_(torch.empty(p.shape).normal_(0.0, 0.02, generator=gen))
+
+    # ------------------------------------------------------------------ packed operands
+    def _pack(self, dev):
+        ver = sum(p._version for p in self.parameters())
+        if self._packed is not None and self._packed_version == ver and self._packed["word"].device == dev:
+            return self._packed
+        sd = {n: p.detach().to(dev, torch.float32) for n, p in self.named_parameters()}
+        L = self.cfg["layers"]
+        pk: Dict[str, torch.Tensor] = {}
+        e = "embeddings."
+        pk["word"], pk["pos"], pk["type"] = sd[e + "word_embeddings.weight"].contiguous(), sd[e + "position_embeddings.weight"].contiguous(), sd[e + "token_type_embeddings.weight"].contiguous()
+        pk["eln_w"], pk["eln_b"] = sd[e + "LayerNorm.weight"].contiguous(), sd[e + "LayerNorm.bias"].contiguous()
+        pk["zero_h"] = torch.zeros(self.cfg["hidden"], dtype=torch.float32, device=dev)
+
+        def stack(fn):
+            return torch.stack([fn(f"encoder.layer.{i}.") for i in range(L)]).contiguous()
+        pk["wqkv"] = stack(lambda l: torch.cat([sd[l + f"attention.self.{n}.weight"] for n in ("query", "key", "value")], 0))
+        pk["bqkv"] = stack(lambda l: torch.cat([sd[l + f"attention.self.{n}.bias"] for n in ("query", "key", "value")], 0))
+        for key, name in (("wo", "attention.output.dense.weight"), ("bo", "attention.output.dense.bias"), ("ln1_w", "attention.output.LayerNorm.weight"),
+                          ("ln1_b", "attention.output.LayerNorm.bias"), ("w1", "intermediate.dense.weight"), ("b1", "intermediate.dense.bias"),
+                          ("w2", "output.dense.weight"), ("b2", "output.dense.bias"), ("ln2_w", "output.LayerNorm.weight"), ("ln2_b", "output.LayerNorm.bias")):
+            pk[key] = stack(lambda l, name=name: sd[l + name])
+        if self.precision == "bf16":
+            for key in ("wqkv", "wo", "w1", "w2"):
+                src = pk[key]
+                dst = torch.empty(src.shape, dtype=torch.bfloat16, device=dev)
+                _lib.call("climb_cast_bf16", src, dst, src.numel(), _stream())
+                pk[key + "_op"] = dst
+        else:
+            for key in ("wqkv", "wo", "w1", "w2"):
+                pk[key + "_op"] = pk[key]
+        self._packed, self._packed_version = pk, ver
+        return pk
+
+    def _workspace(self, dev, B, T):
+        key = (str(dev), B, T)
+        ws = self._ws.get(key)
+        if ws is None:
+            if len(self._ws) >= 3:
+                self._ws.pop(next(iter(self._ws)))
+            H, Fd, nh = self.cfg["hidden"], self.cfg["ffn"], self.cfg["heads"]
+            Tp = _round_up(T, 32)
+            M = B * Tp
+            adt = torch.float32 if self.precision == "fp32" else torch.bfloat16
+
+            def buf(shape, dt=torch.float32):
+                return torch.zeros(shape, dtype=dt, device=dev)
+            ws = dict(Tp=Tp, M=M, x=buf((M, H)), y=buf((M, H)), h=buf((M, H)), qkv=buf((M, 3 * H), adt), ctx=buf((M, H), adt), pre=buf((M, Fd), adt),
+                      a=buf((M, Fd), adt), lse=buf((B, nh, Tp)), key_bias=buf((B, Tp)), mean=buf((M,)), rstd=buf((M,)), tmean=buf((B * T,)), trstd=buf((B * T,)))
+            ws["xb"] = ws["x"] if self.precision == "fp32" else buf((M, H), adt)
+            ws["hb"] = ws["h"] if self.precision == "fp32" else buf((M, H), adt)
+            self._ws[key] = ws
+        return ws
+
+    # ------------------------------------------------------------------ kernels
+    def _gemm(self, X, W, bias, Y, M, N, K, epi=EPI_NONE, aux=None, aux_out=None, out_f32=False):
+        st = _stream()
+        if self.precision == "fp32":
+            _lib.call("climb_gemm_f32", X, K, 1, W, K, 1, Y, N, M, N, K, bias, epi, aux, N, aux_out, N, 0.0, None, 0, 0, st)
+        else:
+            _lib.call("climb_gemm_bf16_nt", X, K, W, K, Y, N, F32 if out_f32 else BF16, M, N, K, bias, epi, aux, N, aux_out, N, None, 0, st)
+
+    def _ln(self, x, w, b, out, out_dt, ws, M):
+        H = self.cfg["hidden"]
+        _lib.call("climb_layernorm_fwd", x, H, w, b, self.cfg["ln_eps"], out, H, out_dt, ws["mean"], ws["rstd"], M, H, _stream())
+
+    @torch.no_grad()
+    def forward(self, input_ids, attention_mask, token_type_ids) -> torch.Tensor:
+        """[B, T] int64 x 3 -> last_hidden_state as a [B, roundup(T, 32), 768] fp32 buffer whose first T rows per sequence are valid
+        (the ViLT engine's `inputs_embeds` operand; rows beyond T are scratch)."""
+        dev = input_ids.device
+        if dev.type != "cuda":
+            raise RuntimeError("climb_amd.bert needs a HIP device; there is no CPU path in the product (oracle/bert_oracle.py is the CPU checker)")
+        cfg = self.cfg
+        B, T = input_ids.shape
+        H, Fd, nh = cfg["hidden"], cfg["ffn"], cfg["heads"]
+        pk = self._pack(dev)
+        ws = self._workspace(dev, B, T)
+        Tp, M = ws["Tp"], ws["M"]
+        st = _stream()
+        adt = F32 if self.precision == "fp32" else BF16
+        _lib.call("climb_key_bias", attention_mask, ws["key_bias"], B, T, T, Tp, st)
+        x = ws["x"]
+        x.zero_()                                       # padding rows: finite (zero) inputs, masked as keys
+        _lib.call("climb_embed_text_fwd", input_ids, token_type_ids, pk["word"], pk["type"], pk["pos"], pk["eln_w"], pk["eln_b"], pk["zero_h"],
+                  cfg["ln_eps"], x, B, T, Tp, H, ws["tmean"], ws["trstd"], 0, st)
+        attn = "climb_attn_fwd_f32" if self.precision == "fp32" else "climb_attn_fwd_bf16"
+        for i in range(cfg["layers"]):
+            if self.precision == "bf16":
+                _lib.call("climb_cast_bf16", x, ws["xb"], M * H, st)
+            self._gemm(ws["xb"], pk["wqkv_op"][i], pk["bqkv"][i], ws["qkv"], M, 3 * H, H)
+            _lib.call(attn, ws["qkv"], ws["key_bias"], ws["ctx"], ws["lse"], B, Tp, nh, cfg["head_dim"], st)
+            self._gemm(ws["ctx"], pk["wo_op"][i], pk["bo"][i], ws["y"], M, H, H, EPI_RESID, aux=x, out_f32=True)          # + x (HFB:290)
+            self._ln(ws["y"], pk["ln1_w"][i], pk["ln1_b"][i], ws["h"], F32, ws, M)
+            if self.precision == "bf16":
+                self._ln(ws["y"], pk["ln1_w"][i], pk["ln1_b"][i], ws["hb"], BF16, ws, M)
+            self._gemm(ws["hb"], pk["w1_op"][i], pk["b1"][i], ws["a"], M, Fd, H, EPI_GELU, aux_out=ws["pre"])
+            self._gemm(ws["a"], pk["w2_op"][i], pk["b2"][i], ws["y"], M, H, Fd, EPI_RESID, aux=ws["h"], out_f32=True)          # + h (HFB:349)
+            self._ln(ws["y"], pk["ln2_w"][i], pk["ln2_b"][i], x, F32, ws, M)
+        return x.view(B, Tp, H)

@@ -1,9 +1,14 @@
-"""REF/configs/model_configs.py:6-12, :58 -- the `vilt` entry, resolving to this package's classes."""
+"""REF/configs/model_configs.py:6-12, :36-41, :58-63 -- the `vilt` and `viltbert` entries, resolving to this package's classes."""
 from ..modeling.vilt import ViltEncoderWrapper, convert_batch_to_vilt_input_dict
 
-ALLOWED_CL_ENCODERS = ["vilt"]
+from ..modeling.viltbert import ViltBertEncoderWrapper, convert_batch_to_viltbert_input_dict
+
+ALLOWED_CL_ENCODERS = ["vilt", "viltbert"]
 
 vilt_config = {"encoder_dim": 768, "visual_input_type": "pil-image", "encoder_class": ViltEncoderWrapper,
                "batch2inputs_converter": convert_batch_to_vilt_input_dict, "encoder_name": "ViLT"}
 
-model_configs = {"vilt": vilt_config}
+viltbert_config = {"encoder_dim": 768, "visual_input_type": "pil-image", "encoder_class": ViltBertEncoderWrapper,
+                   "batch2inputs_converter": convert_batch_to_viltbert_input_dict, "encoder_name": "ViLT-BERT"}        # REF/configs/model_configs.py:36-41
+
+model_configs = {"vilt": vilt_config, "viltbert": viltbert_config}

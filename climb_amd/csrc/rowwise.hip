@@ -273,19 +273,21 @@ __global__ __launch_bounds__(256) void embed_text_fwd_kernel(const long* __restr
                                                              const float* __restrict__ pos, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, const float* __restrict__ mod0, float eps,
                                                              float* __restrict__ x, int B, int T, int S_pad, int H,
-                                                             float* __restrict__ mean_out, float* __restrict__ rstd_out) {
+                                                             float* __restrict__ mean_out, float* __restrict__ rstd_out, int emb_ld) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= B * T) return;
   const int b = row / T, t = row - b * T;
-  const long id = ids[row], tt = tts[row];
+  const long tt = tts[row];
+  // ids == NULL: `word` is an inputs_embeds matrix [B, emb_ld, H] (HF ViltEmbeddings / TextEmbeddings with inputs_embeds: ViLT-BERT)
+  const float* wrow = ids ? word + ids[row] * H : word + ((long)b * emb_ld + t) * H;
   float4 v[3];
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     int c = (i * 64 + lane) * 4;
     if (c < H) {
-      float4 w = ld4(word + id * H + c), ty = ld4(type + tt * H + c), p = ld4(pos + (long)t * H + c);
+      float4 w = ld4(wrow + c), ty = ld4(type + tt * H + c), p = ld4(pos + (long)t * H + c);
       v[i] = make_float4(w.x + ty.x + p.x, w.y + ty.y + p.y, w.z + ty.z + p.z, w.w + ty.w + p.w);
       s += v[i].x + v[i].y + v[i].z + v[i].w;
     } else v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -315,10 +317,11 @@ __global__ __launch_bounds__(256) void embed_text_fwd_kernel(const long* __restr
 }
 extern "C" int climb_embed_text_fwd(const long* ids, const long* tts, const float* word, const float* type, const float* pos,
                                     const float* gamma, const float* beta, const float* mod0, float eps, float* x, int B, int T, int S_pad,
-                                    int H, float* mean, float* rstd, void* stream) {
+                                    int H, float* mean, float* rstd, int emb_ld, void* stream) {
   if (H % 4 || H > 768) return CLIMB_EUNSUPPORTED;
+  if (!ids && emb_ld < T) return CLIMB_EINVAL;
   hipLaunchKernelGGL(embed_text_fwd_kernel, dim3((B * T + 3) / 4), dim3(256), 0, (hipStream_t)stream, ids, tts, word, type, pos, gamma, beta,
-                     mod0, eps, x, B, T, S_pad, H, mean, rstd);
+                     mod0, eps, x, B, T, S_pad, H, mean, rstd, emb_ld);
   LAUNCH_CHECK();
   return CLIMB_OK;
 }
@@ -331,7 +334,7 @@ __global__ __launch_bounds__(256) void embed_text_bwd_kernel(const long* __restr
                                                              const float* __restrict__ pos, const float* __restrict__ gamma,
                                                              const float* __restrict__ mean, const float* __restrict__ rstd,
                                                              const float* __restrict__ dres, int B, int T, int S_pad, int H,
-                                                             float* dword, float* __restrict__ dpre, float* __restrict__ part) {
+                                                             float* dword, float* __restrict__ dpre, float* __restrict__ part, int emb_ld) {
   __shared__ __attribute__((aligned(16))) float red[3][4][768];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   float4 ag[3], ab[3], am[3], gm[3];
@@ -345,7 +348,8 @@ __global__ __launch_bounds__(256) void embed_text_bwd_kernel(const long* __restr
     const int row = blockIdx.x * 32 + rr * 4 + wid;
     if (row >= B * T) break;
     const int b = row / T, t = row - b * T;
-    const long id = ids[row], tt = tts[row];
+    const long id = ids ? ids[row] : 0, tt = tts[row];
+    const float* wrow = ids ? word + id * H : word + ((long)b * emb_ld + t) * H;
     const float mu = mean[row], rs = rstd[row];
     float4 xh[3], g[3], d[3];
     float s1 = 0.f, s2 = 0.f;
@@ -353,7 +357,7 @@ __global__ __launch_bounds__(256) void embed_text_bwd_kernel(const long* __restr
     for (int i = 0; i < 3; ++i) {
       int c = (i * 64 + lane) * 4;
       if (c < H) {
-        float4 w = ld4(word + id * H + c), ty = ld4(type + tt * H + c), p = ld4(pos + (long)t * H + c);
+        float4 w = ld4(wrow + c), ty = ld4(type + tt * H + c), p = ld4(pos + (long)t * H + c);
         d[i] = ld4(dres + ((long)b * S_pad + t) * H + c);
         xh[i] = make_float4((w.x + ty.x + p.x - mu) * rs, (w.y + ty.y + p.y - mu) * rs, (w.z + ty.z + p.z - mu) * rs,
                             (w.w + ty.w + p.w - mu) * rs);
@@ -372,7 +376,7 @@ __global__ __launch_bounds__(256) void embed_text_bwd_kernel(const long* __restr
         if (dpre) st4(dpre + (long)row * H + c, make_float4(o[0], o[1], o[2], o[3]));
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          if (dword) atomicAdd(dword + id * H + c + j, o[j]);          // random vocabulary rows: low contention
+          if (dword && ids) atomicAdd(dword + id * H + c + j, o[j]);   // random vocabulary rows: low contention (no table behind inputs_embeds)
         ag[i].x += d[i].x * xh[i].x; ag[i].y += d[i].y * xh[i].y; ag[i].z += d[i].z * xh[i].z; ag[i].w += d[i].w * xh[i].w;
         ab[i].x += d[i].x; ab[i].y += d[i].y; ab[i].z += d[i].z; ab[i].w += d[i].w;
         am[i].x += d[i].x; am[i].y += d[i].y; am[i].z += d[i].z; am[i].w += d[i].w;
@@ -416,10 +420,11 @@ __global__ void embed_text_bwd_tables_kernel(const float* __restrict__ dpre, con
 // part: ceil(B*T/32)*3*H floats; dpre: B*T*H floats; part2: T*2*H floats (token-type partials, reduce with stride 2H over T)
 extern "C" int climb_embed_text_bwd(const long* ids, const long* tts, const float* word, const float* type, const float* pos,
                                     const float* gamma, const float* mean, const float* rstd, const float* dres, int B, int T, int S_pad, int H,
-                                    float* dword, float* dpos, float* dpre, float* part, float* part2, void* stream) {
+                                    float* dword, float* dpos, float* dpre, float* part, float* part2, int emb_ld, void* stream) {
   if (H != 768) return CLIMB_EUNSUPPORTED;
+  if (!ids && emb_ld < T) return CLIMB_EINVAL;
   hipLaunchKernelGGL(embed_text_bwd_kernel, dim3((B * T + 31) / 32), dim3(256), 0, (hipStream_t)stream, ids, tts, word, type, pos, gamma, mean,
-                     rstd, dres, B, T, S_pad, H, dword, dpre, part);
+                     rstd, dres, B, T, S_pad, H, dword, dpre, part, emb_ld);
   LAUNCH_CHECK();
   if (dpre) {
     int n = T * (H / 4);

@@ -148,6 +148,7 @@ class ViltEngine:
         self.grad_ready_hook: Optional[Callable[[int, int], None]] = None   # (lo, hi) flat range whose grads are final
         self.touched: List[tuple] = []                  # flat ranges that received gradients in the last backward
         self.saved = None
+        self._unused = set()                            # trainable tensors the last forward did not use (their .grad stays None, like torch's)
         self.active_adapter: Optional[str] = None       # name of the adapter applied in forward/backward (None = plain ViLT)
         self.prof = None                                # bench.py: {"kernel": name, "events": [(start, end, flops)]}
         # weight-gradient GEMMs run on a second HIP stream, concurrently with the input-gradient chain they do not feed
@@ -370,12 +371,14 @@ class ViltEngine:
 
     # ------------------------------------------------------------------ encoder forward
     def encoder_forward(self, input_ids, token_type_ids, attention_mask, pixel_values, img_type: torch.Tensor, save: bool = True,
-                        pixel_mask: Optional[torch.Tensor] = None):
+                        pixel_mask: Optional[torch.Tensor] = None, inputs_embeds: Optional[torch.Tensor] = None):
         """[B,T] int64 ids/types/mask, [B,3,Hc,Wc] fp32 pixels, img_type int32 [B] (HF `image_token_type_idx` per sequence).
         `pixel_mask` None = every image fills the 384x384 canvas (benchmark shape); int64 [B,Hc,Wc] = padded variable-resolution
         batch as `ViltProcessor` produces it (HF:92-178 path).  Returns pooled [B,H] fp32 (HF:636-663 pooler_output)."""
         cfg, L = self.cfg, self.layout
-        B, T = input_ids.shape
+        B, T = token_type_ids.shape
+        if inputs_embeds is not None:      # [B, >= T, H] fp32 in place of the word-embedding lookup (ViLT-BERT); no gradient flows into it
+            assert inputs_embeds.dtype == torch.float32 and inputs_embeds.is_contiguous() and inputs_embeds.shape[0] == B and inputs_embeds.shape[1] >= T
         H, Fd, nh = cfg["hidden"], cfg["ffn"], cfg["heads"]
         P_ = cfg["patch"]
         Hc, Wc = int(pixel_values.shape[-2]), int(pixel_values.shape[-1])
@@ -405,10 +408,12 @@ class ViltEngine:
         ws.img_type.copy_(img_type)
         _lib.call("climb_key_bias", attention_mask, ws.key_bias, B, T, ws.S, ws.S_pad, st)
         x0 = ws.x[0]
-        _lib.call("climb_embed_text_fwd", input_ids, token_type_ids, self.p(e + "text_embeddings.word_embeddings.weight"),
+        _lib.call("climb_embed_text_fwd", input_ids if inputs_embeds is None else None, token_type_ids,
+                  self.p(e + "text_embeddings.word_embeddings.weight") if inputs_embeds is None else inputs_embeds,
                   self.p(e + "text_embeddings.token_type_embeddings.weight"), self.p(e + "text_embeddings.position_embeddings.weight"),
                   self.p(e + "text_embeddings.LayerNorm.weight"), self.p(e + "text_embeddings.LayerNorm.bias"),
-                  self.p(e + "token_type_embeddings.weight"), cfg["ln_eps"], x0, B, T, ws.S_pad, H, ws.tmean, ws.trstd, st)
+                  self.p(e + "token_type_embeddings.weight"), cfg["ln_eps"], x0, B, T, ws.S_pad, H, ws.tmean, ws.trstd,
+                  0 if inputs_embeds is None else int(inputs_embeds.shape[1]), st)
         _lib.call("climb_im2col", pixel_values, ws.a_patch, adt, B, cfg["channels"], Hc, Wc, P_, st)
         if var:
             _lib.call("climb_patch_grid_dims", pixel_mask, B, Hc, Wc, P_, ws.dims, st)
@@ -457,9 +462,12 @@ class ViltEngine:
             _lib.call("climb_elementwise", 6, ws.pooled, None, ws.pooled, B * H, 1.0, st)
         else:
             self._gemm_f32(ws.clsn, H, 1, self.p(ENC + "pooler.dense.weight"), H, 1, ws.pooled, H, B, H, H, self.p(ENC + "pooler.dense.bias"), EPI_TANH)
+        # the word-embedding table is bypassed by inputs_embeds: it receives no gradient and the optimizer must skip it (torch: grad None)
+        self._unused = {e + "text_embeddings.word_embeddings.weight"} if inputs_embeds is not None else set()
         if save:
             self._generation = getattr(self, "_generation", 0) + 1
-            self.saved = dict(ws=ws, input_ids=input_ids, token_type_ids=token_type_ids, adapter=ad, var=var, generation=self._generation)
+            self.saved = dict(ws=ws, input_ids=input_ids, token_type_ids=token_type_ids, adapter=ad, var=var, generation=self._generation,
+                              inputs_embeds=inputs_embeds)
         return ws.pooled
 
     def linear_fwd_f32out(self, X, wname, bname, Y, M, N, K):
@@ -499,7 +507,7 @@ class ViltEngine:
             segs = self._segs = self.layout.segments()
         runs = []
         for name, start, length in segs:
-            if start < lo or start >= hi or not self.requires_grad[name]:
+            if start < lo or start >= hi or not self.requires_grad[name] or name in self._unused:
                 continue
             if runs and runs[-1][1] == start:
                 runs[-1][1] = start + length
@@ -616,12 +624,14 @@ class ViltEngine:
         Kp = cfg["channels"] * cfg["patch"] ** 2
         self.linear_dw(ws.dproj, ws.a_patch, e + "patch_embeddings.projection.weight", B * ws.NP, H, Kp, e + "patch_embeddings.projection.bias", ws)
         te = e + "text_embeddings."
-        _lib.call("climb_embed_text_bwd", sv["input_ids"], sv["token_type_ids"], self.p(te + "word_embeddings.weight"),
+        ie = sv.get("inputs_embeds")
+        _lib.call("climb_embed_text_bwd", sv["input_ids"] if ie is None else None, sv["token_type_ids"],
+                  self.p(te + "word_embeddings.weight") if ie is None else ie,
                   self.p(te + "token_type_embeddings.weight"), self.p(te + "position_embeddings.weight"), self.p(te + "LayerNorm.weight"),
                   ws.tmean, ws.trstd, ws.dres, B, T, ws.S_pad, H,
-                  self.g(te + "word_embeddings.weight") if rg[te + "word_embeddings.weight"] else None,
+                  self.g(te + "word_embeddings.weight") if (rg[te + "word_embeddings.weight"] and ie is None) else None,
                   self.g(te + "position_embeddings.weight") if rg[te + "position_embeddings.weight"] else None,
-                  ws.dpre, ws.part, ws.part2, st)
+                  ws.dpre, ws.part, ws.part2, 0 if ie is None else int(ie.shape[1]), st)
         nb = (B * T + 31) // 32
         # [dgamma | dbeta | dmodality row 0 (text rows)] in one launch; the modality table starts with row 0
         self.reduce3(ws.part, nb, H, te + "LayerNorm.weight", te + "LayerNorm.bias", e + "token_type_embeddings.weight")

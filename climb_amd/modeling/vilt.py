@@ -240,15 +240,15 @@ class _EngineHost:
     # --- autograd-aware entry points (used when a reference-style trainer calls model(...) then loss.backward())
     def encode(self, enc: Dict[str, torch.Tensor]) -> torch.Tensor:
         eng = self.engine()
-        B = enc["input_ids"].shape[0]
+        B = enc["token_type_ids"].shape[0]
         it = enc.get("image_token_type_idx", None)
         if it is None:
             it = 1
         img_type = it.to(torch.int32) if isinstance(it, torch.Tensor) else torch.full((B,), int(it), dtype=torch.int32, device=eng.device)
         sentinel = self.any_encoder_grad() if torch.is_grad_enabled() else None
         if sentinel is None:
-            return eng.encoder_forward(enc["input_ids"], enc["token_type_ids"], enc["attention_mask"], enc["pixel_values"], img_type,
-                                       save=False, pixel_mask=enc.get("pixel_mask")).clone()
+            return eng.encoder_forward(enc.get("input_ids"), enc["token_type_ids"], enc["attention_mask"], enc["pixel_values"], img_type,
+                                       save=False, pixel_mask=enc.get("pixel_mask"), inputs_embeds=enc.get("inputs_embeds")).clone()
         return _EncoderFn.apply(sentinel, self, enc, img_type)
 
     def head(self, task_key: str, pooled_in: torch.Tensor, training: bool) -> torch.Tensor:
@@ -267,8 +267,8 @@ class _EncoderFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, sentinel, host, enc, img_type):
         eng = host._engine
-        pooled = eng.encoder_forward(enc["input_ids"], enc["token_type_ids"], enc["attention_mask"], enc["pixel_values"], img_type,
-                                     pixel_mask=enc.get("pixel_mask"))
+        pooled = eng.encoder_forward(enc.get("input_ids"), enc["token_type_ids"], enc["attention_mask"], enc["pixel_values"], img_type,
+                                     pixel_mask=enc.get("pixel_mask"), inputs_embeds=enc.get("inputs_embeds"))
         ctx.host = host
         ctx.generation = eng.saved["generation"]
         return pooled.clone()
@@ -361,6 +361,10 @@ class ViltEncoderWrapper(EncoderWrapper):
         enc = self.processor(images=images, text=texts, max_length=self.max_text_length, padding=True, truncation=True, return_tensors="pt")
         return {k: v.to(dev, non_blocking=True) for k, v in enc.items()}
 
+    def prepare_encodings(self, enc: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        """Last step before the encoder kernels; the plain ViLT wrapper has nothing to add (ViLT-BERT puts BERT's features here)."""
+        return enc
+
     def expand_modality_type_embeddings(self, type_vocab_size=3):
         """REF:98-109: third modality row = copy of the second."""
         old = self.vilt.embeddings.token_type_embeddings.weight.data
@@ -380,7 +384,7 @@ class ViltEncoderWrapper(EncoderWrapper):
 
     def forward(self, **encodings) -> torch.FloatTensor:
         """REF:111-124: pooler_output [B, 768].  Accepts `image_token_type_idx` (int, or int32 tensor [B])."""
-        return self.host().encode(encodings)
+        return self.host().encode(self.prepare_encodings(encodings))
 
     def freeze_all_weights(self):
         for p in self.vilt.parameters():
@@ -398,11 +402,16 @@ class ViltEncoderWrapper(EncoderWrapper):
 # ----------------------------------------------------------------------------------------------- continual learner
 class ViltContinualLearner(ContinualLearner):
     """REF/modeling/vilt.py:147-367."""
+    encoder_attr = "vilt_encoder"          # the attribute (and state_dict prefix) the encoder wrapper is registered under
+
+    @property
+    def _enc(self) -> ViltEncoderWrapper:
+        return getattr(self, self.encoder_attr)
 
     def __init__(self, ordered_cl_tasks: List[str], encoder: ViltEncoderWrapper, encoder_dim: int, task_configs: Dict):
         super().__init__()
         self.encoder_dim = encoder_dim
-        self.vilt_encoder = encoder
+        setattr(self, self.encoder_attr, encoder)
         self.ordered_cl_tasks = ordered_cl_tasks
         self.task_configs = task_configs
         self.task_layer_dict = {}
@@ -410,10 +419,10 @@ class ViltContinualLearner(ContinualLearner):
             self.add_task_layer(task_key, task_configs[task_key])
         self.task_layer = nn.ModuleDict(self.task_layer_dict)
         if "nlvr2" in ordered_cl_tasks:
-            self.vilt_encoder.expand_modality_type_embeddings()
-        self.task_layer.to(next(self.vilt_encoder.vilt.parameters()).device)
-        self._host = _EngineHost(self.vilt_encoder, self.task_layer, list(ordered_cl_tasks), task_configs, self.vilt_encoder.precision)
-        self.vilt_encoder._host = self._host
+            self._enc.expand_modality_type_embeddings()
+        self.task_layer.to(next(self._enc.vilt.parameters()).device)
+        self._host = _EngineHost(self._enc, self.task_layer, list(ordered_cl_tasks), task_configs, self._enc.precision)
+        self._enc._host = self._host
 
     def add_task_layer(self, task_key: str, task_config: Dict):
         """REF:179-203.  torch modules are used as parameter containers (names `0.weight` ... `3.bias`); the arithmetic
@@ -496,9 +505,9 @@ class ViltContinualLearner(ContinualLearner):
 
     def _forward_any(self, task_key, images, texts):
         images, texts = self._flatten_inputs(task_key, images, texts)
-        enc = self.vilt_encoder.process_inputs(images, texts)
+        enc = self._enc.process_inputs(images, texts)
         enc, kind = self._expand(task_key, enc)
-        pooled = self._shape_pooled(self.vilt_encoder(**enc), kind)
+        pooled = self._shape_pooled(self._enc(**enc), kind)
         logits = self._host.head(task_key, pooled, self.training)
         return pooled, logits
 
@@ -512,7 +521,7 @@ class ViltContinualLearner(ContinualLearner):
         return self._forward_any(task_key, images, texts)
 
     def get_encoder(self):
-        return self.vilt_encoder
+        return self._enc
 
     # --- fused training step: forward + loss + backward (+ EWC term) with no autograd graph.  This is what
     # climb_amd.train.*Trainer.train_step runs; semantics = REF/train/visionlanguage_tasks/train_vqa.py:135-166.
@@ -521,15 +530,16 @@ class ViltContinualLearner(ContinualLearner):
         eng = host.engine()
         host.before_backward()
         images, texts = self._flatten_inputs(task_key, images, texts)
-        enc = self.vilt_encoder.process_inputs(images, texts)
+        enc = self._enc.process_inputs(images, texts)
         enc, kind = self._expand(task_key, enc)
-        B = enc["input_ids"].shape[0]
+        enc = self._enc.prepare_encodings(enc)
+        B = enc["token_type_ids"].shape[0]
         it = enc["image_token_type_idx"]
         img_type = it if isinstance(it, torch.Tensor) else torch.full((B,), int(it), dtype=torch.int32, device=eng.device)
         if host.ddp is not None:
             host.ddp.begin()
-        pooled_seq = eng.encoder_forward(enc["input_ids"], enc["token_type_ids"], enc["attention_mask"], enc["pixel_values"], img_type,
-                                         pixel_mask=enc.get("pixel_mask"))
+        pooled_seq = eng.encoder_forward(enc.get("input_ids"), enc["token_type_ids"], enc["attention_mask"], enc["pixel_values"], img_type,
+                                         pixel_mask=enc.get("pixel_mask"), inputs_embeds=enc.get("inputs_embeds"))
         pooled = self._shape_pooled(pooled_seq, kind)
         logits, hs = eng.head_forward(task_key, pooled, self.training, dropout_keep)
         target = target.to(eng.device, non_blocking=True)
@@ -554,7 +564,8 @@ class ViltContinualLearner(ContinualLearner):
     # the graph's static outputs (overwritten by the next replay).  Falls back to the eager path under data parallelism / EWC.
     def graphed_forward_backward(self, task_key: str, images, texts, target: torch.Tensor, ewc=None, dropout_keep=None):
         host = self._host
-        if host.ddp is not None or dropout_keep is not None or not isinstance(texts, dict) or (self.training and self.task_configs[task_key]["model_type"] == "multi-choice"):
+        if host.ddp is not None or dropout_keep is not None or not isinstance(texts, dict) or hasattr(self._enc, "bert") or \
+                (self.training and self.task_configs[task_key]["model_type"] == "multi-choice"):
             return self.fused_forward_backward(task_key, images, texts, target, ewc, dropout_keep)
         eng = host.engine()
         img = images if isinstance(images, dict) else {"pixel_values": images}
@@ -602,16 +613,16 @@ class ViltContinualLearner(ContinualLearner):
 
     # --- adapters (REF:357-367); arithmetic of the absent GLAMOR fork is unpinned, see climb_amd/cl_algorithms/adapters.py
     def add_adapter(self, task_key: str, config: Dict):
-        self.vilt_encoder.vilt.add_adapter(task_key, config)
+        self._enc.vilt.add_adapter(task_key, config)
 
     def train_adapter(self, task_key: str):
-        self.vilt_encoder.vilt.train_adapter(task_key)
+        self._enc.vilt.train_adapter(task_key)
 
     def set_active_adapters(self, task_key: str):
-        self.vilt_encoder.vilt.set_active_adapters(task_key)
+        self._enc.vilt.set_active_adapters(task_key)
 
     def get_active_adapters(self):
-        return self.vilt_encoder.vilt.active_adapters
+        return self._enc.vilt.active_adapters
 
 
 # ----------------------------------------------------------------------------------------------- factories

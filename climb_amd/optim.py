@@ -43,6 +43,8 @@ class FusedAdamW(torch.optim.Optimizer):
                 for p in g["params"]:
                     n = by_id.get(id(p))
                     if n is None:
+                        if not p.requires_grad:         # frozen parameters outside the flat buffer (ViLT-BERT's BERT): torch skips them too
+                            continue
                         raise RuntimeError("FusedAdamW: parameter is not part of the bound model (was the model re-created?)")
                     self._group_of[n] = gi
         return eng

@@ -399,6 +399,55 @@ def case_cl_eval(fname="cl_eval.json"):
     json.dump(out, open(os.path.join(OUT, fname), "w"), indent=1)
 
 
+def case_viltbert(fname="viltbert_vqa_b3.npz", tasks=("vqa", "nlvr2"), B=3, wseed=42, bseed=7, dseed=21):
+    """Row F4: the reference's ViltBertContinualLearner (REF/modeling/viltbert.py): frozen BERT last hidden state as `inputs_embeds` of
+    ViLT.  EVAL mode (the reference leaves BERT's dropouts live in train mode -- torch-RNG dependent; see oracle/bert_oracle.py)."""
+    import bert_oracle as bo
+    print(f"[{fname}] ViLT-BERT forward/backward (eval mode), B={B}, ragged text")
+    tasks = list(tasks)
+    P = vo.init_params(tasks, wseed)
+    PB = bo.init_bert_params(bseed)
+    enc = vo.synthetic_encodings(B, seed=dseed, ragged_text=True)
+    target = vo.synthetic_vqa_targets(B, seed=dseed)
+    model = ri.build_reference_viltbert_learner(tasks, P, PB)
+    model.eval()
+    trainer = ri.make_trainer("vqa")
+    import modeling.viltbert as ref_vb
+    trainer.batch2inputs_converter = ref_vb.convert_batch_to_viltbert_input_dict
+    model.viltbert_encoder.process_inputs = lambda images, texts: dict(enc)
+    batch = {"raw_texts": [""] * B, "images": None, "target_scores": target}
+    model.zero_grad()
+    torch.manual_seed(0)
+    loss, (pooled, logits), _, _ = trainer.train_step(model, batch, None, None, None)
+    G = {n.replace("viltbert_encoder.", "vilt_encoder."): p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+    assert not any(".bert." in n for n in G), "BERT is frozen (no_grad): no gradient reaches it"
+    word = "vilt_encoder.vilt.embeddings.text_embeddings.word_embeddings.weight"
+    assert word not in G, "the word-embedding table is bypassed by inputs_embeds"
+    # oracle agreement
+    with torch.no_grad():
+        feats = bo.bert_forward(PB, enc["input_ids"], enc["token_type_ids"], enc["attention_mask"])
+    ref_feats = model.viltbert_encoder.get_bert_outputs(**enc)
+    check("bert last_hidden_state", feats, ref_feats, 2e-5)
+    oenc = dict(enc, inputs_embeds=feats)
+    oenc.pop("input_ids")
+    leaves = {n: P[n].clone().requires_grad_(True) for n in P}
+    o_pooled, o_logits = vo.learner_forward(leaves, "vqa", oenc, training=False)
+    o_loss = vo.vqa_loss(o_logits, target)
+    o_loss.backward()
+    o_G = {n: leaves[n].grad for n in G}
+    check("pooled", o_pooled, pooled, 2e-5)
+    check("logits", o_logits, logits, 2e-5)
+    check("loss", o_loss, loss, 2e-5)
+    assert leaves[word].grad is None
+    gn, gh = tensor_summary(G)
+    on, _ = tensor_summary(o_G)
+    check("grad norms", on, gn, 1e-4)
+    np.savez_compressed(os.path.join(OUT, fname), pooled=pooled.detach().numpy(), logits=logits.detach().numpy(), loss=np.float64(loss.item()),
+                        bert_feats_head=ref_feats[:, :, :8].detach().numpy(), bert_feats_norm=np.float64(ref_feats.double().norm().item()),
+                        grad_names=np.array(list(G.keys())), grad_norms=gn, grad_heads=gh,
+                        meta=np.array([f"task=vqa;tasks={','.join(tasks)};B={B};wseed={wseed};bseed={bseed};dseed={dseed};ragged=1;eval=1"]))
+
+
 def case_fullsize():
     """BASELINE configs[1] at its own size (64 sequences of 40 tokens + 384x384 per GPU) and the equal-sized NLVR2 / VCR batches
     (32 pairs, 16 x 4 choices): the reference's own `*Trainer.train_step` (REF/train/visionlanguage_tasks/train_vqa.py:135-174)."""
@@ -420,6 +469,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "fullsize":
         case_fullsize()
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "viltbert":
+        case_viltbert()
+        return
     case_single_image("vqa", ["vqa", "nlvr2"], 2, "vqa_b2.npz")
     case_single_image("vqa", ["vqa", "nlvr2"], 3, "vqa_b3_ragged.npz", ragged=True, dseed=2)
     case_single_image("snli-ve", ["snli-ve", "vcr"], 2, "snlive_b2.npz", dseed=8)
@@ -432,6 +484,7 @@ def main():
     case_varres("vqa_b4_varres.npz")
     case_cl_eval()
     case_fullsize()
+    case_viltbert()
     print("golden fixtures written to", OUT)
 
 

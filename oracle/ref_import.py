@@ -138,3 +138,22 @@ def make_trainer(task_key, loss=None):
 def bypass_processor(model, enc):
     """hand fixed tensor encodings to the model instead of PIL/tokenizer work."""
     model.vilt_encoder.process_inputs = lambda images, texts: {k: v for k, v in enc.items()}
+
+
+def build_reference_viltbert_learner(tasks, state, bert_state):
+    """The reference's own ViltBertContinualLearner (REF/modeling/viltbert.py:31-530) around seeded random-init ViltModel / BertModel."""
+    import torch
+    import transformers
+    ns = import_reference()
+    import modeling.viltbert as ref_vb
+    proc = ns.ViltProcessor(image_processor=ns.ViltImageProcessor(), tokenizer=ns.BertTokenizerFast.from_pretrained("bert-base-uncased"))
+    bert = transformers.BertModel(transformers.BertConfig())
+    missing, unexpected = bert.load_state_dict({k: v.clone() for k, v in bert_state.items()}, strict=False)
+    assert not unexpected and all("position_ids" in m or "token_type_ids" in m for m in missing), (missing, unexpected)
+    enc = ref_vb.ViltBertEncoderWrapper(proc, ns.ViltModel(ns.ViltConfig()), bert, torch.device("cpu"))
+    model = ref_vb.ViltBertContinualLearner(list(tasks), enc, 768, ns.task_configs)
+    sd = {k.replace("vilt_encoder.", "viltbert_encoder."): v.clone() for k, v in state.items()}
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    assert all(("position_ids" in m) or ("token_type_ids" in m) or m.startswith("viltbert_encoder.bert.") for m in missing), missing
+    return model

@@ -194,11 +194,12 @@ def gelu(x):
     return 0.5 * x * (1.0 + torch.erf(x * (1.0 / math.sqrt(2.0))))
 
 
-def text_embed(P, input_ids, token_type_ids, cfg=CFG):
-    """HF:237-269 TextEmbeddings.forward: LN(word[ids] + type[tt] + pos[0:T]); dropout p=0."""
+def text_embed(P, input_ids, token_type_ids, cfg=CFG, inputs_embeds=None):
+    """HF:237-269 TextEmbeddings.forward: LN(word[ids] + type[tt] + pos[0:T]); dropout p=0.  `inputs_embeds` [B,T,H] replaces the
+    table lookup (HF:250-251; ViLT-BERT feeds BERT's last hidden state here, REF/modeling/viltbert.py:142-147)."""
     e = ENC + "embeddings.text_embeddings."
-    T = input_ids.shape[1]
-    x = P[e + "word_embeddings.weight"][input_ids]
+    T = token_type_ids.shape[1]
+    x = P[e + "word_embeddings.weight"][input_ids] if inputs_embeds is None else inputs_embeds
     x = x + P[e + "token_type_embeddings.weight"][token_type_ids]
     x = x + P[e + "position_embeddings.weight"][:T].unsqueeze(0)
     return layer_norm(x, P[e + "LayerNorm.weight"], P[e + "LayerNorm.bias"], cfg["ln_eps"])
@@ -303,7 +304,7 @@ def encoder_forward(P, enc: Dict[str, torch.Tensor], image_token_type_idx: int =
                     return_sequence: bool = False, adapter=None):
     """REF/modeling/vilt.py:111-124 -> HF:536-647 ViltModel.forward -> pooler_output [B,768]."""
     e = ENC + "embeddings."
-    text = text_embed(P, enc["input_ids"], enc["token_type_ids"], cfg)
+    text = text_embed(P, enc.get("input_ids"), enc["token_type_ids"], cfg, enc.get("inputs_embeds"))
     pv, pm = enc["pixel_values"], enc["pixel_mask"]
     if pv.shape[-2:] == (cfg["image"], cfg["image"]) and bool((pm == 1).all()):
         img, img_mask = visual_embed_fixed(P, pv, pm, cfg)

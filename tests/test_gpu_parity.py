@@ -527,6 +527,70 @@ def test_houlsby_adapters_vs_oracle_restatement(precision, tol):
     assert not torch.allclose(l_vqa, l_other)
 
 
+# ------------------------------------------------------------------------------------------------ ViLT-BERT (row F4)
+@pytest.mark.parametrize("precision,tol", [("fp32", TOL), ("bf16", 6e-2)])      # bf16: 24 layers of bf16 operands instead of 12 (measured: pooled 4.9e-2)
+def test_viltbert_vs_reference(golden_dir, precision, tol):
+    """REF/modeling/viltbert.py: a frozen BERT-base's last hidden state replaces ViLT's word-embedding lookup.  Golden = the reference's
+    own ViltBertContinualLearner (eval mode) on seeded weights; the BERT features are also checked against the CPU oracle."""
+    from oracle import bert_oracle as bo
+    from climb_amd.modeling import create_continual_learner_map
+    from climb_amd.configs.task_configs import task_configs
+    from climb_amd.configs.model_configs import model_configs
+    z = np.load(os.path.join(golden_dir, "viltbert_vqa_b3.npz"))
+    m = _meta(z)
+    tasks, B = m["tasks"].split(","), int(m["B"])
+    dev = _dev()
+    model = create_continual_learner_map["viltbert"](model_name_or_path="random-init:0", ordered_cl_tasks=tasks, model_config=model_configs["viltbert"],
+                                                     task_configs=task_configs, device=dev, precision=precision)
+    P, PB = vo.init_params(tasks, int(m["wseed"])), bo.init_bert_params(int(m["bseed"]))
+    sd = {k.replace("vilt_encoder.", "viltbert_encoder."): v for k, v in P.items()}
+    sd.update({"viltbert_encoder.bert." + k: v for k, v in PB.items()})
+    model.load_state_dict(sd, strict=True)
+    model.to(dev)
+    assert list(model.state_dict().keys())[0].startswith("viltbert_encoder.vilt.") and model.get_encoder() is model.viltbert_encoder
+    enc = vo.synthetic_encodings(B, seed=int(m["dseed"]), ragged_text=True)
+    target = vo.synthetic_vqa_targets(B, seed=int(m["dseed"]))
+    images, texts = enc_to_inputs(enc)
+    # the frozen text features
+    dtexts = {k: v.to(dev) for k, v in texts.items()}
+    feats = model.get_encoder().get_bert_outputs(**dtexts)[:, :enc["input_ids"].shape[1]].float().cpu()
+    with torch.no_grad():
+        ofeats = bo.bert_forward(PB, enc["input_ids"], enc["token_type_ids"], enc["attention_mask"])
+    valid = enc["attention_mask"].bool()
+    _close(feats[valid], ofeats[valid], tol, "BERT last_hidden_state (valid tokens) vs oracle")
+    _close(feats[valid][:, :8], torch.from_numpy(z["bert_feats_head"])[valid], tol, "BERT features vs reference")
+    model.eval()                                           # the fixture is eval mode (see oracle/bert_oracle.py on the train-mode dropout quirk)
+    loss, (pooled, logits), _, _ = model.fused_forward_backward("vqa", images, texts, target)
+    _close(pooled, z["pooled"], tol, "pooled vs reference")
+    _close(logits, z["logits"], tol, "logits vs reference")
+    _close(loss, z["loss"], tol, "loss vs reference")
+    G = {n.replace("viltbert_encoder.", "vilt_encoder."): g for n, g in grads_of(model).items()}
+    names = [str(n) for n in z["grad_names"]]
+    assert set(G) == set(names), set(G) ^ set(names)       # no gradient for BERT, none for the bypassed word-embedding table
+    norms, heads = _summary(G, names)
+    if precision == "fp32":
+        assert np.array_equal(logits.argmax(-1).cpu().numpy(), z["logits"].argmax(-1))
+        _close(norms, z["grad_norms"], tol, "grad norms vs reference")
+        _close(heads, z["grad_heads"], tol, "grad heads vs reference")
+    else:
+        big = z["grad_norms"] > 1e-3 * z["grad_norms"].max()
+        assert (np.abs(norms - z["grad_norms"])[big] / z["grad_norms"][big]).max() < 6e-2
+    # an optimizer step moves ViLT and the head, not BERT and not the bypassed table
+    before = {n: p.detach().clone() for n, p in model.named_parameters()}
+    opt = model.create_optimizer({"lr": 1e-3, "weight_decay": 1e-2, "adam_epsilon": 1e-8})
+    opt.step()
+    opt.zero_grad()
+    word = "viltbert_encoder.vilt.embeddings.text_embeddings.word_embeddings.weight"
+    for n, p in model.named_parameters():
+        changed = not torch.equal(p.detach(), before[n])
+        expect = not (".bert." in n or n == word or n.startswith("task_layer.nlvr2."))
+        assert changed == expect, n
+    # reference-style call path: model(task_key=..., images=..., texts=...) -> (pooled, logits)
+    with torch.no_grad():
+        out = model(task_key="vqa", images=images, texts=texts)
+    assert out[1].shape == (B, 3129) and bool(torch.isfinite(out[1]).all())
+
+
 # ------------------------------------------------------------------------------------------------ full size vs the REFERENCE
 def _full_size_inputs(z):
     """Rebuild the seeded inputs of a tests/golden/*_b{64,32,16}.npz fixture (oracle/gen_golden.py::case_fullsize)."""

@@ -202,3 +202,33 @@ def test_variable_resolution_general_visual_embed(golden_dir):
     norms, heads = _summary(G, names)
     _close(norms, z["grad_norms"], 1e-4, "grad norms")
     _close(heads, z["grad_heads"], 1e-4, "grad heads")
+
+
+def test_bert_oracle_equals_transformers_bert_and_fixture(golden_dir):
+    """Row F4: oracle/bert_oracle.py against transformers' own BertModel (a dependency of the reference installed here and on the GPU box)
+    on the seeded weights, and against the features the reference's ViltBertEncoderWrapper.get_bert_outputs produced (fixture)."""
+    import numpy as np
+    import torch
+    transformers = pytest.importorskip("transformers")
+    from oracle import bert_oracle as bo
+    from oracle import vilt_oracle as vo
+    z = np.load(os.path.join(golden_dir, "viltbert_vqa_b3.npz"))
+    m = dict(kv.split("=", 1) for kv in str(z["meta"][0]).split(";"))
+    PB = bo.init_bert_params(int(m["bseed"]))
+    enc = vo.synthetic_encodings(int(m["B"]), seed=int(m["dseed"]), ragged_text=True)
+    with torch.no_grad():
+        feats = bo.bert_forward(PB, enc["input_ids"], enc["token_type_ids"], enc["attention_mask"])
+        hf = transformers.BertModel(transformers.BertConfig()).eval()
+        hf.load_state_dict({k: v for k, v in PB.items()}, strict=False)
+        ref = hf(input_ids=enc["input_ids"], attention_mask=enc["attention_mask"], token_type_ids=enc["token_type_ids"]).last_hidden_state
+    assert float((feats - ref).abs().max() / ref.abs().max()) < 2e-5
+    assert float((feats[:, :, :8] - torch.from_numpy(z["bert_feats_head"])).abs().max()) < 2e-5 * float(ref.abs().max())
+    assert abs(float(feats.double().norm()) - float(z["bert_feats_norm"])) < 1e-4 * float(z["bert_feats_norm"])
+    # the ViLT half on top of those features reproduces the reference's pooled output / logits / loss
+    P = vo.init_params(m["tasks"].split(","), int(m["wseed"]))
+    oenc = {k: v for k, v in enc.items() if k != "input_ids"}
+    oenc["inputs_embeds"] = feats
+    with torch.no_grad():
+        pooled, logits = vo.learner_forward(P, "vqa", oenc, training=False)
+    assert float((pooled - torch.from_numpy(z["pooled"])).abs().max()) < 2e-5
+    assert float((logits - torch.from_numpy(z["logits"])).abs().max()) < 2e-5 * float(np.abs(z["logits"]).max())
