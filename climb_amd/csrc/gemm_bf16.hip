@@ -337,9 +337,10 @@ extern "C" int climb_set_option(int key, int value) {
   if (key == 2) { g_nt_small_m = value; return CLIMB_OK; }
   if (key == 4) { g_nt_96 = value; return CLIMB_OK; }
   if (key == 5) { g_nt_192 = value; return CLIMB_OK; }
-  if (key == 7 && value >= 0 && value <= 3) { g_nt_256 = value; return CLIMB_OK; }
+  if (key == 7 && value >= 0 && value <= 4) { g_nt_256 = value; return CLIMB_OK; }
   if (key == 8) { climb_nt256_set_probe(value != 0); return CLIMB_OK; }
   if (key == 10 && (value == 0 || value == 1)) { g_tn_p = value; return CLIMB_OK; }
+  if (key == 11 && value >= 0) { climb_nt2_set_dephase(value); return CLIMB_OK; }
   if (key == 9 && value >= 0) { climb_nt256_set_grid(value); return CLIMB_OK; }
   if (key == 6 && (value == 4 || value == 8)) { g_tn_waves = value; return CLIMB_OK; }
   if (key == 3 && value > 0) { g_tn_target = value; return CLIMB_OK; }
@@ -372,6 +373,11 @@ static int nt_dispatch(const bf16_t* A, long lda, const bf16_t* B, long ldb, TO*
     int bn = c192 < c256 ? 192 : 256;
     if (g_nt_256 == 2) bn = 256;
     if (g_nt_256 == 3) bn = 192;
+    if (g_nt_256 == 4) {            // two 4-wave workgroups per CU, 128 x 192 tiles (gemm_bf16_nt2p.hip)
+      int rc = climb_nt2_launch(A, lda, B, ldb, C, ldc, sizeof(TO) == 4 ? CLIMB_DT_F32 : CLIMB_DT_BF16, M, N, K, bias, epi, aux, ldaux, aux_out, ldauxo, st);
+      if (rc == CLIMB_OK) { LAUNCH_CHECK(); return CLIMB_OK; }
+      if (rc != CLIMB_EUNSUPPORTED) return rc;
+    }
     const bool big = (long)M * N >= 2048L * 768;            // below that the 64 x 128 / 128 x 128 kernels fill the chip better
     // measured (r02, M = 12288): at K = 768 the single-round N = 768 shapes are a tie or better on the 192 x 192 three-stage kernel
     // (dctx 24.6 vs 26.9 us); from K = 2304 on the persistent kernel's k-loop wins (down 88 -> 81, dhn 74 -> 69, dxn 53 -> 51 us)

@@ -75,6 +75,16 @@ __device__ __forceinline__ void nt_aux_prefetch(AuxRegs<EPI, NI * 4 * MJ>& ax, i
                                                 const bf16_t* __restrict__ aux2, long ldaux2) {
   nt_aux_prefetch_l<EPI, NI, MJ>(ax, threadIdx.x & 63, mw, nw, M, N, aux, ldaux, aux2, ldaux2);
 }
+// Makes the compiler wait for the operand loads HERE (an empty asm that "uses" every register): placed before a block's first store,
+// so that the wait is a counted load wait and not the vmcnt(0) store drain a later first use would cost (see NtBias).
+template <int EPI, int CNT>
+__device__ __forceinline__ void nt_aux_touch(AuxRegs<EPI, CNT>& ax) {
+#pragma unroll
+  for (int i = 0; i < CNT; ++i) {
+    if (EPI == EPI_RESID || EPI == EPI_RESID2) asm volatile("" : "+v"(ax.r[i].x), "+v"(ax.r[i].y), "+v"(ax.r[i].z), "+v"(ax.r[i].w));
+    if (EPI == EPI_DGELU || EPI == EPI_DSILU || EPI == EPI_RESID2) asm volatile("" : "+v"(ax.h[i].x), "+v"(ax.h[i].y));
+  }
+}
 __device__ __forceinline__ float4 bf16x4_to_f32(uint2 r) {
   return make_float4(__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16), __uint_as_float(r.y & 0xffff0000u));
 }
@@ -93,9 +103,30 @@ __device__ __forceinline__ void nt_epi_stage(const f32x16 (&acc)[NI], unsigned c
       *reinterpret_cast<float4*>(stage + l31 * PITCH + ((i * 8 + ((2 * g + half) ^ (l31 & 7))) << 4)) =
           make_float4(acc[i][4 * g], acc[i][4 * g + 1], acc[i][4 * g + 2], acc[i][4 * g + 3]);
 }
+// The bias a lane needs while it drains a block: its column chunk c = (p*64 + lane) % CPR repeats with period CPR / gcd(64, CPR)
+// (1 for 16 / 32 chunks per row, 3 for 24), so 1 - 3 float4 loaded ONCE, before the wave's first store.  Why it matters: on gfx9
+// loads and stores share the vmcnt counter and hipcc must treat a counter with both kinds pending as out of order -- a bias load
+// issued after a store is waited for with vmcnt(0), i.e. every iteration of the drain loop waited for ALL earlier stores to
+// complete (visible in the ISA as `s_waitcnt vmcnt(0)` per iteration; measured r02: the dominant cost of the epilogues).
+template <int NI> struct NtBias {
+  static constexpr int CPR = NI * 8;
+  static constexpr int gcd_(int a, int b) { return b == 0 ? a : gcd_(b, a % b); }
+  static constexpr int PERIOD = CPR / gcd_(64, CPR);
+  float4 v[PERIOD];
+};
+template <int NI>
+__device__ __forceinline__ void nt_bias_preload(NtBias<NI>& b, const float* __restrict__ bias, int lane, int nw, int N) {
+#pragma unroll
+  for (int pp = 0; pp < NtBias<NI>::PERIOD; ++pp) {
+    const int c = (pp * 64 + lane) % NtBias<NI>::CPR, n = min(nw + c * 4, N - 4);
+    b.v[pp] = bias ? ld4(bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+#pragma unroll
+  for (int pp = 0; pp < NtBias<NI>::PERIOD; ++pp) asm volatile("" : "+v"(b.v[pp].x), "+v"(b.v[pp].y), "+v"(b.v[pp].z), "+v"(b.v[pp].w));
+}
 template <typename TO, int EPI, int NI, int AXJ, typename AX>
-__device__ __forceinline__ void nt_epi_drain(const AX& ax, const unsigned char* __restrict__ stage, int lane, int mb, int nw, int M, int N,
-                                             TO* __restrict__ C, long ldc, const float* __restrict__ bias, bf16_t* __restrict__ aux_out, long ldauxo) {
+__device__ __forceinline__ void nt_epi_drain(const AX& ax, const NtBias<NI>& bb, const unsigned char* __restrict__ stage, int lane, int mb, int nw, int M,
+                                             int N, TO* __restrict__ C, long ldc, bf16_t* __restrict__ aux_out, long ldauxo) {
   constexpr int CPR = NI * 8, PITCH = NI * 128;          // chunks / bytes per staged row
 #pragma unroll
   for (int p = 0; p < NI * 4; ++p) {
@@ -103,8 +134,8 @@ __device__ __forceinline__ void nt_epi_drain(const AX& ax, const unsigned char* 
     float4 v = *reinterpret_cast<const float4*>(stage + r * PITCH + (((c & ~7) | ((c ^ r) & 7)) << 4));
     const int m = mb + r, n = nw + c * 4;
     if (m >= M || n >= N) continue;
-    if (bias) {
-      const float4 bv = ld4(bias + n);
+    {
+      const float4 bv = bb.v[p % NtBias<NI>::PERIOD];
       v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
     }
     if (EPI == EPI_GELU) {
@@ -131,23 +162,23 @@ __device__ __forceinline__ void nt_epi_drain(const AX& ax, const unsigned char* 
   }
 }
 template <typename TO, int EPI, int NI, int AXJ, typename AX>
-__device__ __forceinline__ void nt_epi_block(const f32x16 (&acc)[NI], const AX& ax, unsigned char* __restrict__ stage, int mb, int nw, int M, int N,
-                                             TO* __restrict__ C, long ldc, const float* __restrict__ bias, bf16_t* __restrict__ aux_out, long ldauxo) {
+__device__ __forceinline__ void nt_epi_block(const f32x16 (&acc)[NI], const AX& ax, const NtBias<NI>& bb, unsigned char* __restrict__ stage, int mb, int nw,
+                                             int M, int N, TO* __restrict__ C, long ldc, bf16_t* __restrict__ aux_out, long ldauxo) {
   const int lane = threadIdx.x & 63;
   nt_epi_stage<NI>(acc, stage, lane);
-  nt_epi_drain<TO, EPI, NI, AXJ>(ax, stage, lane, mb, nw, M, N, C, ldc, bias, aux_out, ldauxo);
+  nt_epi_drain<TO, EPI, NI, AXJ>(ax, bb, stage, lane, mb, nw, M, N, C, ldc, aux_out, ldauxo);
 }
 
 template <int J, typename TO, int EPI, int NI, int MJ>
-__device__ __forceinline__ void nt_epilogue_j(const f32x16 (&acc)[NI][MJ], const AuxRegs<EPI, NI * 4 * MJ>& ax, unsigned char* __restrict__ stage, int mw,
-                                              int nw, int M, int N, TO* __restrict__ C, long ldc, const float* __restrict__ bias,
+__device__ __forceinline__ void nt_epilogue_j(const f32x16 (&acc)[NI][MJ], const AuxRegs<EPI, NI * 4 * MJ>& ax, const NtBias<NI>& bb,
+                                              unsigned char* __restrict__ stage, int mw, int nw, int M, int N, TO* __restrict__ C, long ldc,
                                               bf16_t* __restrict__ aux_out, long ldauxo) {
   if constexpr (J < MJ) {
     f32x16 a[NI];
 #pragma unroll
     for (int i = 0; i < NI; ++i) a[i] = acc[i][J];
-    nt_epi_block<TO, EPI, NI, J * NI * 4>(a, ax, stage, mw + J * 32, nw, M, N, C, ldc, bias, aux_out, ldauxo);
-    nt_epilogue_j<J + 1, TO, EPI, NI, MJ>(acc, ax, stage, mw, nw, M, N, C, ldc, bias, aux_out, ldauxo);
+    nt_epi_block<TO, EPI, NI, J * NI * 4>(a, ax, bb, stage, mw + J * 32, nw, M, N, C, ldc, aux_out, ldauxo);
+    nt_epilogue_j<J + 1, TO, EPI, NI, MJ>(acc, ax, bb, stage, mw, nw, M, N, C, ldc, aux_out, ldauxo);
   }
 }
 
@@ -155,7 +186,9 @@ template <typename TO, int EPI, int NI, int MJ>
 __device__ __forceinline__ void nt_epilogue(const f32x16 (&acc)[NI][MJ], const AuxRegs<EPI, NI * 4 * MJ>& ax, unsigned char* __restrict__ stage, int mw,
                                             int nw, int M, int N, TO* __restrict__ C, long ldc, const float* __restrict__ bias,
                                             bf16_t* __restrict__ aux_out, long ldauxo) {
-  nt_epilogue_j<0, TO, EPI, NI, MJ>(acc, ax, stage, mw, nw, M, N, C, ldc, bias, aux_out, ldauxo);
+  NtBias<NI> bb;                     // every load of the epilogue is issued before its first store (see NtBias)
+  nt_bias_preload<NI>(bb, bias, threadIdx.x & 63, nw, N);
+  nt_epilogue_j<0, TO, EPI, NI, MJ>(acc, ax, bb, stage, mw, nw, M, N, C, ldc, aux_out, ldauxo);
 }
 
 // XCD-aware tile order.  Blocks are dealt round-robin to the 8 XCDs (private 4 MB L2 each); remap so that every XCD owns a
@@ -186,3 +219,7 @@ void climb_nt256_set_grid(int v);       // workgroups launched at most (0 = one 
 // shapes it does not take (the caller then uses the 128 x 128 kernel)
 int climb_tnp_launch(const bf16_t* A, long lda, const bf16_t* B, long ldb, float* C, long ldc, int M, int N, int K, float* dbias, hipStream_t st);
 void climb_tnp_set_workspace(void* ptr, long bytes);
+// gemm_bf16_nt2p.hip: 128 x 192 tiles, TWO persistent 4-wave workgroups per CU (the epilogue of one runs under the k-loop of the other)
+int climb_nt2_launch(const bf16_t* A, long lda, const bf16_t* B, long ldb, void* C, long ldc, int c_dtype, int M, int N, int K, const float* bias, int epi,
+                     const void* aux, long ldaux, bf16_t* aux_out, long ldauxo, hipStream_t st);
+void climb_nt2_set_dephase(int units_of_64_clocks);

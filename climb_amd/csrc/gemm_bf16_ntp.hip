@@ -129,29 +129,37 @@ __device__ __forceinline__ void ntp_prologue(const NtpStage<NI>& sg, const bf16_
 // NIE*4 KB staging region; the residual / pre-activation operands of sub-block s + 1 are fetched while sub-block s drains.
 template <int NI> struct NtpEpi { static constexpr int NIE = NI == 4 ? 2 : NI, PER_ROW = NI / NIE, NSB = 2 * PER_ROW; };
 template <int S, typename TO, int EPI, int NI>
-__device__ __forceinline__ void ntp_epilogue(const f32x16 (&acc)[NI][2], AuxRegs<EPI, NtpEpi<NI>::NIE * 4> cur, bool first, unsigned char* __restrict__ stage,
-                                             int el, int mw, int nw, int M, int N, TO* __restrict__ C, long ldc, const float* __restrict__ bias,
-                                             const void* __restrict__ aux, long ldaux, bf16_t* __restrict__ aux_out, long ldauxo) {
+__device__ __forceinline__ void ntp_epilogue(const f32x16 (&acc)[NI][2], AuxRegs<EPI, NtpEpi<NI>::NIE * 4> (&ax)[NtpEpi<NI>::NSB],
+                                             NtBias<NtpEpi<NI>::NIE> (&bb)[NtpEpi<NI>::PER_ROW], unsigned char* __restrict__ stage, int el, int mw, int nw,
+                                             int M, int N, TO* __restrict__ C, long ldc, const float* __restrict__ bias, const void* __restrict__ aux,
+                                             long ldaux, bf16_t* __restrict__ aux_out, long ldauxo) {
   using E = NtpEpi<NI>;
   if constexpr (S < E::NSB) {
     constexpr int J = S / E::PER_ROW, H = S % E::PER_ROW;
-    if constexpr (S == 0) nt_aux_prefetch_l<EPI, E::NIE, 1>(cur, el, mw, nw, M, N, aux, ldaux, nullptr, 0);
+    if constexpr (S == 0) {
+      // no load may sit behind a store (see NtBias in gemm_bf16_nt.h): bias once; the operands of sub-block s + 1 are fetched after the
+      // accumulators of sub-block s were staged (registers) and waited for BEFORE sub-block s stores
+#pragma unroll
+      for (int h = 0; h < E::PER_ROW; ++h) nt_bias_preload<E::NIE>(bb[h], bias, el, nw + h * E::NIE * 32, N);
+      nt_aux_prefetch_l<EPI, E::NIE, 1>(ax[0], el, mw, nw, M, N, aux, ldaux, nullptr, 0);
+    }
     {
       f32x16 blk[E::NIE];
 #pragma unroll
       for (int i = 0; i < E::NIE; ++i) blk[i] = acc[H * E::NIE + i][J];
       nt_epi_stage<E::NIE>(blk, stage, el);
     }
-    __builtin_amdgcn_sched_barrier(0);      // order pinned: this sub-block's accumulators are dead before the next one's operands arrive
-    AuxRegs<EPI, E::NIE * 4> nxt;
+    __builtin_amdgcn_sched_barrier(0);
     if constexpr (S + 1 < E::NSB) {
       constexpr int J1 = (S + 1) / E::PER_ROW, H1 = (S + 1) % E::PER_ROW;
-      nt_aux_prefetch_l<EPI, E::NIE, 1>(nxt, el, mw + J1 * 32, nw + H1 * E::NIE * 32, M, N, aux, ldaux, nullptr, 0);
+      nt_aux_prefetch_l<EPI, E::NIE, 1>(ax[S + 1], el, mw + J1 * 32, nw + H1 * E::NIE * 32, M, N, aux, ldaux, nullptr, 0);
+      nt_aux_touch(ax[S + 1]);
     }
+    nt_aux_touch(ax[S]);
     __builtin_amdgcn_sched_barrier(0);
-    nt_epi_drain<TO, EPI, E::NIE, 0>(cur, stage, el, mw + J * 32, nw + H * E::NIE * 32, M, N, C, ldc, bias, aux_out, ldauxo);
+    nt_epi_drain<TO, EPI, E::NIE, 0>(ax[S], bb[H], stage, el, mw + J * 32, nw + H * E::NIE * 32, M, N, C, ldc, aux_out, ldauxo);
     __builtin_amdgcn_sched_barrier(0);
-    ntp_epilogue<S + 1, TO, EPI, NI>(acc, nxt, false, stage, el, mw, nw, M, N, C, ldc, bias, aux, ldaux, aux_out, ldauxo);
+    ntp_epilogue<S + 1, TO, EPI, NI>(acc, ax, bb, stage, el, mw, nw, M, N, C, ldc, bias, aux, ldaux, aux_out, ldauxo);
   }
 }
 
@@ -229,8 +237,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_ntp_kernel(const bf16_t* __rest
       // loop and kept in registers across the k-loop (measured: 27 spilled registers and a vmcnt(0) in the k-loop otherwise).
       int el = lane;
       asm volatile("" : "+v"(el));
-      ntp_epilogue<0, TO, EPI, NI>(acc, AuxRegs<EPI, NtpEpi<NI>::NIE * 4>(), true, smem + wid * (NtpEpi<NI>::NIE * 4096), el, m0 + wr * 64,
-                                   n0 + wc * (32 * NI), M, N, C, ldc, bias, aux, ldaux, aux_out, ldauxo);
+      NtBias<NtpEpi<NI>::NIE> bb[NtpEpi<NI>::PER_ROW];
+      AuxRegs<EPI, NtpEpi<NI>::NIE * 4> ax[NtpEpi<NI>::NSB];
+      ntp_epilogue<0, TO, EPI, NI>(acc, ax, bb, smem + wid * (NtpEpi<NI>::NIE * 4096), el, m0 + wr * 64, n0 + wc * (32 * NI), M, N, C, ldc, bias, aux,
+                                   ldaux, aux_out, ldauxo);
     }
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();       // the staging regions are the next tile's k-tile buffers

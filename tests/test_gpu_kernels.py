@@ -326,10 +326,10 @@ def test_gemm_bf16_nt(M, N, K):
     assert _rel(C16.float(), ur.grad) < 5e-3
 
 
-@pytest.mark.parametrize("force", [2, 3])
+@pytest.mark.parametrize("force", [2, 3, 4])
 @pytest.mark.parametrize("M,N,K", [(256, 256, 128), (300, 328, 192), (1000, 2304, 768), (512, 3072, 768), (256, 768, 3072), (777, 512, 2304)])
 def test_gemm_bf16_nt_256_tiles(M, N, K, force):
-    """The persistent 256 x 256 (option 7 = 2) / 256 x 192 (= 3) counted-vmcnt kernel forced on at shapes that walk its edges: the
+    """The persistent 256 x 256 (option 7 = 2) / 256 x 192 (= 3) / two-workgroup 128 x 192 (= 4) counted-vmcnt kernels forced on at shapes that walk its edges: the
     minimum of two k-tiles, an odd k-tile count, ragged last row / column tiles, every epilogue it implements, both output types --
     against float64 of the same bf16-rounded operands."""
     from climb_amd import _lib
@@ -360,7 +360,7 @@ def test_gemm_bf16_nt_256_tiles(M, N, K, force):
         _lib.call("climb_set_option", 7, 1)
 
 
-@pytest.mark.parametrize("force", [2, 3])
+@pytest.mark.parametrize("force", [2, 3, 4])
 @pytest.mark.parametrize("N,K", [(2304, 768), (3072, 768), (768, 3072)])
 def test_gemm_bf16_nt_256_race_screen_full_size(N, K, force):
     """Benchmark-size launches (M = 12288: every CU busy, several rounds) of the 256 x 256 kernel, repeated: its LDS-DMA /

@@ -30,6 +30,8 @@ if __name__ == "__main__":
         _lib.call("climb_set_option", 7, int(os.environ["NT256"]))
     if os.environ.get("NT256_GRID") is not None:
         _lib.call("climb_set_option", 9, int(os.environ["NT256_GRID"]))
+    if os.environ.get("DEPHASE") is not None:
+        _lib.call("climb_set_option", 11, int(os.environ["DEPHASE"]))
     if os.environ.get("TNP") is not None:
         _lib.call("climb_set_option", 10, int(os.environ["TNP"]))
     if os.environ.get("NT192") is not None:
