@@ -99,7 +99,13 @@ def main():
     eng = model._host.engine()
     dominant = "gemm_bf16_nt" if args.precision == "bf16" else "gemm_f32"
     prof = {"kernel": dominant, "events": []}
-    prof_every = 4          # HIP-event pairs around the dominant kernel on every 4th timed step (each pair costs ~4 us of stream time)
+    prof_every = 10         # HIP-event pairs around every launch of the dominant kernel on every 10th timed step (an instrumented step costs
+    #                         +0.6 ms: 97 launches x 2 event records), created and recorded once BEFORE the timed region (event creation inside it
+    #                         showed up as a 4 - 38 ms outlier step)
+    n_prof_steps = (args.steps + prof_every - 1) // prof_every
+    prof["pool"] = [torch.cuda.Event(enable_timing=True) for _ in range(2 * 128 * n_prof_steps)]
+    for ev in prof["pool"]:
+        ev.record()
 
     def fence():
         if world > 1:
@@ -117,7 +123,10 @@ def main():
     eng.prof = None
     fence()
     dt = time.perf_counter() - t0
-    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    step_ms_seq = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
+    if os.environ.get("CLIMB_AMD_BENCH_STEPS"):
+        print("per-step ms:", " ".join(f"{v:.2f}" for v in step_ms_seq), file=sys.stderr)
+    step_ms = sorted(step_ms_seq)
     # data parallel: the same K steps again with the collectives deferred to after the backward (or overlapped, if the default was
     # deferred), so that one multi-GPU run answers whether overlap pays on this fabric
     dp_ab = None
@@ -141,7 +150,6 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     events = prof["events"]
-    n_prof_steps = (args.steps + prof_every - 1) // prof_every
     in_sync = ddp.replicas_in_sync() if ddp is not None else True
 
     if rank == 0:

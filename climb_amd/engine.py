@@ -345,7 +345,11 @@ class ViltEngine:
     def _timed_call(self, kernel, flops, name, *args):
         prof = self.prof
         if prof is not None and prof["kernel"] == kernel:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            pool = prof.get("pool")            # pre-created events: creating hundreds inside a timed region costs milliseconds now and then
+            if pool:
+                e0, e1 = pool.pop(), pool.pop()
+            else:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             _lib.call(name, *args)
             e1.record()
