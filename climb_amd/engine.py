@@ -144,6 +144,7 @@ class ViltEngine:
         self._shadow_stale = False
         self._ewc_ws = None
         self._bce_ws = None
+        self._head_ws: Dict[tuple, dict] = {}
         self.requires_grad: Dict[str, bool] = {n: True for n in layout.shapes}
         self.grad_ready_hook: Optional[Callable[[int, int], None]] = None   # (lo, hi) flat range whose grads are final
         self.touched: List[tuple] = []                  # flat ranges that received gradients in the last backward
@@ -643,7 +644,31 @@ class ViltEngine:
             _lib.call("climb_colreduce", ws.part2, 2 * H, T, self.g(te + "token_type_embeddings.weight"), 2 * H, 1.0, st)
 
     # ------------------------------------------------------------------ task heads (fp32; REF/modeling/vilt.py:179-203)
-    def head_forward(self, task_key: str, pooled_in: torch.Tensor, training: bool, keep_mask: Optional[torch.Tensor] = None):
+    def _head_buffers(self, task_key: str, Bh: int, reuse: bool):
+        """Scratch of the classification head and the loss for `Bh` rows.  `reuse` (the fused step: forward, loss and backward in one call)
+        takes them from a per-(task, rows) cache -- no allocation in the step; the autograd-facing path gets fresh
+        tensors, because its forward's buffers must survive until an unrelated backward."""
+        key = (task_key, Bh)
+        hb = self._head_ws.get(key) if reuse else None
+        if hb is None:
+            tc = self.task_cfgs[task_key]
+            H, dev, f32 = self.cfg["hidden"], self.device, torch.float32
+            D, NL = 2 * H, tc["num_labels"]
+            ldl = _round_up(NL, 4)          # 16-byte aligned rows so the head GEMMs take the vector load paths (3129 -> 3132)
+            lnb = _lib.query("climb_layernorm_bwd_rows_per_block")
+            hb = dict(z=torch.empty((Bh, D), dtype=f32, device=dev), zn=torch.empty((Bh, D), dtype=f32, device=dev), gz=torch.empty((Bh, D), dtype=f32, device=dev),
+                      mean=torch.empty((Bh,), dtype=f32, device=dev), rstd=torch.empty((Bh,), dtype=f32, device=dev),
+                      logits=torch.zeros((Bh, ldl), dtype=f32, device=dev), dlogits=torch.zeros((Bh, ldl), dtype=f32, device=dev),
+                      dg=torch.empty((Bh, D), dtype=f32, device=dev), dzn=torch.empty((Bh, D), dtype=f32, device=dev), dz=torch.empty((Bh, D), dtype=f32, device=dev),
+                      part=torch.empty((((Bh + lnb - 1) // lnb) * 3 * D,), dtype=f32, device=dev), dx=torch.empty((Bh, tc.get("num_images", 1) * H), dtype=f32, device=dev),
+                      ones=torch.ones((max(Bh, 8),), dtype=f32, device=dev), loss=torch.empty((), dtype=f32, device=dev))
+            if reuse:
+                if len(self._head_ws) >= 8:
+                    self._head_ws.pop(next(iter(self._head_ws)))
+                self._head_ws[key] = hb
+        return hb
+
+    def head_forward(self, task_key: str, pooled_in: torch.Tensor, training: bool, keep_mask: Optional[torch.Tensor] = None, reuse: bool = False):
         tc = self.task_cfgs[task_key]
         H = self.cfg["hidden"]
         st = _stream()
@@ -654,13 +679,10 @@ class ViltEngine:
         if tc["model_type"] == "classification":
             Bh, Kin = pooled_in.shape
             D, NL = 2 * H, tc["num_labels"]
-            hs.z = torch.empty((Bh, D), dtype=torch.float32, device=dev)
-            hs.zn = torch.empty_like(hs.z)
-            hs.gz = torch.empty_like(hs.z)
-            hs.mean = torch.empty((Bh,), dtype=torch.float32, device=dev)
-            hs.rstd = torch.empty_like(hs.mean)
-            ldl = _round_up(NL, 4)          # 16-byte aligned rows so the head GEMMs take the vector load paths (3129 -> 3132)
-            hs.logits = torch.zeros((Bh, ldl), dtype=torch.float32, device=dev)[:, :NL]
+            hb = hs.buf = self._head_buffers(task_key, Bh, reuse)
+            hs.z, hs.zn, hs.gz, hs.mean, hs.rstd = hb["z"], hb["zn"], hb["gz"], hb["mean"], hb["rstd"]
+            ldl = _round_up(NL, 4)
+            hs.logits = hb["logits"][:, :NL]
             self._gemm_f32(pooled_in, Kin, 1, self.p(h + "0.weight"), Kin, 1, hs.z, D, Bh, D, Kin, self.p(h + "0.bias"))
             _lib.call("climb_layernorm_fwd", hs.z, D, self.p(h + "1.weight"), self.p(h + "1.bias"), self.cfg["head_ln_eps"], hs.zn, D, F32,
                       hs.mean, hs.rstd, Bh, D, st)
@@ -691,24 +713,24 @@ class ViltEngine:
         h = f"task_layer.{task_key}."
         rg = self.requires_grad
         dev = self.device
-        ones = torch.ones((max(dlogits.shape[0] * (dlogits.shape[1] if tc["model_type"] != "classification" else 1), 8),),
-                          dtype=torch.float32, device=dev)
         if tc["model_type"] == "classification":
             Bh, Kin = hs.x.shape
             D, NL = 2 * H, tc["num_labels"]
             ldl = dlogits.stride(0)
+            hb = hs.buf
+            ones = hb["ones"]
             if rg[h + "3.weight"]:
                 self._gemm_f32(dlogits, 1, ldl, hs.gz, 1, D, self.g(h + "3.weight"), D, NL, D, Bh, beta=1.0)
             if rg[h + "3.bias"]:
                 self._gemm_f32(dlogits, 1, ldl, ones, 0, 1, self.g(h + "3.bias"), 1, NL, 1, Bh, beta=1.0)
-            dg = torch.empty((Bh, D), dtype=torch.float32, device=dev)
+            dg = hb["dg"]
             self._gemm_f32(dlogits, ldl, 1, self.p(h + "3.weight"), 1, D, dg, D, Bh, D, NL)
-            dzn = torch.empty_like(dg)
+            dzn = hb["dzn"]
             _lib.call("climb_elementwise", 1, dg, hs.zn, dzn, Bh * D, 1.0, st)
-            dz = torch.empty_like(dg)
+            dz = hb["dz"]
             lnb = _lib.query("climb_layernorm_bwd_rows_per_block")
             nb = (Bh + lnb - 1) // lnb
-            part = torch.empty((nb * 3 * D,), dtype=torch.float32, device=dev)
+            part = hb["part"]
             _lib.call("climb_layernorm_bwd", dzn, D, F32, hs.z, D, hs.mean, hs.rstd, self.p(h + "1.weight"), None, 0, dz, D, None, 0, part, Bh, D, st)
             self.bias_grad_from_part(part.data_ptr(), 3 * D, nb, h + "1.weight", D)
             self.bias_grad_from_part(part.data_ptr() + 4 * D, 3 * D, nb, h + "1.bias", D)
@@ -716,12 +738,13 @@ class ViltEngine:
                 self._gemm_f32(dz, 1, D, hs.x, 1, Kin, self.g(h + "0.weight"), Kin, D, Kin, Bh, beta=1.0)
             if rg[h + "0.bias"]:
                 self._gemm_f32(dz, 1, D, ones, 0, 1, self.g(h + "0.bias"), 1, D, 1, Bh, beta=1.0)
-            dx = torch.empty((Bh, Kin), dtype=torch.float32, device=dev)
+            dx = hb["dx"]
             self._gemm_f32(dz, D, 1, self.p(h + "0.weight"), 1, Kin, dx, Kin, Bh, Kin, D)
             self._ready(*self.layout.head_range[task_key])
             return dx
         b, nc = dlogits.shape
         n = b * nc
+        ones = torch.ones((max(n, 8),), dtype=torch.float32, device=dev)
         dl = dlogits.reshape(n, 1)
         if rg[h + "1.weight"]:
             self._gemm_f32(dl, 1, 1, hs.xd, 1, H, self.g(h + "1.weight"), H, 1, H, n, beta=1.0)
@@ -735,12 +758,18 @@ class ViltEngine:
         return dx.view(b, nc, H)
 
     # ------------------------------------------------------------------ losses
-    def loss_and_grad(self, task_key: str, logits: torch.Tensor, target: torch.Tensor, gscale: float = 1.0):
-        """VQA: BCEWithLogits(mean)*num_labels (REF train_vqa.py:155-157); others: CrossEntropyLoss (train_nlvr2.py:80)."""
+    def loss_and_grad(self, task_key: str, logits: torch.Tensor, target: torch.Tensor, gscale: float = 1.0, hs: Optional["HeadState"] = None):
+        """VQA: BCEWithLogits(mean)*num_labels (REF train_vqa.py:155-157); others: CrossEntropyLoss (train_nlvr2.py:80).  With the head
+        state of a fused step the loss scalar and dlogits live in its cached buffers (the padding columns of dlogits were zeroed at
+        allocation and are never written)."""
         st = _stream()
-        loss = torch.empty((), dtype=torch.float32, device=self.device)
         Bh, NL = logits.shape
-        dlogits = torch.zeros((Bh, logits.stride(0)), dtype=torch.float32, device=self.device)[:, :NL]      # same padded rows as logits
+        hb = getattr(hs, "buf", None) if hs is not None else None
+        if hb is not None and "dlogits" in hb and hb["dlogits"].shape == (Bh, logits.stride(0)):
+            loss, dlogits = hb["loss"], hb["dlogits"][:, :NL]
+        else:
+            loss = torch.empty((), dtype=torch.float32, device=self.device)
+            dlogits = torch.zeros((Bh, logits.stride(0)), dtype=torch.float32, device=self.device)[:, :NL]      # same padded rows as logits
         if task_key == "vqa":
             if self._bce_ws is None:
                 self._bce_ws = torch.empty((_lib.query("climb_bce_workspace_floats"),), dtype=torch.float32, device=self.device)

@@ -541,11 +541,11 @@ class ViltContinualLearner(ContinualLearner):
         pooled_seq = eng.encoder_forward(enc.get("input_ids"), enc["token_type_ids"], enc["attention_mask"], enc["pixel_values"], img_type,
                                          pixel_mask=enc.get("pixel_mask"), inputs_embeds=enc.get("inputs_embeds"))
         pooled = self._shape_pooled(pooled_seq, kind)
-        logits, hs = eng.head_forward(task_key, pooled, self.training, dropout_keep)
+        logits, hs = eng.head_forward(task_key, pooled, self.training, dropout_keep, reuse=True)
         target = target.to(eng.device, non_blocking=True)
         if task_key == "vqa":
             target = target.float()
-        loss, dlogits = eng.loss_and_grad(task_key, logits, target)
+        loss, dlogits = eng.loss_and_grad(task_key, logits, target, hs=hs)
         dpool = eng.head_backward(hs, dlogits)
         first, emb = host.frozen_prefix()
         if host.any_encoder_grad() is not None:
@@ -556,8 +556,8 @@ class ViltContinualLearner(ContinualLearner):
         if ewc is not None and ewc.do_ewc():
             ewc_task, ewc_loss = ewc.add_penalty_gradient(self)
         host.after_backward()
-        # `pooled` is a view of the workspace the next step overwrites: hand the caller its own copy (49 K floats)
-        return loss, (pooled.clone(), logits), ewc_task, ewc_loss
+        # `pooled`, `logits` and `loss` live in buffers the next step overwrites: hand the caller its own copies (a few hundred KB)
+        return loss.clone(), (pooled.clone(), logits.clone()), ewc_task, ewc_loss
 
     # --- the same step captured once into a hipGraph and replayed: the ~330 kernel launches of a step become one graph launch
     # (HIP streams and graphs instead of a tracing compiler).  Inputs are copied into static buffers; the returned tensors are
