@@ -6,13 +6,26 @@
 // One workgroup per (batch, head); S <= 288 keys means a whole head's K and V (S_pad x 64 bf16 = 24.6 KB each at
 // S_pad = 192) are LDS-resident: single pass over HBM, the S x S scores never leave the CU.
 //
-// LDS image of every [rows][64] operand: 128-B rows, 16-B chunks XOR-swizzled by swz(row).  It is read two ways:
+// LDS image of every [rows][64] operand: 128-B rows, 16-B chunks XOR-swizzled by swz(row); the two operands of a kernel (K and V, or Q
+// and dO) are interleaved by 32-row block -- block ib = 8 KB: X rows, then Y rows -- so one set of per-lane addresses serves both
+// (Y = X + 4096, an immediate offset).  It is read two ways:
 //   * "row" fragments (8 consecutive d of one row)      -> ds_read_b128, conflict-free
 //   * "column" fragments (4 consecutive rows at one d)  -> ds_read_b64_tr_b16 (LDS transpose read), conflict-free
 // so K serves both S^T = K Q^T and dQ^T = K^T dS^T from one image, likewise V, Q, dO.
 #include "common.h"
 
 #define AB_D 64
+// measurement builds only (tools/attn_probe.sh): 1 = skip the inner-loop arithmetic, 2 = skip the staging stream, 4 = skip the output stores
+#ifndef AB_PROBE
+#define AB_PROBE 0
+#endif
+#ifdef AB_TRACE          // measurement builds only: wave 0 of every forward workgroup logs wall-clock stamps (100 MHz) into a host-provided buffer
+__device__ unsigned long long* ab_trace_buf;
+extern "C" int climb_attn_set_trace(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(ab_trace_buf), &p, sizeof(p)); }
+#define AB_STAMP(i) do { if (tid == 0) ab_trace_buf[(long)blockIdx.x * 16 + (i)] = wall_clock64(); } while (0)
+#else
+#define AB_STAMP(i) do {} while (0)
+#endif
 
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
@@ -28,43 +41,82 @@ __device__ __forceinline__ bf16x8 to_bf16x8(u32x4 v) {
 }
 __device__ __forceinline__ int crow(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 
-// stage rows [0, nrows) x 64 bf16 of a strided global matrix into the swizzled LDS image with LDS-DMA
-// (global_load_lds_dwordx4: asynchronous, no VGPRs, no ds_write pass; the destination is linear per wave-instruction, so
-// the swizzle goes on the per-lane SOURCE address).  nrows is a multiple of 8; the caller's __syncthreads() drains vmcnt.
 typedef __attribute__((address_space(3))) void lds_void_t;
-typedef __attribute__((address_space(1))) const void gbl_void_t;
-__device__ __forceinline__ void stage_image(unsigned char* __restrict__ S, const bf16_t* __restrict__ src, long ld, int nrows, int tid, int nthreads) {
-  const int lane = tid & 63, wave = tid >> 6, nwaves = nthreads >> 6;
-  for (int j = wave; j < nrows / 8; j += nwaves) {
-    const int slot = j * 64 + lane, row = slot >> 3, c = (slot & 7) ^ aswz(row);
-    __builtin_amdgcn_global_load_lds((gbl_void_t*)(src + (long)row * ld + c * 8), (lds_void_t*)(S + j * 1024), 16, 0, 0);
-  }
-}
-// row fragment: image row (row0 + lane&31), d = 16*ks + 8*(lane>>5) .. +7
-__device__ __forceinline__ bf16x8 row_frag(const unsigned char* __restrict__ S, int row0, int ks, int lane) {
-  const int row = row0 + (lane & 31), c = 2 * ks + (lane >> 5);
+#define AB_BLK 8192          // LDS bytes per 32-row block: X half, Y half
+#define AB_Y 4096
+// row fragment: row (lane&31) of the 32-row half-block at S, d = 16*ks + 8*(lane>>5) .. +7
+__device__ __forceinline__ bf16x8 row_frag(const unsigned char* S, int ks, int lane) {
+  const int row = lane & 31, c = 2 * ks + (lane >> 5);
   return to_bf16x8(*reinterpret_cast<const u32x4*>(S + row * 128 + ((c ^ aswz(row)) << 4)));
 }
-// column fragment for output index d = d0 + (lane&31): rows r0 + 4*half + {0..3} and r0 + 8 + 4*half + {0..3}
-// (exactly the rows whose P / dS values a lane holds in accumulator registers 8s..8s+7 of a 32x32 block)
-__device__ __forceinline__ bf16x8 col_frag(const unsigned char* __restrict__ S, int r0, int d0, int lane) {
+// The four column fragments of one 32-row block (st = 0, 1: rows r0 .. +15 / r0 + 16 .. +31; d0 = 0, 32) in ONE asm statement with its own
+// lgkmcnt(0).  Used while the staging stream is in flight: hipcc orders every LDS access it cannot prove independent behind pending LDS
+// DMA with a vmcnt(0), the transpose-read builtin carries no alias information to prove anything with, and an asm read is invisible to
+// that bookkeeping.  (row + 16 keeps the swizzle, so st = 1 is the immediate offset 2048.)
+struct ColAddr { unsigned a0, b0, a32, b32; };      // LDS byte addresses of the (rowa, rowb) x (d0 = 0, 32) reads for the X half of block 0
+__device__ __forceinline__ ColAddr col_addr(const unsigned char* S, int lane) {
   const int g16 = lane >> 4, i = lane & 15;
-  const int col = d0 + (g16 & 1) * 16 + 4 * (i & 3);      // first of this lane's 4 contiguous d (8 bytes inside one 16-B chunk)
-  const int c = col >> 3, within = (col & 7) * 2;
-  const int rowa = r0 + 4 * (g16 >> 1) + (i >> 2), rowb = rowa + 8;
-  s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(S + rowa * 128 + ((c ^ aswz(rowa)) << 4) + within));
-  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(S + rowb * 128 + ((c ^ aswz(rowb)) << 4) + within));
-  union { s16x4 h[2]; bf16x8 b; } u;
-  u.h[0] = lo;
-  u.h[1] = hi;
-  return u.b;
+  const int rowa = 4 * (g16 >> 1) + (i >> 2), rowb = rowa + 8;
+  const unsigned base = (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char*)S;
+  ColAddr r;
+#pragma unroll
+  for (int dd = 0; dd < 2; ++dd) {
+    const int col = dd * 32 + (g16 & 1) * 16 + 4 * (i & 3), c = col >> 3, within = (col & 7) * 2;
+    const unsigned a = base + rowa * 128 + ((c ^ aswz(rowa)) << 4) + within, bb = base + rowb * 128 + ((c ^ aswz(rowb)) << 4) + within;
+    if (dd == 0) { r.a0 = a; r.b0 = bb; } else { r.a32 = a; r.b32 = bb; }
+  }
+  return r;
 }
-// 8 fp32 accumulator registers (8s..8s+7 of a block) -> bf16x8 MFMA operand
-__device__ __forceinline__ bf16x8 pack8(const f32x16& v, int s) {
+// f[st][dd]; Y = 0 / 1: the block's X / Y half
+template <int Y>
+__device__ __forceinline__ void col_frags4(bf16x8 (&f)[2][2], const ColAddr& ca, int blk) {
+  const unsigned o = blk * AB_BLK;
+  const unsigned a0 = ca.a0 + o, b0 = ca.b0 + o, a32 = ca.a32 + o, b32 = ca.b32 + o;
+  s16x4 l00, h00, l01, h01, l10, h10, l11, h11;
+  asm volatile(
+      "ds_read_b64_tr_b16 %0, %8 offset:%12\n\t"
+      "ds_read_b64_tr_b16 %1, %9 offset:%12\n\t"
+      "ds_read_b64_tr_b16 %2, %10 offset:%12\n\t"
+      "ds_read_b64_tr_b16 %3, %11 offset:%12\n\t"
+      "ds_read_b64_tr_b16 %4, %8 offset:%13\n\t"
+      "ds_read_b64_tr_b16 %5, %9 offset:%13\n\t"
+      "ds_read_b64_tr_b16 %6, %10 offset:%13\n\t"
+      "ds_read_b64_tr_b16 %7, %11 offset:%13\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&v"(l00), "=&v"(h00), "=&v"(l01), "=&v"(h01), "=&v"(l10), "=&v"(h10), "=&v"(l11), "=&v"(h11)
+      : "v"(a0), "v"(b0), "v"(a32), "v"(b32), "n"(Y * AB_Y), "n"(Y * AB_Y + 2048)
+      : "memory");
+  union { s16x4 h[2]; bf16x8 b; } u;
+  u.h[0] = l00; u.h[1] = h00; f[0][0] = u.b;
+  u.h[0] = l01; u.h[1] = h01; f[0][1] = u.b;
+  u.h[0] = l10; u.h[1] = h10; f[1][0] = u.b;
+  u.h[0] = l11; u.h[1] = h11; f[1][1] = u.b;
+}
+// bf16 pairs 4 st .. 4 st + 3 (accumulator registers 8 st .. 8 st + 7 of a block) as the MFMA operand of k-step st
+__device__ __forceinline__ bf16x8 packed4(const unsigned int (&v)[8], int st) {
   union { unsigned int u[4]; bf16x8 b; } c;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) c.u[j] = pack_bf16x2(v[8 * s + 2 * j], v[8 * s + 2 * j + 1]);
+  for (int j = 0; j < 4; ++j) c.u[j] = v[4 * st + j];
   return c.b;
+}
+// the two fragments (d0 = 0, 32) of k-step st only: half the registers, for the kernel that has none to spare
+template <int Y, int ST>
+__device__ __forceinline__ void col_frags2(bf16x8 (&f)[2], const ColAddr& ca, int blk) {
+  const unsigned o = blk * AB_BLK;
+  const unsigned a0 = ca.a0 + o, b0 = ca.b0 + o, a32 = ca.a32 + o, b32 = ca.b32 + o;
+  s16x4 l0, h0, l1, h1;
+  asm volatile(
+      "ds_read_b64_tr_b16 %0, %4 offset:%8\n\t"
+      "ds_read_b64_tr_b16 %1, %5 offset:%8\n\t"
+      "ds_read_b64_tr_b16 %2, %6 offset:%8\n\t"
+      "ds_read_b64_tr_b16 %3, %7 offset:%8\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&v"(l0), "=&v"(h0), "=&v"(l1), "=&v"(h1)
+      : "v"(a0), "v"(b0), "v"(a32), "v"(b32), "n"(Y * AB_Y + ST * 2048)
+      : "memory");
+  union { s16x4 h[2]; bf16x8 b; } u;
+  u.h[0] = l0; u.h[1] = h0; f[0] = u.b;
+  u.h[0] = l1; u.h[1] = h1; f[1] = u.b;
 }
 // this lane's B operand for a 32-row register block: row (row0 + lane&31) of a global [.,64] bf16 matrix, 4 k-steps
 __device__ __forceinline__ void load_rows(bf16x8 (&f)[4], const bf16_t* __restrict__ src, long ld, int row0, int lane) {
@@ -72,103 +124,304 @@ __device__ __forceinline__ void load_rows(bf16x8 (&f)[4], const bf16_t* __restri
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) f[ks] = to_bf16x8(*reinterpret_cast<const u32x4*>(p + 16 * ks));
 }
-// O^T-style accumulator (col = row index of the output matrix, rows = d) -> 4 consecutive d per register group
+// O^T-style accumulator (col = row index of the output matrix, rows = d): a lane owns 4 consecutive d per register group, and its
+// partner lane (xor 32) owns the 4 next to them.  The pair trades groups (v_permlane32_swap) so every lane stores 16 contiguous
+// bytes and a store instruction covers each row with 32-byte pieces instead of 16-byte ones.
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 __device__ __forceinline__ void store_acc(bf16_t* __restrict__ dst, const f32x16 (&o)[2], int half, float scale) {
 #pragma unroll
   for (int d = 0; d < 2; ++d)
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
-      st4(dst + d * 32 + 8 * g + 4 * half,
-          make_float4(o[d][4 * g] * scale, o[d][4 * g + 1] * scale, o[d][4 * g + 2] * scale, o[d][4 * g + 3] * scale));
+    for (int gp = 0; gp < 2; ++gp) {
+      const int g0 = 8 * gp, g1 = 8 * gp + 4;
+      const u32x2 r0 = __builtin_amdgcn_permlane32_swap(pack_bf16x2(o[d][g0] * scale, o[d][g0 + 1] * scale),
+                                                        pack_bf16x2(o[d][g1] * scale, o[d][g1 + 1] * scale), false, false);
+      const u32x2 r1 = __builtin_amdgcn_permlane32_swap(pack_bf16x2(o[d][g0 + 2] * scale, o[d][g0 + 3] * scale),
+                                                        pack_bf16x2(o[d][g1 + 2] * scale, o[d][g1 + 3] * scale), false, false);
+      u32x4 v;
+      v.x = r0.x; v.y = r1.x; v.z = r0.y; v.w = r1.y;
+      *reinterpret_cast<u32x4*>(dst + d * 32 + 8 * (2 * gp + half)) = v;
+    }
+}
+// sum / max over the two lanes (xor 32) that share a matrix column
+__device__ __forceinline__ float pair_max(float x) {
+  const u32x2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return fmaxf(__uint_as_float(r.x), __uint_as_float(r.y));
+}
+__device__ __forceinline__ float pair_sum(float x) {
+  const u32x2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float(r.x) + __uint_as_float(r.y);
 }
 
+// ------------------------------------------------------------------------------------------------------ streamed staging
+// The two LDS images of a workgroup are consumed in 32-row blocks by the inner loop, so they are STREAMED: every wave issues its
+// share of both images in block order (unit = 8 rows = one 1-KB wave-instruction; wave w owns units w, w + NW, ...: a "round"; the X and
+// Y unit of a round go out back to back), and before block ib a wave waits only until the loads of LATER blocks are the ones still
+// outstanding (counted vmcnt) -- the raw s_barrier that follows makes every wave's share of the block visible.  The first MFMA starts
+// when 1/NB of the data has arrived instead of all of it; with every workgroup of the launch in lock step that is the difference between
+// "load, then compute" and the two overlapped.
+#define AB_LOG2E 1.44269504088896340736f
+#define AB_LN2 0.69314718055994530942f
+#define AB_NEG (-3.0e38f)
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+template <int N> __device__ __forceinline__ void ab_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void ab_wait_vm_pairs(int pairs) {      // at most 2 * pairs loads outstanding; `pairs` is wave-uniform
+  switch (pairs) {
+    case 0: ab_wait_vm<0>(); break;
+    case 1: ab_wait_vm<2>(); break;
+    case 2: ab_wait_vm<4>(); break;
+    case 3: ab_wait_vm<6>(); break;
+    case 4: ab_wait_vm<8>(); break;
+    case 5: ab_wait_vm<10>(); break;
+    case 6: ab_wait_vm<12>(); break;
+    default: ab_wait_vm<14>(); break;
+  }
+}
+__device__ __forceinline__ void negate_rows(bf16x8 (&f)[4]) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    union { bf16x8 b; u32x4 u; } c;
+    c.b = f[k];
+    c.u ^= 0x80008000u;
+    f[k] = c.b;
+  }
+}
+// pins hipcc's s_waitcnt for register loads to this point
+__device__ __forceinline__ void use_rows(bf16x8 (&f)[4]) { asm volatile("" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3])); }
+// The DMA is the MUBUF form (buffer_load_dwordx4 ... lds), not global_load_lds: hipcc books a FLAT-encoded LDS load as "pending flat" and
+// then drains vmcnt to 0 for ANY register load that is waited on while one is in flight; buffer loads are counted exactly.
+//
+// Issue order.  Asking for everything at once (all rounds up front, every workgroup of the launch at the same moment) puts ~60 MB in
+// flight and the FIRST data a wave needs -- its Q rows, block 0 -- arrives after 5-8 us of queueing (tools/attn_trace.py).  So only
+// AB_PRO rounds go out before the loop (compile-time count: hipcc's own vmcnt arithmetic for the register loads stays exact) and the
+// rest are topped up inside it, two blocks ahead of the one being computed.
+#define AB_PRO 3
+struct Streamer {
+  __amdgpu_buffer_rsrc_t rx, ry;
+  unsigned char* Ls;
+  int ldx2, ldy2, nunits, wave, nwaves, lane;      // row strides in bytes
+  int issued, need, cover, total;                  // rounds issued / rounds block `ib` needs / units those cover / rounds there are
+
+  __device__ __forceinline__ void init(unsigned char* ls, const bf16_t* Xg, long ldx, const bf16_t* Yg, long ldy, int nunits_, int wave_,
+                                       int nwaves_, int lane_) {
+    rx = __builtin_amdgcn_make_buffer_rsrc((void*)Xg, 0, 0x7fffffff, 0x00020000);
+    ry = __builtin_amdgcn_make_buffer_rsrc((void*)Yg, 0, 0x7fffffff, 0x00020000);
+    Ls = ls; ldx2 = (int)ldx * 2; ldy2 = (int)ldy * 2; nunits = nunits_; wave = wave_; nwaves = nwaves_; lane = lane_;
+    issued = need = cover = 0;
+    total = (nunits + nwaves - 1) / nwaves;        // >= 4 >= AB_PRO for every launch shape of this file
+  }
+  // round r: unit wave + r * nwaves of both images (past the end: the last unit again -- same bytes to the same place)
+  __device__ __forceinline__ void round(int r) {
+    int j = wave + r * nwaves;
+    j = j < nunits ? j : nunits - 1;
+    const int slot = j * 64 + lane, row = slot >> 3, c = (slot & 7) ^ aswz(row);
+    unsigned char* dst = Ls + (j >> 2) * AB_BLK + (j & 3) * 1024;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void_t*)dst, 16, row * ldx2 + c * 16, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(ry, (lds_void_t*)(dst + AB_Y), 16, row * ldy2 + c * 16, 0, 0, 0);
+  }
+  __device__ __forceinline__ void prologue() {
+#pragma unroll
+    for (int r = 0; r < AB_PRO; ++r) round(r);
+    issued = AB_PRO;
+  }
+  // before block ib is read: wait until only rounds block ib does not need are outstanding (block ib = units 4 ib .. 4 ib + 3, whole once
+  // every wave has landed ceil(4 (ib + 1) / NW) rounds), make that visible, then top the stream up to what block ib + 2 needs
+  __device__ __forceinline__ void block(int ib) {
+    while (cover < 4 * (ib + 1) && need < total) { cover += nwaves; ++need; }
+    while (issued < need) round(issued++);         // (only if AB_PRO were too small for block 0)
+    ab_wait_vm_pairs(issued - need);
+    __builtin_amdgcn_s_barrier();
+    int need2 = need, cover2 = cover;
+    while (cover2 < 4 * (ib + 3) && need2 < total) { cover2 += nwaves; ++need2; }
+    while (issued < need2) round(issued++);
+  }
+};
+// Two things keep hipcc from draining vmcnt to 0 in front of a ds_read while DMAs are in flight (SIInsertWaitcnts orders LDS reads
+// behind LDS DMA unless alias information says otherwise): no __restrict__ on anything that touches LDS here (its alias scopes make
+// every DMA a tracked store the read "may alias"), and every LDS read is a typed vector load (carries TBAA; a HIP float4 struct copy
+// carries none and gets the conservative wait).
+// a float vector (key bias, lse, delta) of n elements into LDS, raw, 64 elements per wave-instruction; lanes past n read 0 (buffer range
+// check) into the padding of the LDS vector.  Nothing in these kernels WRITES LDS with ds_write while the stream is in flight: hipcc
+// orders a DS store behind every pending LDS DMA (vmcnt(0)), which would serialise the very thing being overlapped.
+#define AB_VEC(S_pad) (((S_pad) + 63) & ~63)
+__device__ __forceinline__ void vec_issue(float* dst_s, const float* src, int n, int wave, int nwaves, int lane) {
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, n * 4, 0x00020000);
+  for (int u = wave; u < (n + 63) / 64; u += nwaves)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(dst_s + u * 64), 4, (u * 64 + lane) * 4, 0, 0, 0);
+}
 // ------------------------------------------------------------------------------------------------------ forward
-// dynamic LDS: Ks[S_pad][128 B] | Vs[S_pad][128 B] | bias_s[S_pad] f32
+// dynamic LDS: NB blocks of (K rows | V rows) | bias_s[AB_VEC(S_pad)] f32
+// One wave owns 64 queries (two 32-query blocks, NW = ceil(NB / 2) waves): every K row fragment and every V column fragment it reads
+// from LDS feeds two MFMA chains, and -- the reason for the shape -- at ~160 VGPRs and 3 waves per workgroup, three workgroups are
+// resident per CU (one wave per 32 queries needs <= 96 VGPRs for that and does not get there; its 768 workgroups then run as 1.5 rounds).
+// Softmax: v_exp_f32 is base 2.  Scores stay in MFMA units (S / scale): s starts at bias[key] / scale (exact, scale = 1/8; a masked key is
+// -inf from there on) and the running maximum m_run is in the same units, so the exponent is ONE fma per pair,
+// (s - m_run) * (scale log2 e).  The maximum is LAZY: the
+// reference point m_run only moves when some row's block maximum exceeds it by more than 2^8 (a wave-uniform branch), so the 32-register
+// rescale of O and its exp are skipped in almost every block; P <= 256 then, which costs bf16 nothing (relative precision) and the fp32
+// sums nothing either.  The row sum stays per lane (each lane sums its own 16 keys of a block) and the two halves meet once, at the end.
+#define AB_TAU 5.545f            // 8 ln 2
+#define AB_M0 (-1.0e30f)         // initial reference point: far below any score, and -AB_M0 * scale log2 e still finite
+
+struct SoftmaxRow { float m_run, nm2, l_run; };
+// one 32x32 score block: lazy maximum, P as bf16 pairs (MFMA k-slot pair i of step st = i >> 2), row sums
+__device__ __forceinline__ void softmax_block(const f32x16& s, f32x16 (&o)[2], SoftmaxRow& st, unsigned int (&pk)[8], float c1, float tau) {
+  float mx = -3.0e38f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[r]);
+  mx = pair_max(mx);
+  if (__builtin_amdgcn_ballot_w64(mx > st.m_run + tau) != 0) {
+    const float m_new = fmaxf(st.m_run, mx);
+    const float alpha = __builtin_amdgcn_exp2f((st.m_run - m_new) * c1);
+    st.l_run *= alpha;
+    st.m_run = m_new;
+    st.nm2 = -m_new * c1;
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+  }
+  f32x2 sum2 = {0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const f32x2 e = f32x2{s[2 * i], s[2 * i + 1]} * c1 + st.nm2;
+    const f32x2 pe = {__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y)};
+    sum2 += pe;
+    pk[i] = pack_bf16x2(pe.x, pe.y);
+  }
+  st.l_run += sum2.x + sum2.y;
+}
+__device__ __forceinline__ void bias_init(f32x16& s, const float* bias_blk, float inv_scale) {
+  const f32x4* bp = reinterpret_cast<const f32x4*>(bias_blk);    // registers 4g .. 4g+3 <-> keys 8g + 4 half + {0..3} of the block
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const f32x4 v = bp[2 * g];
+    const f32x2 a0 = f32x2{v.x, v.y} * inv_scale, a1 = f32x2{v.z, v.w} * inv_scale;
+    s[4 * g] = a0.x; s[4 * g + 1] = a0.y; s[4 * g + 2] = a1.x; s[4 * g + 3] = a1.y;
+  }
+}
+
+template <int QB>
 __global__ __launch_bounds__(576) void attn_fwd_bf16_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ key_bias,
                                                             bf16_t* __restrict__ ctx, float* __restrict__ lse_out, int S_pad, int heads, float scale) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* Ks = smem;
-  unsigned char* Vs = Ks + S_pad * 128;
-  float* bias_s = reinterpret_cast<float*>(Vs + S_pad * 128);
+  float* bias_s = reinterpret_cast<float*>(smem + S_pad * 256);
   const int H = heads * AB_D, ld = 3 * H;
   const int b = blockIdx.x / heads, h = blockIdx.x % heads;
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, half = lane >> 5, l31 = lane & 31;
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6), half = lane >> 5, l31 = lane & 31;
   const int nwaves = blockDim.x >> 6;
   const bf16_t* Qg = qkv + (long)b * S_pad * ld + h * AB_D;
   const bf16_t* Kg = Qg + H;
   const bf16_t* Vg = Qg + 2 * H;
-  stage_image(Ks, Kg, ld, S_pad, tid, blockDim.x);
-  stage_image(Vs, Vg, ld, S_pad, tid, blockDim.x);
-  for (int i = tid; i < S_pad; i += blockDim.x) bias_s[i] = key_bias[(long)b * S_pad + i];
-  __syncthreads();
   const int NB = S_pad / 32;
-  for (int qb = wid; qb < NB; qb += nwaves) {
-    bf16x8 qf[4];
-    load_rows(qf, Qg, ld, qb * 32, lane);
-    f32x16 o[2];
+  // oldest in the vmcnt queue: what the first MFMA needs from registers, then the key bias, then the stream
+  int qbs[QB];                   // QB = 2, odd NB: the last wave computes its one block twice and stores it once
+#pragma unroll
+  for (int q = 0; q < QB; ++q) qbs[q] = QB * wid + q < NB ? QB * wid + q : QB * wid;
+  AB_STAMP(0);
+  bf16x8 qf[QB][4];
+#pragma unroll
+  for (int q = 0; q < QB; ++q) load_rows(qf[q], Qg, ld, qbs[q] * 32, lane);
+  __builtin_amdgcn_sched_barrier(0);
+  vec_issue(bias_s, key_bias + (long)b * S_pad, S_pad, wid, nwaves, lane);
+  Streamer sw;
+  sw.init(smem, Kg, ld, Vg, ld, S_pad / 8, wid, nwaves, lane);
+  if (!(AB_PROBE & 2)) sw.prologue();
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int q = 0; q < QB; ++q) use_rows(qf[q]);          // hipcc's wait for the Q rows lands HERE (straight-line code, exact count), not inside the loop
+  AB_STAMP(1);
+  const ColAddr va = col_addr(smem, lane);
+  const float c1 = scale * AB_LOG2E, inv_scale = 1.0f / scale, tau = AB_TAU * inv_scale;
+  f32x16 o[QB][2];
+  SoftmaxRow sr[QB];
+#pragma unroll
+  for (int q = 0; q < QB; ++q) {
+    sr[q].m_run = AB_M0; sr[q].nm2 = -AB_M0 * c1; sr[q].l_run = 0.f;
+  }
+#pragma unroll
+  for (int q = 0; q < QB; ++q)
 #pragma unroll
     for (int d = 0; d < 2; ++d)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
-    float m_run = -3.0e38f, l_run = 0.f;
-    for (int kb = 0; kb < NB; ++kb) {
-      f32x16 s;
+      for (int r = 0; r < 16; ++r) o[q][d][r] = 0.f;
+  for (int kb = 0; kb < NB; ++kb) {
+    if (!(AB_PROBE & 2)) sw.block(kb);
+    if (kb < 10) AB_STAMP(2 + kb);
+    if (AB_PROBE & 1) continue;
+    f32x16 s[QB];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) s[r] = 0.f;
+    for (int q = 0; q < QB; ++q) bias_init(s[q], bias_s + kb * 32 + 4 * half, inv_scale);
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Ks, kb * 32, ks, lane), qf[ks], s, 0, 0, 0);
-      float mx = -3.0e38f;
+    for (int ks = 0; ks < 4; ++ks) {
+      const bf16x8 kf = row_frag(smem + kb * AB_BLK, ks, lane);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        s[r] = s[r] * scale + bias_s[kb * 32 + crow(r, half)];
-        mx = fmaxf(mx, s[r]);
-      }
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float m_new = fmaxf(m_run, mx);
-      const float alpha = __expf(m_run - m_new);
-      float sum = 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        s[r] = __expf(s[r] - m_new);
-        sum += s[r];
-      }
-      sum += __shfl_xor(sum, 32, 64);
-      l_run = l_run * alpha + sum;
-      m_run = m_new;
-#pragma unroll
-      for (int d = 0; d < 2; ++d)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
-      // O^T[d][q] += V^T[d][key] P^T[key][q]; MFMA k-slot (half, j) <-> key kb*32 + 16*st + 8*(j>>2) + 4*half + (j&3)
-#pragma unroll
-      for (int st = 0; st < 2; ++st) {
-        const bf16x8 pf = pack8(s, st);
-        o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(col_frag(Vs, kb * 32 + 16 * st, 0, lane), pf, o[0], 0, 0, 0);
-        o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(col_frag(Vs, kb * 32 + 16 * st, 32, lane), pf, o[1], 0, 0, 0);
-      }
+      for (int q = 0; q < QB; ++q) s[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[q][ks], s[q], 0, 0, 0);
     }
-    store_acc(ctx + ((long)b * S_pad + qb * 32 + l31) * H + h * AB_D, o, half, 1.0f / l_run);
-    if (half == 0) lse_out[((long)b * heads + h) * S_pad + qb * 32 + l31] = m_run + __logf(l_run);
+    unsigned int pk[QB][8];
+#pragma unroll
+    for (int q = 0; q < QB; ++q) softmax_block(s[q], o[q], sr[q], pk[q], c1, tau);
+    __builtin_amdgcn_sched_barrier(0);
+    // O^T[d][q] += V^T[d][key] P^T[key][q]; MFMA k-slot (half, j) <-> key kb*32 + 16*st + 8*(j>>2) + 4*half + (j&3)
+    bf16x8 vf[2];
+    col_frags2<1, 0>(vf, va, kb);
+#pragma unroll
+    for (int q = 0; q < QB; ++q) {
+      o[q][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0], packed4(pk[q], 0), o[q][0], 0, 0, 0);
+      o[q][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1], packed4(pk[q], 0), o[q][1], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    col_frags2<1, 1>(vf, va, kb);
+#pragma unroll
+    for (int q = 0; q < QB; ++q) {
+      o[q][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0], packed4(pk[q], 1), o[q][0], 0, 0, 0);
+      o[q][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1], packed4(pk[q], 1), o[q][1], 0, 0, 0);
+    }
   }
+  AB_STAMP(12);
+#pragma unroll
+  for (int q = 0; q < QB; ++q) {
+    if (q > 0 && qbs[q] == qbs[0]) break;
+    const int qb = qbs[q];
+    const float l_tot = pair_sum(sr[q].l_run);
+    // a row with every key masked (does not occur: the first text token is always valid) gives 0, not NaN, here and in the backward
+    if (!(AB_PROBE & 4) || l_tot == 12345.f)
+    store_acc(ctx + ((long)b * S_pad + qb * 32 + l31) * H + h * AB_D, o[q], half, l_tot > 0.f ? 1.0f / l_tot : 0.f);
+    if (half == 0) lse_out[((long)b * heads + h) * S_pad + qb * 32 + l31] = l_tot > 0.f ? sr[q].m_run * scale + __logf(l_tot) : 0.f;
+  }
+  AB_STAMP(13);
+#ifdef AB_TRACE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  AB_STAMP(14);
+#endif
 }
 
-
-// one wave per 32-row block: the per-workgroup latency chain (stage K/V -> load Q -> scores -> softmax -> P.V -> store) is
-// walked once instead of NB/3 times, and a CU holds 3 workgroups x NB waves
-static int pick_waves(int NB) { return NB <= 9 ? NB : 8; }
-
+static int g_attn_qb = 0;      // measurement knob (climb_set_option 12): force 1 or 2 query blocks per wave
+void climb_attn_set_qb(int v) { g_attn_qb = v; }     // C++ linkage: library-internal (climb_set_option key 12)
 extern "C" int climb_attn_fwd_bf16(const void* qkv, const float* key_bias, void* ctx, float* lse, int B, int S_pad, int heads, int head_dim,
                                    void* stream) {
   if (head_dim != AB_D || S_pad % 32 || S_pad <= 0 || S_pad > 512) return CLIMB_EUNSUPPORTED;
-  size_t lds = (size_t)S_pad * 256 + (size_t)S_pad * 4;
+  size_t lds = (size_t)S_pad * 256 + (size_t)AB_VEC(S_pad) * 4;
   static size_t lds_set = 0;          // raise the dynamic-LDS cap once per size (not a stream operation: keep it out of graph capture)
   if (lds > lds_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_bf16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute((const void*)attn_fwd_bf16_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     lds_set = lds;
   }
-  hipLaunchKernelGGL(attn_fwd_bf16_kernel, dim3(B * heads), dim3(64 * pick_waves(S_pad / 32)), lds, (hipStream_t)stream, (const bf16_t*)qkv, key_bias,
-                     (bf16_t*)ctx, lse, S_pad, heads, 1.0f / sqrtf((float)head_dim));
+  const int NB = S_pad / 32;
+  const float scale = 1.0f / sqrtf((float)head_dim);
+  // query blocks per wave: 2 where the workgroup's LDS lets three (NB <= 6) sit on a CU -- or where one wave per block would need more than
+  // 9 waves; 1 in between (measured at NB = 9: 50 vs 57 us per layer)
+  const int qb = g_attn_qb ? g_attn_qb : ((NB <= 6 || NB > 9) ? 2 : 1);
+  if (qb == 1 && NB <= 9)
+    hipLaunchKernelGGL(attn_fwd_bf16_kernel<1>, dim3(B * heads), dim3(64 * NB), lds, (hipStream_t)stream, (const bf16_t*)qkv, key_bias,
+                       (bf16_t*)ctx, lse, S_pad, heads, scale);
+  else
+    hipLaunchKernelGGL(attn_fwd_bf16_kernel<2>, dim3(B * heads), dim3(64 * ((NB + 1) / 2)), lds, (hipStream_t)stream, (const bf16_t*)qkv, key_bias,
+                       (bf16_t*)ctx, lse, S_pad, heads, scale);
   LAUNCH_CHECK();
   return CLIMB_OK;
 }
@@ -180,46 +433,54 @@ extern "C" int climb_attn_fwd_bf16(const void* qkv, const float* key_bias, void*
 //     S = Q K^T, dP = dO V^T, P, dS;  dV^T += dO^T P,  dK^T += Q^T dS
 // delta[q] = sum_d dO[q][d] O[q][d] (the softmax-backward row term) is computed by PHASE 0 itself, whose waves already hold
 // their dO rows in registers, and written out for PHASE 1, which needs it for every query.
-// dynamic LDS: Xs[S_pad][128 B] | Ys[S_pad][128 B] | bias_s | lse_s | delta_s
-// launch bound 576 (= 9 waves, 3 per SIMD) caps the kernel at 168 VGPRs: three workgroups stay resident per CU, which is worth
-// more than the 17 spilled dwords of phase 1 (measured: 63 us vs 80 us per layer with a 256-thread bound)
+// Base-2 exponent like the forward; the factor `scale` of dS is a power of two here (1/8), applied to the fp32 accumulators at the store
+// instead of to every dS element: bit-identical, 16 multiplies per block cheaper.  Images are streamed (see above), 8 rounds:
+// NW = ceil(NB / 2) waves, two outer blocks per wave.
+// dynamic LDS: NB blocks of (X rows | Y rows) | bias_s | lse_s | delta_s (AB_VEC(S_pad) floats each)
+// launch bound 576 (= 9 waves, 3 per SIMD) caps the kernel at 168 VGPRs: three workgroups stay resident per CU at S_pad = 192
 template <int PHASE>
 __global__ __launch_bounds__(576) void attn_bwd_bf16_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ key_bias,
                                                             const bf16_t* __restrict__ dctx, const bf16_t* __restrict__ ctx,
                                                             const float* __restrict__ lse, float* __restrict__ delta,
                                                             bf16_t* __restrict__ dqkv, int S_pad, int heads, float scale) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* Xs = smem;
-  unsigned char* Ys = Xs + S_pad * 128;
-  float* bias_s = reinterpret_cast<float*>(Ys + S_pad * 128);
-  float* lse_s = bias_s + S_pad;
-  float* delta_s = lse_s + S_pad;
+  float* bias_s = reinterpret_cast<float*>(smem + S_pad * 256);
+  float* lse_s = bias_s + AB_VEC(S_pad);
+  float* delta_s = lse_s + AB_VEC(S_pad);
   const int H = heads * AB_D, ld = 3 * H;
   const int b = blockIdx.x / heads, h = blockIdx.x % heads;
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, half = lane >> 5, l31 = lane & 31;
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6), half = lane >> 5, l31 = lane & 31;
   const int nwaves = blockDim.x >> 6;
   const bf16_t* Qg = qkv + (long)b * S_pad * ld + h * AB_D;
   const bf16_t* Kg = Qg + H;
   const bf16_t* Vg = Qg + 2 * H;
   const bf16_t* dOg = dctx + (long)b * S_pad * H + h * AB_D;
-  if (PHASE == 0) {
-    stage_image(Xs, Kg, ld, S_pad, tid, blockDim.x);
-    stage_image(Ys, Vg, ld, S_pad, tid, blockDim.x);
-  } else {
-    stage_image(Xs, Qg, ld, S_pad, tid, blockDim.x);
-    stage_image(Ys, dOg, H, S_pad, tid, blockDim.x);
-  }
-  for (int i = tid; i < S_pad; i += blockDim.x) {
-    bias_s[i] = key_bias[(long)b * S_pad + i];
-    lse_s[i] = lse[((long)b * heads + h) * S_pad + i];
-    if (PHASE == 1) delta_s[i] = delta[((long)b * heads + h) * S_pad + i];
-  }
-  __syncthreads();
+  const bf16_t* Og = ctx + (long)b * S_pad * H + h * AB_D;
+  const long rowv = ((long)b * heads + h) * S_pad;     // this head's row of lse / delta
   const int NB = S_pad / 32;
-  for (int ob = wid; ob < NB; ob += nwaves) {
-    bf16x8 f1[4], f2[4];
-    if (PHASE == 0) { load_rows(f1, Qg, ld, ob * 32, lane); load_rows(f2, dOg, H, ob * 32, lane); }
-    else            { load_rows(f1, Kg, ld, ob * 32, lane); load_rows(f2, Vg, ld, ob * 32, lane); }
+  int ob = wid;                                   // nwaves <= NB
+  bf16x8 f1[4], f2[4], fo[4];
+  if (PHASE == 0) { load_rows(f1, Qg, ld, ob * 32, lane); load_rows(f2, dOg, H, ob * 32, lane); load_rows(fo, Og, H, ob * 32, lane); }
+  else            { load_rows(f1, Kg, ld, ob * 32, lane); load_rows(f2, Vg, ld, ob * 32, lane); }
+  // per-row scalar of this lane's outer row: lse (phase 0: the row is a query) or key bias (phase 1: a key)
+  float my_c = PHASE == 0 ? lse[rowv + ob * 32 + l31] : key_bias[(long)b * S_pad + ob * 32 + l31];
+  __builtin_amdgcn_sched_barrier(0);
+  // the vectors every lane needs for the INNER index: LDS, raw
+  if (PHASE == 0) vec_issue(bias_s, key_bias + (long)b * S_pad, S_pad, wid, nwaves, lane);
+  else { vec_issue(lse_s, lse + rowv, S_pad, wid, nwaves, lane); vec_issue(delta_s, delta + rowv, S_pad, wid, nwaves, lane); }
+  Streamer sw;
+  if (PHASE == 0) sw.init(smem, Kg, ld, Vg, ld, S_pad / 8, wid, nwaves, lane);
+  else            sw.init(smem, Qg, ld, dOg, H, S_pad / 8, wid, nwaves, lane);
+  if (!(AB_PROBE & 2)) sw.prologue();
+  __builtin_amdgcn_sched_barrier(0);
+  use_rows(f1);                  // hipcc's waits for the register operands land here (exact counts), not inside the loops
+  use_rows(f2);
+  if (PHASE == 0) use_rows(fo);
+  else negate_rows(f2);
+  asm volatile("" : "+v"(my_c));
+  const ColAddr xa = col_addr(smem, lane);
+  const float c1 = scale * AB_LOG2E;
+  for (bool first = true; ob < NB; first = false) {
     f32x16 acc1[2], acc2[2];
 #pragma unroll
     for (int d = 0; d < 2; ++d)
@@ -228,54 +489,113 @@ __global__ __launch_bounds__(576) void attn_bwd_bf16_kernel(const bf16_t* __rest
     const int my = ob * 32 + l31;
     float my_delta = 0.f;
     if (PHASE == 0) {
-      bf16x8 fo[4];
-      load_rows(fo, ctx + (long)b * S_pad * H + h * AB_D, H, ob * 32, lane);
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
         for (int e = 0; e < 8; ++e) my_delta += (float)fo[ks][e] * (float)f2[ks][e];
-      my_delta += __shfl_xor(my_delta, 32, 64);
-      if (half == 0) delta[((long)b * heads + h) * S_pad + my] = my_delta;
+      my_delta = pair_sum(my_delta);
     }
-    const float my_lse = lse_s[my], my_bias = bias_s[my];
+    // The per-row vectors ride in the accumulators: s starts at the INNER index's term, bias[key] / scale (phase 0) or -lse[query] / scale
+    // (phase 1) -- exact, scale = 1/8 -- and the lane's own term (-lse[query] / bias[key]) joins in the exponent's fma:
+    // P = 2^(s * scale log2 e + own log2 e).  Phase 1 also starts dP at
+    // delta[query] and multiplies by the NEGATED V rows (a sign-bit flip, exact): dp = delta - dO V^T, dS comes out negated, and the
+    // sign goes into the factor dK is stored with.  No vector is live next to s / dp, which is what keeps phase 1 inside 168 VGPRs.
+    const float inv_scale = 1.0f / scale;
+    const float is = PHASE == 0 ? inv_scale : -inv_scale;
+    const float k2 = (PHASE == 0 ? -my_c : fmaxf(my_c, AB_NEG)) * AB_LOG2E;      // this lane's own term, added in the exponent's fma
     for (int ib = 0; ib < NB; ++ib) {
+      if (first && !(AB_PROBE & 2)) sw.block(ib);
+      if (AB_PROBE & 1) continue;
       f32x16 s, dp;
+      {
+        const f32x4* ap = reinterpret_cast<const f32x4*>((PHASE == 0 ? bias_s : lse_s) + ib * 32 + 4 * half);
+        const f32x4* dl = reinterpret_cast<const f32x4*>(delta_s + ib * 32 + 4 * half);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) s[r] = dp[r] = 0.f;
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 v = ap[2 * g];
+          const f32x2 a0 = f32x2{v.x, v.y} * is, a1 = f32x2{v.z, v.w} * is;
+          s[4 * g] = a0.x; s[4 * g + 1] = a0.y; s[4 * g + 2] = a1.x; s[4 * g + 3] = a1.y;
+          if (PHASE == 1) {
+            const f32x4 dd = dl[2 * g];
+            dp[4 * g] = dd.x; dp[4 * g + 1] = dd.y; dp[4 * g + 2] = dd.z; dp[4 * g + 3] = dd.w;
+          } else {
+            dp[4 * g] = dp[4 * g + 1] = dp[4 * g + 2] = dp[4 * g + 3] = 0.f;
+          }
+        }
+      }
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Xs, ib * 32, ks, lane), f1[ks], s, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Ys, ib * 32, ks, lane), f2[ks], dp, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(smem + ib * AB_BLK, ks, lane), f1[ks], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(smem + ib * AB_BLK + AB_Y, ks, lane), f2[ks], dp, 0, 0, 0);
       }
-      f32x16 p, ds;
+      // P and dS go to bf16 pairs as they are made (MFMA k-slot pair i of step st = i >> 2): 16 live registers, not 32
+      unsigned int pk[8], dsk[8];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int in = ib * 32 + crow(r, half);
-        if (PHASE == 0) {   // in = key, lane = query
-          p[r] = __expf(s[r] * scale + bias_s[in] - my_lse);
-          ds[r] = p[r] * (dp[r] - my_delta) * scale;
-        } else {            // in = query, lane = key
-          p[r] = __expf(s[r] * scale + my_bias - lse_s[in]);
-          ds[r] = p[r] * (dp[r] - delta_s[in]) * scale;
-        }
+      for (int i = 0; i < 8; ++i) {
+        const f32x2 e = f32x2{s[2 * i], s[2 * i + 1]} * c1 + k2;
+        const f32x2 pe = {__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y)};
+        f32x2 d = {dp[2 * i], dp[2 * i + 1]};
+        if (PHASE == 0) d -= my_delta;
+        d *= pe;
+        if (PHASE == 1) pk[i] = pack_bf16x2(pe.x, pe.y);
+        dsk[i] = pack_bf16x2(d.x, d.y);
       }
+      __builtin_amdgcn_sched_barrier(0);
+      if (PHASE == 0) {
+        bf16x8 xf[2][2];
+        col_frags4<0>(xf, xa, ib);
 #pragma unroll
-      for (int st = 0; st < 2; ++st) {
-        const bf16x8 dsf = pack8(ds, st);
-        acc1[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(col_frag(Xs, ib * 32 + 16 * st, 0, lane), dsf, acc1[0], 0, 0, 0);
-        acc1[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(col_frag(Xs, ib * 32 + 16 * st, 32, lane), dsf, acc1[1], 0, 0, 0);
-        if (PHASE == 1) {
-          const bf16x8 pf = pack8(p, st);
-          acc2[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(col_frag(Ys, ib * 32 + 16 * st, 0, lane), pf, acc2[0], 0, 0, 0);
-          acc2[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(col_frag(Ys, ib * 32 + 16 * st, 32, lane), pf, acc2[1], 0, 0, 0);
+        for (int st = 0; st < 2; ++st) {
+          const bf16x8 dsf = packed4(dsk, st);
+          acc1[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[st][0], dsf, acc1[0], 0, 0, 0);
+          acc1[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[st][1], dsf, acc1[1], 0, 0, 0);
         }
+      } else {
+        // phase 1 has no registers to spare (64 accumulators + 32 K/V rows): one k-step's fragments at a time
+        bf16x8 f[2];
+        col_frags2<0, 0>(f, xa, ib);
+        acc1[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[0], packed4(dsk, 0), acc1[0], 0, 0, 0);
+        acc1[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[1], packed4(dsk, 0), acc1[1], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        col_frags2<1, 0>(f, xa, ib);
+        acc2[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[0], packed4(pk, 0), acc2[0], 0, 0, 0);
+        acc2[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[1], packed4(pk, 0), acc2[1], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        col_frags2<0, 1>(f, xa, ib);
+        acc1[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[0], packed4(dsk, 1), acc1[0], 0, 0, 0);
+        acc1[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[1], packed4(dsk, 1), acc1[1], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        col_frags2<1, 1>(f, xa, ib);
+        acc2[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[0], packed4(pk, 1), acc2[0], 0, 0, 0);
+        acc2[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[1], packed4(pk, 1), acc2[1], 0, 0, 0);
       }
     }
     bf16_t* orow = dqkv + ((long)b * S_pad + my) * ld + h * AB_D;
-    if (PHASE == 0) store_acc(orow, acc1, half, 1.0f);
-    else {
-      store_acc(orow + H, acc1, half, 1.0f);
+    // the next outer block's register operands are requested BEFORE this block's results are stored: they are not queued behind 19-38 MB
+    // of stores, and their latency overlaps the store issue
+    const float was_c = my_c;
+    ob += nwaves;
+    if (ob < NB) {
+      if (PHASE == 0) { load_rows(f1, Qg, ld, ob * 32, lane); load_rows(f2, dOg, H, ob * 32, lane); load_rows(fo, Og, H, ob * 32, lane); }
+      else            { load_rows(f1, Kg, ld, ob * 32, lane); load_rows(f2, Vg, ld, ob * 32, lane); }
+      my_c = PHASE == 0 ? lse[rowv + ob * 32 + l31] : key_bias[(long)b * S_pad + ob * 32 + l31];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if ((AB_PROBE & 4) && was_c != 12345.f) {}
+    else if (PHASE == 0) {
+      store_acc(orow, acc1, half, scale);
+      if (half == 0) delta[rowv + my] = my_delta;
+    } else {
+      store_acc(orow + H, acc1, half, -scale);
       store_acc(orow + 2 * H, acc2, half, 1.0f);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (ob < NB) {
+      use_rows(f1);
+      use_rows(f2);
+      if (PHASE == 0) use_rows(fo);
+      else negate_rows(f2);
+      asm volatile("" : "+v"(my_c));
     }
   }
 }
@@ -283,7 +603,7 @@ __global__ __launch_bounds__(576) void attn_bwd_bf16_kernel(const bf16_t* __rest
 extern "C" int climb_attn_bwd_bf16(const void* qkv, const float* key_bias, const void* dctx, const void* ctx, const float* lse, float* delta,
                                    void* dqkv, int B, int S_pad, int heads, int head_dim, void* stream) {
   if (head_dim != AB_D || S_pad % 32 || S_pad <= 0 || S_pad > 512) return CLIMB_EUNSUPPORTED;
-  size_t lds = (size_t)S_pad * 256 + (size_t)S_pad * 12;
+  size_t lds = (size_t)S_pad * 256 + (size_t)AB_VEC(S_pad) * 12;
   static size_t lds_set = 0;
   if (lds > lds_set) {
     hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_bf16_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -293,7 +613,9 @@ extern "C" int climb_attn_bwd_bf16(const void* qkv, const float* key_bias, const
     lds_set = lds;
   }
   const float scale = 1.0f / sqrtf((float)head_dim);
-  const int nthreads = 64 * ((S_pad / 32) % 3 == 0 ? 3 : 4);     // measured at S_pad = 192: 3-4 waves 63 us, 6 waves 78 us (register pressure)
+  // two outer blocks per wave: 64 nw >= S_pad threads (one element of the LDS vectors each) and 4 NB units over nw waves is at most 8 rounds;
+  // measured at S_pad = 192: 3 waves 63 us, 6 waves 78 us per layer (register pressure: 3 workgroups x 3 waves fill the 168-VGPR budget)
+  const int nthreads = 64 * ((S_pad / 32 + 1) / 2);
   hipLaunchKernelGGL((attn_bwd_bf16_kernel<0>), dim3(B * heads), dim3(nthreads), lds, (hipStream_t)stream, (const bf16_t*)qkv, key_bias,
                      (const bf16_t*)dctx, (const bf16_t*)ctx, lse, delta, (bf16_t*)dqkv, S_pad, heads, scale);
   LAUNCH_CHECK();

@@ -27,7 +27,10 @@ const char* climb_arch(void);
 const char* climb_error_string(int code);
 int climb_device_sync(void);
 /* tuning switches for A/B measurements: key 1 = waves per workgroup of the 128x128 bf16 NT GEMM (4 or 8); key 2 / 4 / 5 = allow the
- * 64x128 / 96x192 / 192x192 NT tile variants (0/1); key 3 = workgroup target of the 128x128 TN split; key 6 = waves per workgroup of the TN GEMM (4 or 8) */
+ * 64x128 / 96x192 / 192x192 NT tile variants (0/1); key 3 = workgroup target of the 128x128 TN split; key 6 = waves per workgroup of the TN GEMM (4 or 8);
+ * key 7 = persistent 256-row NT tiles (0 never, 1 auto, 2 / 3 force 256 / 192 columns, 4 two-workgroup variant); key 8 = k-loop-only probe of that kernel;
+ * key 9 = its grid; key 10 = persistent TN kernel (0/1); key 11 = de-phasing of the two-workgroup variant; key 12 = query blocks per wave of the
+ * bf16 attention forward (0 auto, 1, 2) */
 int climb_set_option(int key, int value);
 
 /* ---- embeddings -------------------------------------------------------------------------------------------------- */

@@ -410,7 +410,7 @@ def test_gemm_bf16_tn_weight_grad(M, N, K):
     assert _rel(db, db0.double() + dY.double().sum(0)) < 1e-5          # fused bias gradient (dY^T . 1)
 
 
-@pytest.mark.parametrize("S_pad,valid", [(64, 50), (192, 185), (224, 200), (288, 281)])
+@pytest.mark.parametrize("S_pad,valid", [(32, 20), (64, 50), (96, 96), (160, 150), (192, 185), (224, 200), (288, 281), (352, 331), (416, 400), (512, 512)])
 def test_attention_bf16_fwd_bwd(S_pad, valid):
     from climb_amd import _lib
     dev = _dev()
