@@ -442,6 +442,32 @@ def test_attention_bf16_fwd_bwd(S_pad, valid):
     assert e_fwd < 1e-2 and e_bwd < 2e-2
 
 
+@pytest.mark.parametrize("S_pad", [96, 192, 288])
+def test_attention_bf16_forward_variants_agree(S_pad):
+    """one / two query blocks per wave (climb_set_option 12) are the same arithmetic in a different wave shape: identical results"""
+    from climb_amd import _lib
+    dev = _dev()
+    B, heads, d = 3, 4, 64
+    H = heads * d
+    g = torch.Generator().manual_seed(S_pad)
+    qkv = _bf(torch.randn(B * S_pad, 3 * H, generator=g)).to(dev)
+    bias = torch.zeros(B, S_pad)
+    bias[:, S_pad - 7:] = -3.0e38
+    bias = bias.to(dev)
+    outs = []
+    try:
+        for qb in (1, 2, 0):
+            _lib.call("climb_set_option", 12, qb)
+            ctx = torch.empty(B * S_pad, H, device=dev, dtype=torch.bfloat16)
+            lse = torch.empty(B, heads, S_pad, device=dev)
+            _lib.call("climb_attn_fwd_bf16", qkv, bias, ctx, lse, B, S_pad, heads, d, _st())
+            outs.append((ctx.float().cpu(), lse.cpu()))
+    finally:
+        _lib.call("climb_set_option", 12, 0)
+    for c, l in outs[1:]:
+        assert torch.equal(c, outs[0][0]) and torch.equal(l, outs[0][1])
+
+
 def test_weight_shadow_cast_and_batched_transpose():
     from climb_amd import _lib
     dev = _dev()
