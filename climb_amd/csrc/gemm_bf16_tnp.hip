@@ -265,6 +265,14 @@ __global__ __launch_bounds__(256) void tnp_reduce_kernel(const float* __restrict
   }
 }
 
+#ifdef TNP_PROBE_REDUCE_ENTRY       // measurement build only (tools/probe/reduce_overlap.py)
+extern "C" int climb_probe_tn_reduce(const float* slab, float* C, long ldc, int N, int K, int splits, void* stream) {
+  const long n4 = (long)N * K / 4;
+  const int grid = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+  hipLaunchKernelGGL(tnp_reduce_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, slab, C, ldc, N, K, splits);
+  return 0;
+}
+#endif
 static float* g_tn_ws = nullptr;
 static long g_tn_ws_bytes = 0;
 // Scratch for the split partial sums (the library allocates nothing: the host registers a buffer once; without one, or when a launch
@@ -284,7 +292,11 @@ static int tnp_launch_one(int nwg, hipStream_t st, const bf16_t* A, long lda, co
   float* slab = nullptr;
   if (splits > 1 && (K % 4) == 0 && (ldc % 4) == 0 && (((uintptr_t)C) & 15) == 0 && (long)splits * N * K * 4 <= g_tn_ws_bytes) slab = g_tn_ws;
   hipLaunchKernelGGL((gemm_bf16_tnp_kernel<NI>), dim3(nwg), dim3(512), LDS, st, A, lda, B, ldb, C, ldc, M, N, K, rows, splits, dbias, slab);
+#ifdef TNP_PROBE_NO_REDUCE          // measurement build only: what would hiding the reduce launches be worth at most
+  if (false) {
+#else
   if (slab) {
+#endif
     const long n4 = (long)N * K / 4;
     const int grid = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
     hipLaunchKernelGGL(tnp_reduce_kernel, dim3(grid), dim3(256), 0, st, slab, C, ldc, N, K, splits);
