@@ -468,6 +468,45 @@ def test_attention_bf16_forward_variants_agree(S_pad):
         assert torch.equal(c, outs[0][0]) and torch.equal(l, outs[0][1])
 
 
+@pytest.mark.parametrize("case", ["soft_bias", "peaked", "masked_row"])
+def test_attention_bf16_edge_inputs(case):
+    """The bf16 attention's lazy running maximum and folded bias under inputs the step never produces: a general additive bias (not only
+    0 / -3e38), scores large enough that every block moves the maximum, and a row whose keys are all masked (defined as 0, not NaN)."""
+    from climb_amd import _lib
+    dev = _dev()
+    B, heads, d, S_pad = 2, 2, 64, 192
+    H = heads * d
+    g = torch.Generator().manual_seed({"soft_bias": 1, "peaked": 2, "masked_row": 3}[case])
+    qkv = torch.randn(B, S_pad, 3 * H, generator=g)
+    bias = torch.zeros(B, S_pad)
+    if case == "soft_bias":
+        bias = torch.randn(B, S_pad, generator=g) * 3.0
+    elif case == "peaked":
+        qkv[..., :2 * H] *= 6.0                    # scores ~ N(0, 36^2): the maximum grows by far more than 2^8 between blocks
+    else:
+        bias[1, :] = -3.0e38                       # batch 1: every key masked
+    qkv = _bf(qkv)
+    dctx = _bf(torch.randn(B, S_pad, H, generator=g))
+    qd, bd, dd = qkv.to(dev).view(B * S_pad, 3 * H), bias.to(dev), dctx.to(dev).view(B * S_pad, H)
+    ctx = torch.empty(B * S_pad, H, device=dev, dtype=torch.bfloat16)
+    lse = torch.empty(B, heads, S_pad, device=dev)
+    delta = torch.empty(B, heads, S_pad, device=dev)
+    dqkv = torch.empty(B * S_pad, 3 * H, device=dev, dtype=torch.bfloat16)
+    _lib.call("climb_attn_fwd_bf16", qd, bd, ctx, lse, B, S_pad, heads, d, _st())
+    _lib.call("climb_attn_bwd_bf16", qd, bd, dd, ctx, lse, delta, dqkv, B, S_pad, heads, d, _st())
+    c, dq = ctx.float().view(B, S_pad, H).cpu(), dqkv.float().view(B, S_pad, 3 * H).cpu()
+    assert torch.isfinite(c).all() and torch.isfinite(dq).all() and torch.isfinite(lse).all()
+    nb = 1 if case == "masked_row" else B          # rows to compare against the fp64 softmax
+    qr = qkv[:nb].double().requires_grad_(True)
+    ref = _attn_ref(qr, bias[:nb].double(), heads)
+    ref.backward(dctx[:nb].double())
+    e_fwd, e_bwd = _rel(c[:nb], ref.detach()), _rel(dq[:nb], qr.grad)
+    print(f"attention bf16 {case}: fwd {e_fwd:.2e} bwd {e_bwd:.2e}")
+    assert e_fwd < 1e-2 and e_bwd < (4e-2 if case == "peaked" else 2e-2)
+    if case == "masked_row":
+        assert (c[1] == 0).all() and (dq[1] == 0).all()
+
+
 def test_weight_shadow_cast_and_batched_transpose():
     from climb_amd import _lib
     dev = _dev()
