@@ -216,3 +216,62 @@ class VCRTrainer(VLTaskTrainer):
         self.task_type = self.task_config["task_type"]
         return tuple(build_vcr_dataloader(args=args, data_dir=self.data_dir, split=sp, task_type=self.task_type,
                                           visual_input_type=self.visual_input_type) for sp in ("train", "val"))
+
+
+# ------------------------------------------------------------------------------------------------ low-shot transfer
+class LowShotMixin:
+    """The reference's LowShot*Trainer classes (REF train_vqa.py:284-360, train_nlvr2.py:261-340, train_snli_ve.py:269-350,
+    train_vcr.py:263-345): the task trainer on a sub-sampled training set (`low_shot_config`: a percentage of the examples, or N shots
+    per class), evaluated only after the epochs the config names, no replay / EWC.  Constructed by REF/train/train_lowshot_multimodal.py:52
+    as `trainer_class(args, task_configs, model_config, device, low_shot_config=...)`."""
+
+    def __init__(self, args, task_configs: Dict, model_config: Dict, device: torch.device, low_shot_config: Dict = None, **kw):
+        super().__init__(args, task_configs, model_config, device, **kw)
+        if low_shot_config is None:
+            raise ValueError(f"{type(self).__name__}: low_shot_config is required")
+        self.low_shot_config = low_shot_config
+        self.eval_epochs = [x - 1 for x in low_shot_config["eval_epochs"]]
+        dataset = self.train_dataloader.dataset
+        if low_shot_config["type"] == "percentage":
+            dataset.convert_to_low_shot(low_shot_percentage=low_shot_config["percentage"])
+        else:
+            dataset.convert_to_low_shot(num_shots_per_class=low_shot_config["num_shots_per_class"])
+        self.max_steps = len(self.train_dataloader) * self.num_epochs
+
+    def train(self, model):
+        model.to(self.device)
+        optimizer = model.create_optimizer(self.hparams)
+        scheduler = polynomial_decay_schedule_with_warmup(optimizer, int(self.max_steps * self.warmup_ratio), self.max_steps, 0.0, 1.0)
+        best_score = 0
+        best_model = {"epoch": 0, "model": copy.deepcopy(model), "optimizer_state": optimizer.state_dict()}
+        model.zero_grad()
+        for epoch in range(self.num_epochs):
+            model.train()
+            for step, batch in enumerate(self.train_dataloader):
+                self.train_step(model, batch, optimizer, scheduler)
+            if epoch in self.eval_epochs:
+                eval_score = self.eval(model)
+                logger.info("Evaluation after epoch {}: {:.2f}".format(epoch + 1, eval_score))
+                wandb_logger.log({self.task_key: {"val_score": eval_score}})
+                if eval_score > best_score:
+                    logger.info("New best evaluation score: {:.2f}".format(eval_score))
+                    best_score = eval_score
+                    best_model["epoch"] = epoch
+                    best_model["model"] = copy.deepcopy(model)
+        return best_score, best_model
+
+
+class LowShotVQATrainer(LowShotMixin, VQATrainer):
+    pass
+
+
+class LowShotNLVR2Trainer(LowShotMixin, NLVR2Trainer):
+    pass
+
+
+class LowShotSNLIVETrainer(LowShotMixin, SNLIVETrainer):
+    pass
+
+
+class LowShotVCRTrainer(LowShotMixin, VCRTrainer):
+    pass

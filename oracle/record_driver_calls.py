@@ -1,4 +1,5 @@
-"""tests/golden/driver_calls.json: every call the REFERENCE's upstream driver makes into this package.  BUILD-CONTAINER ONLY.
+"""tests/golden/driver_calls.json: every call the REFERENCE's upstream driver -- and its low-shot transfer driver -- makes into this
+package.  BUILD-CONTAINER ONLY.
 
     python oracle/record_driver_calls.py
 
@@ -20,6 +21,7 @@ import types
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 DRIVER = "/root/reference/src/train/train_upstream_continual_learning.py"
+LOWSHOT_DRIVER = "/root/reference/src/train/train_lowshot_multimodal.py"
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "integration", "climb_shim"))
 os.environ.setdefault("HF_HUB_OFFLINE", "1")
@@ -98,6 +100,27 @@ def main():
                                      "files": sorted(os.path.relpath(os.path.join(dp, f), os.path.join(out_dir, run_dirs[0]))
                                                      for dp, _, fs in os.walk(os.path.join(out_dir, run_dirs[0])) for f in fs)}
         print(name, len(rec), "calls;", [(r["task_key"], r["best_score"]) for r in results])
+    # ---- the low-shot transfer driver, same shim, same recorder; "after" scenarios reuse the upstream run's checkpoints
+    from climb_amd.configs.task_configs import task_configs
+    sc.apply_lowshot_overrides(task_configs)
+    golden["lowshot_driver"] = "REF/train/train_lowshot_multimodal.py"
+    golden["lowshot_overrides"] = sc.LOWSHOT_OVERRIDES
+    golden["lowshot_scenarios"] = {}
+    for name, spec in sc.LOWSHOT_SCENARIOS.items():
+        out_dir = os.path.join(work, "out_" + (spec["upstream"] or name))
+        calls = driver_trace.install(LOWSHOT_DRIVER)
+        for m in [m for m in sys.modules if m.split(".")[0] in ("modeling", "cl_algorithms", "cl_evaluation", "configs", "utils")]:
+            del sys.modules[m]
+        sys.argv = [LOWSHOT_DRIVER] + sc.lowshot_argv(name, data, out_dir)
+        print("=" * 30, name, " ".join(sys.argv[1:]))
+        runpy.run_path(LOWSHOT_DRIVER, run_name="__main__")
+        rec = [dict(c) for c in calls]
+        driver_trace.uninstall()
+        run_dirs = [d for d in os.listdir(out_dir) if os.path.exists(os.path.join(out_dir, d, "lowshot_results.json"))]
+        assert len(run_dirs) == 1, run_dirs
+        results = json.load(open(os.path.join(out_dir, run_dirs[0], "lowshot_results.json")))
+        golden["lowshot_scenarios"][name] = {"experiment_dir": run_dirs[0], "calls": rec, "results": results}
+        print(name, len(rec), "calls;", [(r.get("lowshot_task_key", r.get("task_key")), r["best_low_shot_score"]) for r in results])
     out = os.path.join(ROOT, "tests", "golden", "driver_calls.json")
     json.dump(golden, open(out, "w"), indent=1)
     print("wrote", out, os.path.getsize(out), "bytes")

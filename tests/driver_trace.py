@@ -1,5 +1,5 @@
-"""Call recorder for the drop-in boundary.  `install(caller_file)` wraps the functions and methods the upstream
-driver (REF/train/train_upstream_continual_learning.py) reaches in this package; every call whose CALLER is a frame of `caller_file`
+"""Call recorder for the drop-in boundary.  `install(caller_file)` wraps the functions and methods the reference's
+drivers (REF/train/train_upstream_continual_learning.py, REF/train/train_lowshot_multimodal.py) reach in this package; every call whose CALLER is a frame of `caller_file`
 is appended to `calls` as {name, nargs, kwargs, returns}.  The same recorder runs (a) under the reference driver itself, through
 integration/climb_shim, in the build container (oracle/record_driver_calls.py -> tests/golden/driver_calls.json) and (b) under
 tests/upstream_driver.py on the GPU, so the two traces can be compared call by call."""
@@ -62,6 +62,8 @@ def install(caller_file):
     _patch(tt.VLTaskTrainer, "__init__", "TaskTrainer", caller_file, is_init=True)
     for m in ("train", "eval", "eval_forgetting"):
         _patch(tt.VLTaskTrainer, m, f"TaskTrainer.{m}", caller_file)
+    _patch(tt.LowShotMixin, "__init__", "LowShotTaskTrainer", caller_file, is_init=True)      # REF train_lowshot_multimodal.py:52-53
+    _patch(tt.LowShotMixin, "train", "LowShotTaskTrainer.train", caller_file)
     _patch(cl.EWC, "__init__", "EWC", caller_file, is_init=True)
     _patch(cl.EWC, "save_task_parameters", "EWC.save_task_parameters", caller_file)
     _patch(cl.ExperienceReplayMemory, "__init__", "ExperienceReplayMemory", caller_file, is_init=True)

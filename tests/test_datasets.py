@@ -100,6 +100,39 @@ def test_trainers_are_constructible_the_way_the_upstream_driver_constructs_them(
         task_configs["vqa"]["task_trainer"](types.SimpleNamespace(batch_size=4), task_configs, model_configs["vilt"], torch.device("cpu"))
 
 
+def test_low_shot_trainers_subsample_the_way_the_low_shot_driver_asks(tree):
+    """REF/train/train_lowshot_multimodal.py:52: `trainer_class(args, task_configs, model_config, device, low_shot_config=...)`; the
+    reference's LowShot*Trainer constructors (train_vqa.py:286-308 and siblings): percentage of the examples / N shots per class,
+    evaluation epochs 1-based in the config and 0-based in the trainer, max_steps from the SHRUNK loader."""
+    import copy
+    import random
+    from climb_amd.configs.model_configs import model_configs
+    from climb_amd.configs.task_configs import task_configs
+    from climb_amd.train import task_trainer as tt
+    args = types.SimpleNamespace(batch_size=4, num_workers=0, visual_input_type="pil-image", climb_data_dir=tree, cl_algorithm="sequential_ft")
+    ref = {"vqa": ("percentage", 0.05, [6, 8, 10]), "nlvr2": ("n-shot-per-class", 2048, [6, 8, 10]), "snli-ve": ("n-shot-per-class", 2048, [2, 4, 5]),
+           "vcr": ("percentage", 0.05, [2, 4, 6, 8, 10])}                                   # REF/configs/task_configs.py:31-34, 51-55, 73-77, 96-100
+    for task, (kind, size, epochs) in ref.items():
+        cfg = task_configs[task]["low_shot_config"]
+        assert cfg["type"] == kind and cfg["eval_epochs"] == epochs and cfg.get("percentage", cfg.get("num_shots_per_class")) == size
+        assert issubclass(cfg["task_trainer"], tt.LowShotMixin) and issubclass(cfg["task_trainer"], task_configs[task]["task_trainer"])
+    random.seed(0)
+    small = {"vqa": dict(percentage=0.5), "nlvr2": dict(num_shots_per_class=2), "snli-ve": dict(num_shots_per_class=1), "vcr": dict(percentage=0.5)}
+    for task, over in small.items():
+        cfg = copy.copy(task_configs[task]["low_shot_config"])
+        cfg.update(over)
+        full = task_configs[task]["task_trainer"](args, task_configs, model_configs["vilt"], torch.device("cpu"))
+        n_full = len(full.get_train_dataloader().dataset)
+        t = cfg["task_trainer"](args, task_configs, model_configs["vilt"], torch.device("cpu"), low_shot_config=cfg)
+        n = len(t.get_train_dataloader().dataset)
+        want = int(over["percentage"] * n_full) if "percentage" in over else over["num_shots_per_class"] * task_configs[task]["num_labels"]
+        assert n == want < n_full, (task, n, want, n_full)
+        assert t.eval_epochs == [e - 1 for e in cfg["eval_epochs"]] and t.max_steps == len(t.get_train_dataloader()) * task_configs[task]["num_epochs"]
+        assert len(t.val_dataloader.dataset) == len(full.val_dataloader.dataset)              # validation untouched
+    with pytest.raises(ValueError):
+        task_configs["vqa"]["low_shot_config"]["task_trainer"](args, task_configs, model_configs["vilt"], torch.device("cpu"))
+
+
 def test_recorded_calls_bind_to_this_packages_signatures(golden_dir):
     """CPU-checkable half (also run on the GPU box): every recorded call's positional count and keyword set binds to the callable of
     the same name in this package."""
@@ -116,9 +149,11 @@ def test_recorded_calls_bind_to_this_packages_signatures(golden_dir):
              "set_seed": (ut.set_seed, 0)}
     classes = {"TaskTrainer": tt.VLTaskTrainer, "EWC": cl.EWC, "ExperienceReplayMemory": cl.ExperienceReplayMemory, "AdapterHandler": cl.AdapterHandler,
                "ViltContinualLearner": ViltContinualLearner, "ViltEncoderWrapper": ViltEncoderWrapper}
+    table["LowShotTaskTrainer"] = (tt.LowShotMixin.__init__, 1)
+    classes["LowShotTaskTrainer"] = tt.LowShotMixin
     g = json.load(open(os.path.join(golden_dir, "driver_calls.json")))
     seen = set()
-    for scen in g["scenarios"].values():
+    for scen in list(g["scenarios"].values()) + list(g["lowshot_scenarios"].values()):
         for c in scen["calls"]:
             if "." in c["name"]:
                 fn, skip = getattr(classes[c["name"].split(".")[0]], c["name"].split(".")[1]), 1
@@ -127,4 +162,4 @@ def test_recorded_calls_bind_to_this_packages_signatures(golden_dir):
             inspect.signature(fn).bind(*([None] * (c["nargs"] + skip)), **{k: None for k in c["kwargs"]})
             seen.add(c["name"])
     assert {"TaskTrainer.train", "EWC.save_task_parameters", "ExperienceReplayMemory.add_task_memory_buffer",
-            "AdapterHandler.activate_adapter_for_training", "catastrophic_forgetting_eval"} <= seen
+            "AdapterHandler.activate_adapter_for_training", "catastrophic_forgetting_eval", "LowShotTaskTrainer", "LowShotTaskTrainer.train"} <= seen

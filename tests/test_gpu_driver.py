@@ -5,7 +5,8 @@ run unchanged through integration/climb_shim by oracle/record_driver_calls.py) m
 the MI355X through tests/upstream_driver.py -- a call-for-call restatement of the driver's main() -- under the same recorder, on the same
 synthetic data tree (PIL images + strings through the real datasets, trainers, device image pipeline, plug-ins, checkpoints and CL
 metrics), and must produce the same call sequence, the same files and (where predictions are pinned) the same scores.
-Scenarios: BASELINE.json configs[2] (adapters VQA -> NLVR2) and configs[3] / [4] (EWC / ER over VQA -> NLVR2 -> SNLI-VE -> VCR, one GPU)."""
+Scenarios: BASELINE.json configs[2] (adapters VQA -> NLVR2) and configs[3] / [4] (EWC / ER over VQA -> NLVR2 -> SNLI-VE -> VCR, one GPU);
+the low-shot transfer driver (REF/train/train_lowshot_multimodal.py) from scratch and from the checkpoints of an upstream run."""
 import json
 import os
 
@@ -13,7 +14,7 @@ import pytest
 import torch
 
 from tests import driver_scenarios as sc
-from tests import driver_trace, synth_data, upstream_driver
+from tests import driver_trace, lowshot_driver, synth_data, upstream_driver
 
 pytestmark = pytest.mark.gpu
 
@@ -80,3 +81,42 @@ def test_upstream_driver_scenario_matches_the_reference_drivers_call_sequence(na
         assert any(".adapters.nlvr2." in k for k in sd) and any(".adapters.vqa." in k for k in sd)
     if name == "freeze_encoder":
         assert all(not p.requires_grad for p in model.get_encoder().parameters())
+
+
+@pytest.mark.parametrize("name", list(sc.LOWSHOT_SCENARIOS))
+def test_lowshot_driver_scenario_matches_the_reference_drivers_call_sequence(name, data_tree, tmp_path, golden_dir):
+    """SURVEY.md row F4, second half: REF/train/train_lowshot_multimodal.py was run unchanged through integration/climb_shim by
+    oracle/record_driver_calls.py; the same scenarios on the MI355X (tests/lowshot_driver.py, LowShot*Trainer on sub-sampled training
+    sets, checkpoints of an upstream run re-loaded) must make the same calls and write the same lowshot_results.json."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import copy
+    from climb_amd.configs.task_configs import task_configs
+    spec = sc.LOWSHOT_SCENARIOS[name]
+    golden = json.load(open(os.path.join(golden_dir, "driver_calls.json")))["lowshot_scenarios"][name]
+    dev = torch.device("cuda:0")
+    out_dir = str(tmp_path / "out")
+    saved = {k: copy.copy(task_configs[k]["low_shot_config"]) for k in sc.LOWSHOT_OVERRIDES}
+    sc.apply_lowshot_overrides(task_configs)
+    try:
+        if spec["upstream"] is not None:           # the checkpoints the low-shot driver loads
+            up = sc.namespace(spec["upstream"], data_tree, out_dir)
+            sc.write_singletask_results(out_dir, up.ordered_cl_tasks)
+            upstream_driver.run_upstream(up, dev, after_model_created=_pin_predictions)
+        args = sc.lowshot_namespace(name, data_tree, out_dir)
+        calls = driver_trace.install(lowshot_driver.__file__)
+        try:
+            out = lowshot_driver.run_lowshot(args, dev, after_model_created=_pin_predictions)
+            got = [dict(c) for c in calls]
+        finally:
+            driver_trace.uninstall()
+    finally:
+        for k, v in saved.items():
+            task_configs[k]["low_shot_config"] = v
+    assert got == golden["calls"], next(((g, w) for g, w in zip(got, golden["calls"]) if g != w), (len(got), len(golden["calls"])))
+    results = json.load(open(os.path.join(out_dir, golden["experiment_dir"], "lowshot_results.json")))
+    assert len(results) == len(golden["results"])
+    for r, g in zip(results, golden["results"]):
+        assert {k: v for k, v in r.items() if k != "best_low_shot_score"} == {k: v for k, v in g.items() if k != "best_low_shot_score"}
+        assert r["best_low_shot_score"] == pytest.approx(g["best_low_shot_score"], abs=1e-4), (r, g)
+    assert all(bool(torch.isfinite(p).all()) for p in out["model"].parameters())
