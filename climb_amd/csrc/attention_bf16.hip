@@ -3,8 +3,9 @@
 // "swapped" formulation: every product has the reduction index in MFMA rows of the previous result, so softmax
 // statistics are per-lane scalars (+ one xor-32 shuffle) and P / dS feed the next MFMA straight from registers.
 //
-// One workgroup per (batch, head); S <= 288 keys means a whole head's K and V (S_pad x 64 bf16 = 24.6 KB each at
-// S_pad = 192) are LDS-resident: single pass over HBM, the S x S scores never leave the CU.
+// One workgroup per (batch, head); S <= 512 keys means a whole head's K and V (S_pad x 64 bf16 = 24.6 KB each at
+// S_pad = 192) are LDS-resident: single pass over HBM, the S x S scores never leave the CU.  The images are STREAMED in (see "streamed
+// staging" below): the inner loop starts on the first 32-row block while the later ones are still in flight.
 //
 // LDS image of every [rows][64] operand: 128-B rows, 16-B chunks XOR-swizzled by swz(row); the two operands of a kernel (K and V, or Q
 // and dO) are interleaved by 32-row block -- block ib = 8 KB: X rows, then Y rows -- so one set of per-lane addresses serves both
@@ -28,7 +29,6 @@ extern "C" int climb_attn_set_trace(void* p) { return (int)hipMemcpyToSymbol(HIP
 #endif
 
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
-typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
 __device__ __forceinline__ int aswz(int row) {
   int y = (row >> 1) & 7;
@@ -39,7 +39,7 @@ __device__ __forceinline__ bf16x8 to_bf16x8(u32x4 v) {
   c.u = v;
   return c.b;
 }
-__device__ __forceinline__ int crow(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+// accumulator register r of a 32 x 32 block holds matrix row (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
 
 typedef __attribute__((address_space(3))) void lds_void_t;
 #define AB_BLK 8192          // LDS bytes per 32-row block: X half, Y half
@@ -161,7 +161,6 @@ __device__ __forceinline__ float pair_sum(float x) {
 // when 1/NB of the data has arrived instead of all of it; with every workgroup of the launch in lock step that is the difference between
 // "load, then compute" and the two overlapped.
 #define AB_LOG2E 1.44269504088896340736f
-#define AB_LN2 0.69314718055994530942f
 #define AB_NEG (-3.0e38f)
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 
