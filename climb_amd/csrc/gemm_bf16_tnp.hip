@@ -331,6 +331,9 @@ int climb_tnp_launch(const bf16_t* A, long lda, const bf16_t* B, long ldb, float
   if (best_ni == 0) return CLIMB_EUNSUPPORTED;
   const int bk = 64 * best_ni, tiles = nbn * ((K + bk - 1) / bk);
   int nwg = tiles * best_splits;
+#ifdef TNP_PROBE_GRID            // measurement build only (tools/probe/split_chip.py): cap the persistent grid
+  if (nwg > TNP_PROBE_GRID) nwg = TNP_PROBE_GRID;
+#endif
   if (nwg > 256) nwg = 256;
   if (best_ni == 4) return tnp_launch_one<4>(nwg, st, A, lda, B, ldb, C, ldc, M, N, K, best_rows, best_splits, dbias);
   return tnp_launch_one<3>(nwg, st, A, lda, B, ldb, C, ldc, M, N, K, best_rows, best_splits, dbias);
