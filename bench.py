@@ -20,7 +20,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 FLOP_PER_SAMPLE = 100.14e9          # forward 33.38 + backward 66.76 GFLOP at S=185, no padding counted
-PEAK = {"bf16": 2500.0, "fp32": 157.3}   # dense MFMA peak TFLOP/s for the operand dtype (MI355X_MICROARCH.md)
+PEAK = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3}   # dense MFMA peak TFLOP/s for the operand dtype (MI355X_MICROARCH.md)
 
 
 def main():
@@ -29,8 +29,10 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=64, help="sequences per GPU per step")
-    ap.add_argument("--precision", default=os.environ.get("CLIMB_AMD_PRECISION", "bf16"), choices=["bf16", "fp32"])
+    ap.add_argument("--precision", default=os.environ.get("CLIMB_AMD_PRECISION", "bf16"), choices=["bf16", "fp16", "fp32"],
+                    help="bf16 (BASELINE configs[1], default); fp16 = the same code path on IEEE-half operands (DESIGN.md section 3); fp32 = parity mode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--child-check", action="store_true", help=argparse.SUPPRESS)       # fp16_operand_line()'s child: run the reference checker leg only
     ap.add_argument("--graph", action="store_true", help="replay the step as a captured hipGraph (measured equal to eager launches at bs=64: the GPU, not the host, is the bottleneck)")
     ap.add_argument("--cpu-steps", type=int, default=6)
     args = ap.parse_args()
@@ -97,7 +99,7 @@ def main():
     for _ in range(args.warmup):
         loss = step()
     eng = model._host.engine()
-    dominant = "gemm_bf16_nt" if args.precision == "bf16" else "gemm_f32"
+    dominant = "gemm_bf16_nt" if args.precision in ("bf16", "fp16") else "gemm_f32"
     prof = {"kernel": dominant, "events": []}
     prof_every = 10         # HIP-event pairs around every launch of the dominant kernel on every 10th timed step (an instrumented step costs
     #                         +0.6 ms: 97 launches x 2 event records), created and recorded once BEFORE the timed region (event creation inside it
@@ -165,7 +167,7 @@ def main():
         try:        # HBM bytes per launch from the committed PMC passes (rocprofv3 cannot be driven from inside the timed run);
             # the file names the hash of the kernel sources it was measured on: a stale figure is reported as null, not repeated
             tj = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
-            if tj.get("csrc_sha16") == csrc_hash() and args.precision == "bf16" and B == 64:
+            if tj.get("csrc_sha16") == csrc_hash() and args.precision in ("bf16", "fp16") and B == 64:
                 traffic = tj[dominant]["hbm_bytes_per_launch"]
         except Exception:
             traffic = None
@@ -190,13 +192,34 @@ def main():
             out["allreduce_MB_per_step"] = round(ddp.bytes_reduced / 1e6 / (args.steps + args.warmup + (args.steps + 2 if dp_ab else 0)), 1)
             if dp_ab:
                 out["dp_overlap_ab"] = dict(dp_ab, **{("overlap" if ddp.overlap else "deferred") + "_ms_per_step": round(ms, 3)})
+        if world == 1 and args.child_check:
+            out["fp16_vs_ref"] = bf16_vs_reference(dev, args.precision)
         if world == 1 and not args.no_cpu_baseline:
-            out["bf16_vs_ref"] = bf16_vs_reference(dev) if args.precision == "bf16" else None
+            out["bf16_vs_ref" if args.precision != "fp16" else "fp16_vs_ref"] = bf16_vs_reference(dev, args.precision) if args.precision != "fp32" else None
+            if args.precision == "bf16":
+                out["fp16_operands"] = fp16_operand_line(args)
             out["cpu_baseline"] = cpu_baseline(args.cpu_steps)
         print(json.dumps(out), flush=True)
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
+
+
+def fp16_operand_line(args):
+    """Reported next to the bf16 headline, never as `value`: the SAME step on the IEEE-half build of the library (fp16 GEMM / attention operands,
+    scaled loss gradient) -- its throughput and its errors against the reference fixture.  A process holds one build, so
+    this is a child process of rank 0."""
+    import subprocess
+    env = dict(os.environ, CLIMB_AMD_H16="fp16")
+    env.pop("CLIMB_AMD_LIB", None)
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--precision", "fp16", "--no-cpu-baseline", "--child-check", "--steps", str(args.steps),
+                            "--warmup", str(args.warmup), "--batch", str(args.batch)], capture_output=True, text=True, timeout=900, env=env)
+        j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        return {"value": j["value"], "unit": j["unit"], "ms_per_step": j["ms_per_step"], "dtype": "fp16", "vs_ref": j.get("fp16_vs_ref"),
+                "note": "same kernels, IEEE-half operands (libclimb_hip_f16.so), static power-of-two loss scale; not the BASELINE dtype"}
+    except Exception as e:      # the headline must not depend on the extra line
+        return {"error": repr(e)[:200]}
 
 
 def csrc_hash():
@@ -210,7 +233,7 @@ def csrc_hash():
     return h.hexdigest()[:16]
 
 
-def bf16_vs_reference(dev):
+def bf16_vs_reference(dev, precision="bf16"):
     """CHECKER leg (rank 0, N = 1, after the timed region; the only place besides cpu_baseline that touches oracle/): one step of the
     timed arithmetic mode on tests/golden/vqa_b64.npz -- the REFERENCE's own outputs for 64 seeded sequences (oracle/gen_golden.py) --
     and its errors against them (max|d| / max|ref|), plus the share of the 64 rows whose argmax answer equals the reference's."""
@@ -224,7 +247,7 @@ def bf16_vs_reference(dev):
     m = dict(kv.split("=", 1) for kv in str(z["meta"][0]).split(";"))
     tasks, B = m["tasks"].split(","), int(m["B"])
     model = create_continual_learner_map["vilt"](model_name_or_path="random-init:0", ordered_cl_tasks=tasks, model_config=model_configs["vilt"],
-                                                 task_configs=task_configs, device=dev, precision="bf16")
+                                                 task_configs=task_configs, device=dev, precision=precision)
     model.load_state_dict(vo.init_params(tasks, int(m["wseed"])), strict=True)
     model.to(dev)
     model.train()

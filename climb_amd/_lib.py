@@ -10,7 +10,40 @@ from typing import Dict, List, Tuple
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "climb_hip.h")
-LIB_PATH = os.environ.get("CLIMB_AMD_LIB") or os.path.join(_HERE, "csrc", "libclimb_hip.so")   # override: developer builds of the same ABI
+# Two builds of the same sources and ABI: bf16 operands (BASELINE configs[1], the default) and IEEE-half operands (8x smaller operand
+# rounding at the same MFMA rate; the engine then scales the loss gradient).  A process holds ONE of them: chosen by CLIMB_AMD_H16, or by
+# the first engine that asks (select_h16); CLIMB_AMD_LIB overrides the path (developer builds of the same ABI).
+_LIB_FILES = {"bf16": "libclimb_hip.so", "fp16": "libclimb_hip_f16.so"}
+_h16_choice = os.environ.get("CLIMB_AMD_H16") or None
+LIB_PATH = os.environ.get("CLIMB_AMD_LIB") or os.path.join(_HERE, "csrc", _LIB_FILES[_h16_choice or "bf16"])
+
+
+def select_h16(name: str):
+    """Ask for the library build with 16-bit operand type `name` ("bf16" / "fp16").  Fails loudly if the process already loaded the other."""
+    global _h16_choice, LIB_PATH
+    if name not in _LIB_FILES:
+        raise ValueError(f"unknown 16-bit operand type {name!r}")
+    if _lib is not None:
+        if h16() != name:
+            raise RuntimeError(f"climb_amd: this process loaded the {h16()} build of the HIP library ({LIB_PATH}); a {name} engine needs the other "
+                               f"one. Set CLIMB_AMD_H16={name} (or create the {name} model first): one process, one 16-bit operand type.")
+        return
+    if _h16_choice is not None and _h16_choice != name and not os.environ.get("CLIMB_AMD_LIB"):
+        raise RuntimeError(f"climb_amd: CLIMB_AMD_H16={_h16_choice} but a {name} engine was requested")
+    _h16_choice = name
+    if not os.environ.get("CLIMB_AMD_LIB"):
+        LIB_PATH = os.path.join(_HERE, "csrc", _LIB_FILES[name])
+
+
+def h16() -> str:
+    """16-bit operand type of the loaded library."""
+    return load().climb_h16().decode()
+
+
+def torch_h16():
+    import torch
+    return torch.float16 if h16() == "fp16" else torch.bfloat16
+
 
 _PROTO = re.compile(r"^\s*(int|const char\*)\s+(climb_\w+)\s*\(([^)]*)\)\s*;", re.M)
 

@@ -107,10 +107,10 @@ class BertParams(nn.Module):
                           ("ln1_b", "attention.output.LayerNorm.bias"), ("w1", "intermediate.dense.weight"), ("b1", "intermediate.dense.bias"),
                           ("w2", "output.dense.weight"), ("b2", "output.dense.bias"), ("ln2_w", "output.LayerNorm.weight"), ("ln2_b", "output.LayerNorm.bias")):
             pk[key] = stack(lambda l, name=name: sd[l + name])
-        if self.precision == "bf16":
+        if self.precision != "fp32":
             for key in ("wqkv", "wo", "w1", "w2"):
                 src = pk[key]
-                dst = torch.empty(src.shape, dtype=torch.bfloat16, device=dev)
+                dst = torch.empty(src.shape, dtype=_lib.torch_h16(), device=dev)
                 _lib.call("climb_cast_bf16", src, dst, src.numel(), _stream())
                 pk[key + "_op"] = dst
         else:
@@ -128,7 +128,7 @@ class BertParams(nn.Module):
             H, Fd, nh = self.cfg["hidden"], self.cfg["ffn"], self.cfg["heads"]
             Tp = _round_up(T, 32)
             M = B * Tp
-            adt = torch.float32 if self.precision == "fp32" else torch.bfloat16
+            adt = torch.float32 if self.precision == "fp32" else _lib.torch_h16()
 
             def buf(shape, dt=torch.float32):
                 return torch.zeros(shape, dtype=dt, device=dev)
@@ -173,13 +173,13 @@ class BertParams(nn.Module):
                   cfg["ln_eps"], x, B, T, Tp, H, ws["tmean"], ws["trstd"], 0, st)
         attn = "climb_attn_fwd_f32" if self.precision == "fp32" else "climb_attn_fwd_bf16"
         for i in range(cfg["layers"]):
-            if self.precision == "bf16":
+            if self.precision != "fp32":
                 _lib.call("climb_cast_bf16", x, ws["xb"], M * H, st)
             self._gemm(ws["xb"], pk["wqkv_op"][i], pk["bqkv"][i], ws["qkv"], M, 3 * H, H)
             _lib.call(attn, ws["qkv"], ws["key_bias"], ws["ctx"], ws["lse"], B, Tp, nh, cfg["head_dim"], st)
             self._gemm(ws["ctx"], pk["wo_op"][i], pk["bo"][i], ws["y"], M, H, H, EPI_RESID, aux=x, out_f32=True)          # + x (HFB:290)
             self._ln(ws["y"], pk["ln1_w"][i], pk["ln1_b"][i], ws["h"], F32, ws, M)
-            if self.precision == "bf16":
+            if self.precision != "fp32":
                 self._ln(ws["y"], pk["ln1_w"][i], pk["ln1_b"][i], ws["hb"], BF16, ws, M)
             self._gemm(ws["hb"], pk["w1_op"][i], pk["b1"][i], ws["a"], M, Fd, H, EPI_GELU, aux_out=ws["pre"])
             self._gemm(ws["a"], pk["w2_op"][i], pk["b2"][i], ws["y"], M, H, Fd, EPI_RESID, aux=ws["h"], out_f32=True)          # + h (HFB:349)

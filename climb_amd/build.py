@@ -11,6 +11,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libclimb_hip.so")
+LIB_F16 = os.path.join(CSRC, "libclimb_hip_f16.so")      # the same sources with IEEE-half operands (common.h: CLIMB_H16_F16)
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc"]
 
@@ -27,8 +28,12 @@ def _stale(target, deps):
 
 
 def build_library(force: bool = False, verbose: bool = True) -> str:
+    _build(LIB_F16, os.path.join(CSRC, "build", "f16"), ["-DCLIMB_H16_F16=1"], force, verbose)
+    return _build(LIB, os.path.join(CSRC, "build"), [], force, verbose)
+
+
+def _build(LIB: str, objdir: str, extra, force: bool, verbose: bool) -> str:
     hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
-    objdir = os.path.join(CSRC, "build")
     os.makedirs(objdir, exist_ok=True)
     jobs = []
     for s in sources():
@@ -39,7 +44,7 @@ def build_library(force: bool = False, verbose: bool = True) -> str:
 
     def cc(job):
         src, obj = job
-        cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
+        cmd = [HIPCC] + FLAGS + extra + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)

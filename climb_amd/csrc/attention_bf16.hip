@@ -356,7 +356,7 @@ __global__ __launch_bounds__(576) void attn_fwd_bf16_kernel(const bf16_t* __rest
     for (int ks = 0; ks < 4; ++ks) {
       const bf16x8 kf = row_frag(smem + kb * AB_BLK, ks, lane);
 #pragma unroll
-      for (int q = 0; q < QB; ++q) s[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[q][ks], s[q], 0, 0, 0);
+      for (int q = 0; q < QB; ++q) s[q] = CLIMB_MFMA_H16(kf, qf[q][ks], s[q], 0, 0, 0);
     }
     unsigned int pk[QB][8];
 #pragma unroll
@@ -367,15 +367,15 @@ __global__ __launch_bounds__(576) void attn_fwd_bf16_kernel(const bf16_t* __rest
     col_frags2<1, 0>(vf, va, kb);
 #pragma unroll
     for (int q = 0; q < QB; ++q) {
-      o[q][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0], packed4(pk[q], 0), o[q][0], 0, 0, 0);
-      o[q][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1], packed4(pk[q], 0), o[q][1], 0, 0, 0);
+      o[q][0] = CLIMB_MFMA_H16(vf[0], packed4(pk[q], 0), o[q][0], 0, 0, 0);
+      o[q][1] = CLIMB_MFMA_H16(vf[1], packed4(pk[q], 0), o[q][1], 0, 0, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
     col_frags2<1, 1>(vf, va, kb);
 #pragma unroll
     for (int q = 0; q < QB; ++q) {
-      o[q][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0], packed4(pk[q], 1), o[q][0], 0, 0, 0);
-      o[q][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1], packed4(pk[q], 1), o[q][1], 0, 0, 0);
+      o[q][0] = CLIMB_MFMA_H16(vf[0], packed4(pk[q], 1), o[q][0], 0, 0, 0);
+      o[q][1] = CLIMB_MFMA_H16(vf[1], packed4(pk[q], 1), o[q][1], 0, 0, 0);
     }
   }
   AB_STAMP(12);
@@ -524,8 +524,8 @@ __global__ __launch_bounds__(576) void attn_bwd_bf16_kernel(const bf16_t* __rest
       }
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(smem + ib * AB_BLK, ks, lane), f1[ks], s, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(smem + ib * AB_BLK + AB_Y, ks, lane), f2[ks], dp, 0, 0, 0);
+        s = CLIMB_MFMA_H16(row_frag(smem + ib * AB_BLK, ks, lane), f1[ks], s, 0, 0, 0);
+        dp = CLIMB_MFMA_H16(row_frag(smem + ib * AB_BLK + AB_Y, ks, lane), f2[ks], dp, 0, 0, 0);
       }
       // P and dS go to bf16 pairs as they are made (MFMA k-slot pair i of step st = i >> 2): 16 live registers, not 32
       unsigned int pk[8], dsk[8];
@@ -546,27 +546,27 @@ __global__ __launch_bounds__(576) void attn_bwd_bf16_kernel(const bf16_t* __rest
 #pragma unroll
         for (int st = 0; st < 2; ++st) {
           const bf16x8 dsf = packed4(dsk, st);
-          acc1[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[st][0], dsf, acc1[0], 0, 0, 0);
-          acc1[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[st][1], dsf, acc1[1], 0, 0, 0);
+          acc1[0] = CLIMB_MFMA_H16(xf[st][0], dsf, acc1[0], 0, 0, 0);
+          acc1[1] = CLIMB_MFMA_H16(xf[st][1], dsf, acc1[1], 0, 0, 0);
         }
       } else {
         // phase 1 has no registers to spare (64 accumulators + 32 K/V rows): one k-step's fragments at a time
         bf16x8 f[2];
         col_frags2<0, 0>(f, xa, ib);
-        acc1[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[0], packed4(dsk, 0), acc1[0], 0, 0, 0);
-        acc1[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[1], packed4(dsk, 0), acc1[1], 0, 0, 0);
+        acc1[0] = CLIMB_MFMA_H16(f[0], packed4(dsk, 0), acc1[0], 0, 0, 0);
+        acc1[1] = CLIMB_MFMA_H16(f[1], packed4(dsk, 0), acc1[1], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
         col_frags2<1, 0>(f, xa, ib);
-        acc2[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[0], packed4(pk, 0), acc2[0], 0, 0, 0);
-        acc2[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[1], packed4(pk, 0), acc2[1], 0, 0, 0);
+        acc2[0] = CLIMB_MFMA_H16(f[0], packed4(pk, 0), acc2[0], 0, 0, 0);
+        acc2[1] = CLIMB_MFMA_H16(f[1], packed4(pk, 0), acc2[1], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
         col_frags2<0, 1>(f, xa, ib);
-        acc1[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[0], packed4(dsk, 1), acc1[0], 0, 0, 0);
-        acc1[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[1], packed4(dsk, 1), acc1[1], 0, 0, 0);
+        acc1[0] = CLIMB_MFMA_H16(f[0], packed4(dsk, 1), acc1[0], 0, 0, 0);
+        acc1[1] = CLIMB_MFMA_H16(f[1], packed4(dsk, 1), acc1[1], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
         col_frags2<1, 1>(f, xa, ib);
-        acc2[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[0], packed4(pk, 1), acc2[0], 0, 0, 0);
-        acc2[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[1], packed4(pk, 1), acc2[1], 0, 0, 0);
+        acc2[0] = CLIMB_MFMA_H16(f[0], packed4(pk, 1), acc2[0], 0, 0, 0);
+        acc2[1] = CLIMB_MFMA_H16(f[1], packed4(pk, 1), acc2[1], 0, 0, 0);
       }
     }
     bf16_t* orow = dqkv + ((long)b * S_pad + my) * ld + h * AB_D;

@@ -10,10 +10,28 @@
 #define CLIMB_DT_F32 0
 #define CLIMB_DT_BF16 1
 
-typedef unsigned short bf16_t;  // raw bf16 bits
+// The 16-bit operand type of the throughput mode.  One source tree, two libraries: libclimb_hip.so (bf16: 8 significant bits, fp32's range;
+// BASELINE configs[1]) and libclimb_hip_f16.so (-DCLIMB_H16_F16: IEEE half, 11 significant bits -- 8x smaller operand rounding at the same
+// MFMA rate, but 5 exponent bits: the host scales the loss gradient).  Every conversion goes through the helpers
+// below and CLIMB_MFMA_H16; names keep "bf16" (the C ABI's CLIMB_DT_BF16 means "the library's 16-bit type").
+#ifndef CLIMB_H16_F16
+#define CLIMB_H16_F16 0
+#endif
+#if CLIMB_H16_F16
+typedef _Float16 h16_scalar_t;
+#define CLIMB_MFMA_H16 __builtin_amdgcn_mfma_f32_32x32x16_f16
+#define CLIMB_H16_NAME "fp16"
+#define CLIMB_H16_ONE_X2 0x3C003C00u          // two packed 1.0
+#else
+typedef __bf16 h16_scalar_t;
+#define CLIMB_MFMA_H16 __builtin_amdgcn_mfma_f32_32x32x16_bf16
+#define CLIMB_H16_NAME "bf16"
+#define CLIMB_H16_ONE_X2 0x3F803F80u
+#endif
+typedef unsigned short bf16_t;  // raw bits of the 16-bit type
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) h16_scalar_t bf16x8;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(8))) short s16x8;
 
@@ -23,12 +41,22 @@ typedef __attribute__((ext_vector_type(8))) short s16x8;
     if (e__ != hipSuccess) return (int)e__;              \
   } while (0)
 
+#if CLIMB_H16_F16
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return (float)__builtin_bit_cast(_Float16, v); }
+// two packed 16-bit values -> floats (lo = bits 0..15)
+__device__ __forceinline__ float h16lo_to_f32(uint32_t u) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(u & 0xffffu)); }
+__device__ __forceinline__ float h16hi_to_f32(uint32_t u) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(u >> 16)); }
+#else
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
-// fp32 -> bf16, round-to-nearest-even: the casts lower to the gfx950 hardware converter v_cvt_pk_bf16_f32
+__device__ __forceinline__ float h16lo_to_f32(uint32_t u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float h16hi_to_f32(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
+#endif
+// fp32 -> 16 bit, round-to-nearest-even: the casts lower to the gfx950 hardware converters v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32
+// (fp16: values beyond +-65504 become inf -- forward activations of this model are far inside, gradients are scaled by the host)
 typedef __attribute__((ext_vector_type(2))) float f32x2_t;
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) h16_scalar_t bf16x2_t;
 __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
-  __bf16 h = (__bf16)f;
+  h16_scalar_t h = (h16_scalar_t)f;
   return __builtin_bit_cast(bf16_t, h);
 }
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
@@ -51,8 +79,7 @@ template <> struct Act<bf16_t> {
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ float4 ld4(const bf16_t* p) {
   uint2 r = *reinterpret_cast<const uint2*>(p);
-  return make_float4(__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u),
-                     __uint_as_float(r.y << 16), __uint_as_float(r.y & 0xffff0000u));
+  return make_float4(h16lo_to_f32(r.x), h16hi_to_f32(r.x), h16lo_to_f32(r.y), h16hi_to_f32(r.y));
 }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 __device__ __forceinline__ void st4(bf16_t* p, float4 v) {

@@ -112,7 +112,7 @@ void gemm_bf16_nt_kernel(const bf16_t* __restrict__ A, long lda, const bf16_t* _
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < MJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[i], fa[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < MJ; ++j) acc[i][j] = CLIMB_MFMA_H16(fb[i], fa[j], acc[i][j], 0, 0, 0);
     }
     if constexpr (!GLDS) {
       if (kt + 1 < nk) {
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt64_kernel(const bf16_t* __res
         fb[i] = as_bf16x8(*reinterpret_cast<const u32x4*>(Bs + rowb * 128 + ((c ^ swz(rowb)) << 4)));
       }
 #pragma unroll
-      for (int i = 0; i < 2; ++i) acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[i], fa, acc[i][0], 0, 0, 0);
+      for (int i = 0; i < 2; ++i) acc[i][0] = CLIMB_MFMA_H16(fb[i], fa, acc[i][0], 0, 0, 0);
     }
     __syncthreads();
   }
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(384) void gemm_bf16_nt96_kernel(const bf16_t* __res
         fb[i] = as_bf16x8(*reinterpret_cast<const u32x4*>(Bs + rowb * 128 + ((c ^ swz(rowb)) << 4)));
       }
 #pragma unroll
-      for (int i = 0; i < 3; ++i) acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[i], fa, acc[i][0], 0, 0, 0);
+      for (int i = 0; i < 3; ++i) acc[i][0] = CLIMB_MFMA_H16(fb[i], fa, acc[i][0], 0, 0, 0);
     }
     __syncthreads();
   }
@@ -303,7 +303,7 @@ __global__ __launch_bounds__(768) void gemm_bf16_nt192_kernel(const bf16_t* __re
         fb[i] = as_bf16x8(*reinterpret_cast<const u32x4*>(Bs + rowb * 128 + ((c ^ swz(rowb)) << 4)));
       }
 #pragma unroll
-      for (int i = 0; i < 3; ++i) acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[i], fa, acc[i][0], 0, 0, 0);
+      for (int i = 0; i < 3; ++i) acc[i][0] = CLIMB_MFMA_H16(fb[i], fa, acc[i][0], 0, 0, 0);
     }
   }
   __syncthreads();      // every wave is past the last k-tile: the stages become 12 per-wave 12 KB staging regions
@@ -539,7 +539,7 @@ __global__ __launch_bounds__(512 / NI) void gemm_bf16_tn_kernel(const bf16_t* __
   bf16x8 ones;
   {
     union { unsigned int u[4]; bf16x8 b; } c;
-    c.u[0] = c.u[1] = c.u[2] = c.u[3] = 0x3F803F80u;
+    c.u[0] = c.u[1] = c.u[2] = c.u[3] = CLIMB_H16_ONE_X2;
     ones = c.b;
   }
   u32x4 ra[4], rb[4];
@@ -577,10 +577,10 @@ __global__ __launch_bounds__(512 / NI) void gemm_bf16_tn_kernel(const bf16_t* __
 #pragma unroll
       for (int i = 0; i < NI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 2; ++j) acc[i][j] = CLIMB_MFMA_H16(fa[i], fb[j], acc[i][j], 0, 0, 0);
       if (do_bias && (t % nkt) == ktile) {
 #pragma unroll
-        for (int i = 0; i < NI; ++i) accb[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], ones, accb[i], 0, 0, 0);
+        for (int i = 0; i < NI; ++i) accb[i] = CLIMB_MFMA_H16(fa[i], ones, accb[i], 0, 0, 0);
       }
     }
     if constexpr (!GLDS) if (t + 1 < nt) {

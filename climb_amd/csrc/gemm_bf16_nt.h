@@ -86,7 +86,7 @@ __device__ __forceinline__ void nt_aux_touch(AuxRegs<EPI, CNT>& ax) {
   }
 }
 __device__ __forceinline__ float4 bf16x4_to_f32(uint2 r) {
-  return make_float4(__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16), __uint_as_float(r.y & 0xffff0000u));
+  return make_float4(h16lo_to_f32(r.x), h16hi_to_f32(r.x), h16lo_to_f32(r.y), h16hi_to_f32(r.y));
 }
 
 // One 32-row block of a wave's output, in two steps: nt_epi_stage writes the accumulators acc[0..NI) (32 x NI*32, lane = row) into the

@@ -85,7 +85,7 @@ __device__ __forceinline__ void nt2_phase(f32x16 (&acc)[NT2_NI][2], bf16x8 (&a)[
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-    for (int jj = 0; jj < 2; ++jj) acc[P][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[ks], a[jj][ks], acc[P][jj], 0, 0, 0);
+    for (int jj = 0; jj < 2; ++jj) acc[P][jj] = CLIMB_MFMA_H16(b[ks], a[jj][ks], acc[P][jj], 0, 0, 0);
   __builtin_amdgcn_s_setprio(0);
   __builtin_amdgcn_sched_barrier(0);
 }

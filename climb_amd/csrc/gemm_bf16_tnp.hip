@@ -72,7 +72,7 @@ __device__ __forceinline__ float tnp_sum8(bf16x8 v) {
   c.b = v;
   float s = 0.f;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) s += __uint_as_float(c.u[i] << 16) + __uint_as_float(c.u[i] & 0xffff0000u);
+  for (int i = 0; i < 4; ++i) s += h16lo_to_f32(c.u[i]) + h16hi_to_f32(c.u[i]);
   return s;
 }
 
@@ -101,7 +101,7 @@ __device__ __forceinline__ void tnp_phase(f32x16 (&acc)[NI][2], bf16x8 (&a)[2][4
 #pragma unroll
   for (int ms = 0; ms < 4; ++ms)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) acc[P][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[j][ms], b[ms], acc[P][j], 0, 0, 0);
+    for (int j = 0; j < 2; ++j) acc[P][j] = CLIMB_MFMA_H16(a[j][ms], b[ms], acc[P][j], 0, 0, 0);
   __builtin_amdgcn_s_setprio(0);
   if constexpr (P == 1) {          // bias share of this reduction tile (VALU, beside the other wave group's MFMAs)
     if (bias_tile) {

@@ -256,6 +256,7 @@ extern "C" int climb_transpose_bf16_batched(const void* src, void* dst, const lo
 
 extern "C" int climb_version() { return 100; }
 extern "C" const char* climb_arch() { return "gfx950"; }
+extern "C" const char* climb_h16() { return CLIMB_H16_NAME; }
 extern "C" const char* climb_error_string(int code) {
   if (code == CLIMB_OK) return "ok";
   if (code == CLIMB_EINVAL) return "climb: invalid argument";

@@ -62,7 +62,7 @@ class Workspace:
         self.S_pad = _round_up(self.S, 32)
         self.M = B * self.S_pad
         M = self.M
-        adt = torch.float32 if eng.precision == "fp32" else torch.bfloat16
+        adt = torch.float32 if eng.precision == "fp32" else eng.t16
         f32 = torch.float32
 
         def buf(shape, dt=f32):
@@ -129,7 +129,18 @@ class HeadState:
 
 class ViltEngine:
     def __init__(self, layout: FlatLayout, device: torch.device, precision: str = "bf16", task_cfgs: Optional[Dict[str, dict]] = None):
-        assert precision in ("fp32", "bf16")
+        # "fp16": the throughput ("bf16") code path on the IEEE-half build of the library, with a scaled loss gradient
+        assert precision in ("fp32", "bf16", "fp16")
+        self.h16 = None if precision == "fp32" else precision
+        if self.h16 is not None:
+            _lib.select_h16(self.h16)
+            if _lib.h16() != self.h16:
+                raise RuntimeError(f"engine precision {precision}: the loaded HIP library computes in {_lib.h16()}")
+            self.t16 = _lib.torch_h16()
+        self.precision_name = precision
+        precision = "fp32" if precision == "fp32" else "bf16"      # the two code paths; `h16` says which 16-bit type the second one runs on
+        self.loss_scale = 1.0           # fp16 only: factor on d(logits) of the current backward, divided out of every range in _ready()
+        self._grad_dirty = False        # the gradient buffer holds sums of earlier backwards (accumulation without zero_grad)
         self.layout = layout
         self.cfg = layout.cfg
         self.device = torch.device(device)
@@ -184,6 +195,21 @@ class ViltEngine:
     def zero_grad(self):
         self.grad.zero_()
         self.touched = []
+        self._grad_dirty = False
+
+    def begin_scaled_backward(self, max_dlogit: float):
+        """fp16 operands only.  Picks the power-of-two loss scale that puts the largest possible |d(logits)| near 1 (the BCE gradient of a
+        64 x 3129 mean is 2.5e-6 per element: below IEEE half's normal range by the time it reaches the first 16-bit GEMM operand) and, if the
+        gradient buffer already holds sums of earlier backwards, brings those to the same scale so that _ready() can divide every range once."""
+        if self.h16 != "fp16":
+            self.loss_scale = 1.0
+            return 1.0
+        import math
+        self.loss_scale = float(2.0 ** max(0, min(24, math.floor(math.log2(128.0 / max(max_dlogit, 1e-30))))))      # |d(logits)| <= 128: 2^9 below half's largest number
+        if self._grad_dirty and self.loss_scale != 1.0:
+            _lib.call("climb_scale_f32", self.grad, self.grad.numel(), self.loss_scale, _stream())
+        self._grad_dirty = True
+        return self.loss_scale
 
     def is_touched(self, name: str) -> bool:
         o = self.layout.offset[name]
@@ -297,14 +323,14 @@ class ViltEngine:
     def _build_shadow(self):
         import numpy as np
         dev = self.device
-        self._shadow = torch.empty(self.layout.total, dtype=torch.bfloat16, device=dev)
+        self._shadow = torch.empty(self.layout.total, dtype=self.t16, device=dev)
         rows, off = [], 0
         self._t_off = {}
         for name, N, K in self._linear_weight_names():
             self._t_off[name] = off
             rows.append((self.layout.offset[name], off, N, K))
             off += N * K
-        self._shadow_t = torch.empty(off, dtype=torch.bfloat16, device=dev)
+        self._shadow_t = torch.empty(off, dtype=self.t16, device=dev)
         self._t_table = torch.from_numpy(np.array(rows, dtype=np.int64)).to(dev)
         self._t_n = len(rows)
 
@@ -522,6 +548,8 @@ class ViltEngine:
 
     def _ready(self, lo, hi):
         for a, b in self._trainable_runs(lo, hi):
+            if self.loss_scale != 1.0:          # fp16 operands: this backward's contributions (and, pre-scaled, earlier sums) carry the loss scale
+                _lib.call("climb_scale_f32", self.grad[a:b], b - a, 1.0 / self.loss_scale, _stream())
             self.touched.append((a, b))
             if self.grad_ready_hook is not None:
                 self.grad_ready_hook(a, b)

@@ -283,7 +283,13 @@ class _EncoderFn(torch.autograd.Function):
                                "run backward before the next grad-enabled forward (or sum the losses of ONE forward)")
         host.before_backward()
         first, emb = host.frozen_prefix()
-        host._engine.encoder_backward(dpooled.contiguous().float(), first_layer=first, embeddings=emb)
+        eng = host._engine
+        dpooled = dpooled.contiguous().float()
+        if eng.h16 == "fp16":
+            if not getattr(eng, "_scaled_by_head", False):       # no head of this package upstream of us in this backward: scale here
+                dpooled = dpooled * eng.begin_scaled_backward(float(dpooled.abs().max()))
+            eng._scaled_by_head = False
+        host._engine.encoder_backward(dpooled, first_layer=first, embeddings=emb)
         host.after_backward()
         if host.ddp is not None:
             host.ddp.finish()
@@ -301,8 +307,16 @@ class _HeadFn(torch.autograd.Function):
     def backward(ctx, dlogits):
         host = ctx.host
         host.before_backward()
-        dx = host._engine.head_backward(ctx.hs, dlogits.contiguous().float())
+        eng = host._engine
+        dlogits = dlogits.contiguous().float()
+        if eng.h16 == "fp16":       # torch computed this d(logits): bring it into IEEE half's range (one host sync, compatibility path only);
+            # the scaled d(pooled) flows through autograd into _EncoderFn.backward and every range is unscaled in the engine's _ready()
+            dlogits = dlogits * eng.begin_scaled_backward(float(dlogits.abs().max()))
+            eng._scaled_by_head = True
+        dx = eng.head_backward(ctx.hs, dlogits)
         host.after_backward()
+        if eng.h16 == "fp16" and not ctx.needs_input_grad[0]:
+            eng._scaled_by_head = False
         return dx, None, None, None, None
 
 
@@ -545,7 +559,9 @@ class ViltContinualLearner(ContinualLearner):
         target = target.to(eng.device, non_blocking=True)
         if task_key == "vqa":
             target = target.float()
-        loss, dlogits = eng.loss_and_grad(task_key, logits, target, hs=hs)
+        # fp16 operands: d(logits) is produced already multiplied by the loss scale (every |d logit| of both losses is <= 1 / rows)
+        gs = eng.begin_scaled_backward(1.0 / max(1, logits.shape[0]))
+        loss, dlogits = eng.loss_and_grad(task_key, logits, target, gscale=gs, hs=hs)
         dpool = eng.head_backward(hs, dlogits)
         first, emb = host.frozen_prefix()
         if host.any_encoder_grad() is not None:

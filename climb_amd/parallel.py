@@ -98,10 +98,13 @@ class GradientAllReducer:
         self.eng = eng
         eng.grad_ready_hook = self.on_ready
         mode = os.environ.get("CLIMB_AMD_DP_COMPRESS") or self.compress
+        fp16_lib = getattr(eng, "h16", None) == "fp16"       # the library's 16-bit cast is IEEE half there: unscaled gradients do not fit its range
         if mode is None:
-            mode = "bf16" if getattr(eng, "precision", "fp32") == "bf16" else "none"
+            mode = "bf16" if (getattr(eng, "precision", "fp32") == "bf16" and not fp16_lib) else "none"
         if mode not in ("none", "bf16"):
             raise ValueError(f"unknown gradient compression {mode!r}")
+        if mode == "bf16" and fp16_lib:
+            raise ValueError("gradient compression 'bf16' is not available on the fp16-operand build of the library (its 16-bit cast is IEEE half)")
         self.compress = mode
         self._stage = self._pack = None
 

@@ -24,6 +24,9 @@ extern "C" {
 /* ---- library ---------------------------------------------------------------------------------------------------- */
 int climb_version(void);
 const char* climb_arch(void);
+/* the 16-bit operand type this build of the library computes in: "bf16" (libclimb_hip.so) or "fp16" (libclimb_hip_f16.so, the same sources
+ * with -DCLIMB_H16_F16=1).  Every `void*` 16-bit buffer and CLIMB_DT_BF16 below mean that type. */
+const char* climb_h16(void);
 const char* climb_error_string(int code);
 int climb_device_sync(void);
 /* tuning switches for A/B measurements: key 1 = waves per workgroup of the 128x128 bf16 NT GEMM (4 or 8); key 2 / 4 / 5 = allow the

@@ -1,0 +1,50 @@
+"""The IEEE-half build of the library (libclimb_hip_f16.so: the same sources with -DCLIMB_H16_F16=1).  A process holds one
+16-bit operand type, so everything here runs in subprocesses with CLIMB_AMD_H16=fp16:
+  * the kernel suite (tests/test_gpu_kernels.py) against float64 of the same half-rounded operands;
+  * one training step at the benchmark's batch size against the REFERENCE's outputs (tests/golden/vqa_b64.npz): the throughput mode on
+    fp16 operands with a scaled loss gradient -- logits and gradient norms inside north_star's 1e-3, every argmax equal to the reference's;
+  * the step-level parity tests of tests/test_gpu_parity.py in that mode (autograd path, gradient accumulation, EWC, hipGraph, training curve)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, timeout=1500):
+    env = dict(os.environ, CLIMB_AMD_H16="fp16")
+    env.pop("CLIMB_AMD_LIB", None)
+    return subprocess.run([sys.executable] + args, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_fp16_build_passes_the_kernel_suite():
+    r = _run(["-m", "pytest", "tests/test_gpu_kernels.py", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider"])
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
+
+
+def test_fp16_step_against_the_reference_at_batch_64():
+    r = _run(["tools/probe/fp16_mode_check.py"])
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("fp16 {")][-1]
+    e = json.loads(line[5:])
+    print(e)
+    assert e["logits"] < 1.5e-3 and e["loss"] < 1e-4 and e["argmax_agreement"] == 1.0
+    assert e["pooled"] < 5e-3                      # max-norm; the bf16 build: 2.2e-2
+    assert e["grad_norm_rel_err_median"] < 1e-4 and e["grad_norm_rel_err_max"] < 1e-3
+
+
+def test_fp16_mode_passes_the_step_level_parity_tests():
+    """tests/test_gpu_parity.py with H16 = fp16 (bf16 tolerances, i.e. loose for this mode): reference fixtures at full size, the
+    reference-style autograd path (loss scale chosen from torch's d(logits)), the Fisher pass (gradient accumulation across backwards
+    without zero_grad: earlier sums are pre-scaled), EWC, mixed-orientation packing, hipGraph replay, shadow refresh after torch-side
+    writes, and 30 optimizer steps tracking the fp32 loss curve."""
+    sel = ("bf16_mode_step or full_size_bf16 or training_curve or reference_style_autograd or fisher_accumulating or ewc_penalty "
+           "or mixed_orientation or hipgraph or shadows_follow or variable_resolution")
+    r = _run(["-m", "pytest", "tests/test_gpu_parity.py", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider", "-k", sel], timeout=2400)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout

@@ -110,7 +110,7 @@ def test_layernorm_fwd_bwd(C, dt):
     dy = torch.randn(M, C, generator=g)
     dres = torch.randn(M, C, generator=g)
     code = 0 if dt == "f32" else 1
-    tdt = torch.float32 if dt == "f32" else torch.bfloat16
+    tdt = torch.float32 if dt == "f32" else _h16()
     tol = 2e-6 if dt == "f32" else 6e-3
     xd = x.to(dev)
     y = torch.empty(M, C, device=dev, dtype=tdt)
@@ -292,8 +292,15 @@ def test_adamw_ewc_fisher_flat_kernels():
 
 
 # ------------------------------------------------------------------------------------------------ bf16 throughput path
+def _h16():
+    """torch dtype of the loaded library's 16-bit operand type: bf16, or IEEE half when the suite runs as CLIMB_AMD_H16=fp16 (the second
+    build of the same sources; tests/test_gpu_fp16_build.py runs this file that way in a subprocess)."""
+    from climb_amd import _lib
+    return _lib.torch_h16()
+
+
 def _bf(x):
-    return x.to(torch.bfloat16)
+    return x.to(_h16())
 
 
 # the last two shapes select the 192x192 three-stage kernel (160..256 tiles), with a ragged last row tile
@@ -312,8 +319,8 @@ def test_gemm_bf16_nt(M, N, K):
     C32 = torch.empty(M, N, device=dev)
     _lib.call("climb_gemm_bf16_nt", Ad, K, Wd, K, C32, N, 0, M, N, K, bd, 0, None, 0, None, 0, None, 0, _st())
     assert _rel(C32, ref) < 1e-5
-    C16 = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
-    U = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    C16 = torch.empty(M, N, device=dev, dtype=_h16())
+    U = torch.empty(M, N, device=dev, dtype=_h16())
     _lib.call("climb_gemm_bf16_nt", Ad, K, Wd, K, C16, N, 1, M, N, K, bd, 1, None, 0, U, N, None, 0, _st())
     assert _rel(U.float(), ref) < 5e-3 and _rel(C16.float(), gelu(ref)) < 5e-3
     R = torch.randn(M, N, generator=g).to(dev)
@@ -344,8 +351,8 @@ def test_gemm_bf16_nt_256_tiles(M, N, K, force):
         C32 = torch.full((M + 1, N), 7.0, device=dev)          # one guard row: a tile that stores past M would be seen
         _lib.call("climb_gemm_bf16_nt", Ad, K, Wd, K, C32, N, 0, M, N, K, bd, 0, None, 0, None, 0, None, 0, _st())
         assert _rel(C32[:M], ref) < 1e-5 and bool((C32[M] == 7.0).all())
-        C16 = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
-        U = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+        C16 = torch.empty(M, N, device=dev, dtype=_h16())
+        U = torch.empty(M, N, device=dev, dtype=_h16())
         _lib.call("climb_gemm_bf16_nt", Ad, K, Wd, K, C16, N, 1, M, N, K, bd, 1, None, 0, U, N, None, 0, _st())
         assert _rel(U.float(), ref) < 5e-3 and _rel(C16.float(), gelu(ref)) < 5e-3
         R = torch.randn(M, N, generator=g).to(dev)
@@ -371,8 +378,8 @@ def test_gemm_bf16_nt_256_race_screen_full_size(N, K, force):
     dev = _dev()
     M = 12288
     g = torch.Generator(device=dev).manual_seed(N + K)
-    Ad = torch.randn(M, K, device=dev, generator=g).bfloat16()
-    Wd = (torch.randn(N, K, device=dev, generator=g) * 0.05).bfloat16()
+    Ad = torch.randn(M, K, device=dev, generator=g).to(_h16())
+    Wd = (torch.randn(N, K, device=dev, generator=g) * 0.05).to(_h16())
     ref = torch.empty(M, N, device=dev)
     try:
         _lib.call("climb_set_option", 7, 0)
@@ -427,12 +434,12 @@ def test_attention_bf16_fwd_bwd(S_pad, valid):
     ref = _attn_ref(qr, bias.double().clamp(min=-1e300), heads)
     ref.backward(dctx.double())
     qd, bd, dd = qkv.to(dev).view(B * S_pad, 3 * H), bias.to(dev), dctx.to(dev).view(B * S_pad, H)
-    ctx = torch.empty(B * S_pad, H, device=dev, dtype=torch.bfloat16)
+    ctx = torch.empty(B * S_pad, H, device=dev, dtype=_h16())
     lse = torch.empty(B, heads, S_pad, device=dev)
     _lib.call("climb_attn_fwd_bf16", qd, bd, ctx, lse, B, S_pad, heads, d, _st())
     e_fwd = _rel(ctx.float().view(B, S_pad, H)[:, :valid], ref.detach()[:, :valid])
     delta = torch.empty(B, heads, S_pad, device=dev)
-    dqkv = torch.full((B * S_pad, 3 * H), float("nan"), device=dev, dtype=torch.bfloat16)
+    dqkv = torch.full((B * S_pad, 3 * H), float("nan"), device=dev, dtype=_h16())
     delta.fill_(float("nan"))           # scratch: written by the kernel's first phase
     _lib.call("climb_attn_bwd_bf16", qd, bd, dd, ctx, lse, delta, dqkv, B, S_pad, heads, d, _st())
     assert not torch.isnan(dqkv.float()).any()
@@ -458,7 +465,7 @@ def test_attention_bf16_forward_variants_agree(S_pad):
     try:
         for qb in (1, 2, 0):
             _lib.call("climb_set_option", 12, qb)
-            ctx = torch.empty(B * S_pad, H, device=dev, dtype=torch.bfloat16)
+            ctx = torch.empty(B * S_pad, H, device=dev, dtype=_h16())
             lse = torch.empty(B, heads, S_pad, device=dev)
             _lib.call("climb_attn_fwd_bf16", qkv, bias, ctx, lse, B, S_pad, heads, d, _st())
             outs.append((ctx.float().cpu(), lse.cpu()))
@@ -488,10 +495,10 @@ def test_attention_bf16_edge_inputs(case):
     qkv = _bf(qkv)
     dctx = _bf(torch.randn(B, S_pad, H, generator=g))
     qd, bd, dd = qkv.to(dev).view(B * S_pad, 3 * H), bias.to(dev), dctx.to(dev).view(B * S_pad, H)
-    ctx = torch.empty(B * S_pad, H, device=dev, dtype=torch.bfloat16)
+    ctx = torch.empty(B * S_pad, H, device=dev, dtype=_h16())
     lse = torch.empty(B, heads, S_pad, device=dev)
     delta = torch.empty(B, heads, S_pad, device=dev)
-    dqkv = torch.empty(B * S_pad, 3 * H, device=dev, dtype=torch.bfloat16)
+    dqkv = torch.empty(B * S_pad, 3 * H, device=dev, dtype=_h16())
     _lib.call("climb_attn_fwd_bf16", qd, bd, ctx, lse, B, S_pad, heads, d, _st())
     _lib.call("climb_attn_bwd_bf16", qd, bd, dd, ctx, lse, delta, dqkv, B, S_pad, heads, d, _st())
     c, dq = ctx.float().view(B, S_pad, H).cpu(), dqkv.float().view(B, S_pad, 3 * H).cpu()
@@ -513,9 +520,9 @@ def test_weight_shadow_cast_and_batched_transpose():
     g = torch.Generator().manual_seed(5)
     x = torch.randn(2 * 96 * 160, generator=g)
     xd = x.to(dev)
-    sh = torch.empty_like(xd, dtype=torch.bfloat16)
+    sh = torch.empty_like(xd, dtype=_h16())
     _lib.call("climb_cast_bf16", xd, sh, x.numel(), _st())
-    assert torch.equal(sh.cpu(), x.to(torch.bfloat16))
+    assert torch.equal(sh.cpu(), x.to(_h16()))
     out = torch.empty_like(sh)
     table = torch.tensor([[0, 0, 96, 160], [96 * 160, 96 * 160, 160, 96]], dtype=torch.int64, device=dev)
     _lib.call("climb_transpose_bf16_batched", sh, out, table, 2, 4, _st())
@@ -530,7 +537,7 @@ def test_abi_rejects_bad_arguments_with_codes_not_crashes():
     RuntimeError by the binding) instead of launching, throwing across the ABI or exiting."""
     from climb_amd import _lib
     dev = _dev()
-    a = torch.zeros(64, 64, device=dev, dtype=torch.bfloat16)
+    a = torch.zeros(64, 64, device=dev, dtype=_h16())
     c = torch.zeros(64, 64, device=dev)
     bad = [
         ("climb_gemm_bf16_nt", (a, 64, a, 64, c, 64, 0, 0, 64, 64, None, 0, None, 0, None, 0, None, 0, _st())),       # M = 0

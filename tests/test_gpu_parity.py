@@ -36,6 +36,11 @@ def _meta(z):
     return dict(kv.split("=", 1) for kv in str(z["meta"][0]).split(";"))
 
 
+# the 16-bit throughput mode under test: bf16, or IEEE half when the suite runs as CLIMB_AMD_H16=fp16 (tests/test_gpu_fp16_build.py
+# runs part of this file that way in a subprocess: one process holds one build of the library).  Tolerances below are the bf16 ones.
+H16 = os.environ.get("CLIMB_AMD_H16", "bf16")
+
+
 def make_model(tasks, wseed=42, precision="fp32"):
     from climb_amd.modeling import create_continual_learner_map
     from climb_amd.configs.task_configs import task_configs
@@ -348,7 +353,7 @@ def test_bf16_mode_step_vs_oracle(golden_dir):
     z = np.load(os.path.join(golden_dir, "vqa_b2.npz"))
     m = _meta(z)
     B = int(m["B"])
-    model, P = make_model(m["tasks"].split(","), int(m["wseed"]), precision="bf16")
+    model, P = make_model(m["tasks"].split(","), int(m["wseed"]), precision=H16)
     enc = vo.synthetic_encodings(B, seed=int(m["dseed"]))
     target = vo.synthetic_vqa_targets(B, seed=int(m["dseed"]))
     images, texts = enc_to_inputs(enc)
@@ -381,7 +386,7 @@ def test_bf16_shadows_follow_torch_side_parameter_writes(tmp_path):
     dev = _dev()
     B = 4
     pixels, texts, target = _rand_batch(B, 5, dev)
-    model, _ = make_model(["vqa"], 42, precision="bf16")
+    model, _ = make_model(["vqa"], 42, precision=H16)
     model.train()
     opt = model.create_optimizer({"lr": 1e-3, "weight_decay": 1e-2, "adam_epsilon": 1e-8})
     model.fused_forward_backward("vqa", pixels, texts, target)          # shadows built, one optimizer step taken
@@ -394,7 +399,7 @@ def test_bf16_shadows_follow_torch_side_parameter_writes(tmp_path):
     model.eval()
     with torch.no_grad():
         got = model(task_key="vqa", images=pixels, texts=texts)[1].clone()
-    fresh, _ = make_model(["vqa"], 43, precision="bf16")
+    fresh, _ = make_model(["vqa"], 43, precision=H16)
     fresh.eval()
     with torch.no_grad():
         want = fresh(task_key="vqa", images=pixels, texts=texts)[1].clone()
@@ -418,7 +423,7 @@ def test_bf16_shadows_follow_torch_side_parameter_writes(tmp_path):
 
 
 # ------------------------------------------------------------------------------------------------ Houlsby adapters (unpinned)
-@pytest.mark.parametrize("precision,tol", [("fp32", TOL), ("bf16", 4e-2)])
+@pytest.mark.parametrize("precision,tol", [("fp32", TOL), (H16, 4e-2)])
 def test_houlsby_adapter_nlvr2_step_vs_oracle_restatement(precision, tol):
     """The NLVR2 half of BASELINE.json configs[2]: two images per example (image_token_type_idx 1 / 2, REF/modeling/vilt.py:292-303)
     under an ACTIVE adapter, base frozen -- the step the VQA -> NLVR2 adapter sequence runs for its second task."""
@@ -461,7 +466,7 @@ def test_houlsby_adapter_nlvr2_step_vs_oracle_restatement(precision, tol):
     assert worst < (tol if precision == "fp32" else 6e-2)
 
 
-@pytest.mark.parametrize("precision,tol", [("fp32", TOL), ("bf16", 4e-2)])
+@pytest.mark.parametrize("precision,tol", [("fp32", TOL), (H16, 4e-2)])
 def test_houlsby_adapters_vs_oracle_restatement(precision, tol):
     """BASELINE.json configs[2] arithmetic.  The GLAMOR adapter fork is absent, so this pins the HIP path to the oracle's
     restatement of public adapter-transformers semantics (out = y + up(swish(down(y)))), not to the reference."""
@@ -528,7 +533,7 @@ def test_houlsby_adapters_vs_oracle_restatement(precision, tol):
 
 
 # ------------------------------------------------------------------------------------------------ ViLT-BERT (row F4)
-@pytest.mark.parametrize("precision,tol", [("fp32", TOL), ("bf16", 6e-2)])      # bf16: 24 layers of bf16 operands instead of 12 (measured: pooled 4.9e-2)
+@pytest.mark.parametrize("precision,tol", [("fp32", TOL), (H16, 6e-2)])      # bf16: 24 layers of bf16 operands instead of 12 (measured: pooled 4.9e-2)
 def test_viltbert_vs_reference(golden_dir, precision, tol):
     """REF/modeling/viltbert.py: a frozen BERT-base's last hidden state replaces ViLT's word-embedding lookup.  Golden = the reference's
     own ViltBertContinualLearner (eval mode) on seeded weights; the BERT features are also checked against the CPU oracle."""
@@ -659,7 +664,7 @@ BF16_FULL = dict(pooled=2.5e-2, logits=1.2e-2, loss=3e-3, grad_norm_max=3e-2)   
 
 @pytest.mark.parametrize("fname", FULL_SIZE)
 def test_full_size_bf16_vs_reference(golden_dir, fname):
-    e = full_size_errors(np.load(os.path.join(golden_dir, fname)), "bf16")
+    e = full_size_errors(np.load(os.path.join(golden_dir, fname)), H16)
     print(f"{fname} bf16 vs reference: {e}")
     for k, lim in BF16_FULL.items():
         assert e[k] <= lim, (k, e[k], lim)
@@ -707,7 +712,7 @@ def test_full_size_batch_permutation_and_mode_agreement():
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     del model
     torch.cuda.empty_cache()
-    m16, _ = make_model(["vqa"], 42, precision="bf16")
+    m16, _ = make_model(["vqa"], 42, precision=H16)
     m16.load_state_dict(sd)
     m16.train()
     loss16, (pooled16, logits16), _, _ = m16.fused_forward_backward("vqa", pixels, texts, target)
@@ -723,7 +728,7 @@ def test_full_size_batch_permutation_and_mode_agreement():
 
 
 # ------------------------------------------------------------------------------------------------ variable resolution (row F2)
-@pytest.mark.parametrize("precision,tol", [("fp32", TOL), ("bf16", BF16_TOL)])
+@pytest.mark.parametrize("precision,tol", [("fp32", TOL), (H16, BF16_TOL)])
 def test_variable_resolution_batch_vs_reference(golden_dir, precision, tol):
     """Padded variable-resolution batch (HF:92-178 masked visual_embed with per-sample bilinear position resize): the HIP path keeps
     every canvas patch in raster order and masks the invalid ones; the reference shuffles and pads randomly.  Pooled output,
@@ -791,7 +796,7 @@ def test_maximum_sequence_384x640_vs_oracle():
                                      vo.synthetic_vqa_targets(1, seed=5))
 
 
-@pytest.mark.parametrize("precision,tol", [("fp32", TOL), ("bf16", BF16_TOL)])
+@pytest.mark.parametrize("precision,tol", [("fp32", TOL), (H16, BF16_TOL)])
 def test_mixed_orientation_batch_packs_valid_patches(precision, tol):
     """A portrait image next to a landscape one pads to a 640 x 640 canvas = 400 patches, more than the 288-row sequences the
     attention tiles are sized for; no image has more than 240 valid patches, so the engine packs each sample's valid patches
@@ -829,7 +834,7 @@ def test_hipgraph_replay_matches_eager():
     B = 4
     res = {}
     for mode in ("eager", "graph"):
-        model, _ = make_model(["vqa"], 42, precision="bf16")
+        model, _ = make_model(["vqa"], 42, precision=H16)
         model.train()
         opt = model.create_optimizer({"lr": 1e-3, "weight_decay": 1e-2, "adam_epsilon": 1e-8})
         opt.zero_grad()
@@ -886,7 +891,7 @@ def _dp_worker(rank, world, port, q, precision):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("precision,tol", [("fp32", 1e-4), ("bf16", 4e-2)])      # bf16: payload rounding 2^-9 + bf16 GEMM order noise
+@pytest.mark.parametrize("precision,tol", [("fp32", 1e-4), (H16, 4e-2)])      # bf16: payload rounding 2^-9 + bf16 GEMM order noise
 def test_data_parallel_two_ranks_equals_single_process_on_the_global_batch(precision, tol):
     """Two processes (gloo collectives on device tensors, both on the test box's single GPU) train on halves of a batch of 4 through the
     real engine hooks: weights broadcast from rank 0, per-range gradient all-reduce during the backward, finish() before AdamW.
@@ -937,14 +942,14 @@ def test_odd_batch_sizes_select_other_kernel_variants(B):
     dev = _dev()
     pixels, texts, target = _rand_batch(B, 100 + B, dev)
     out = {}
-    for precision in ("fp32", "bf16"):
+    for precision in ("fp32", H16):
         model, _ = make_model(["vqa"], 42, precision=precision)
         model.train()
         loss, (pooled, logits), _, _ = model.fused_forward_backward("vqa", pixels, texts, target)
         out[precision] = (float(loss), logits.detach().float().cpu(), {n: float(g.double().norm()) for n, g in grads_of(model).items()})
         assert bool(torch.isfinite(logits).all())
     l32, lg32, g32 = out["fp32"]
-    l16, lg16, g16 = out["bf16"]
+    l16, lg16, g16 = out[H16]
     assert abs(l16 - l32) <= 2e-3 * abs(l32)
     _close(lg16, lg32, BF16_TOL, f"logits bf16 vs fp32 at B={B}")
     top = max(g32.values())
@@ -962,7 +967,7 @@ def test_bf16_training_curve_tracks_fp32():
     B, steps = 8, 30
     pixels, texts, target = _rand_batch(B, 77, dev)
     curves = {}
-    for precision in ("fp32", "bf16"):
+    for precision in ("fp32", H16):
         model, _ = make_model(["vqa"], 42, precision=precision)
         model.train()
         opt = model.create_optimizer({"lr": 1e-4, "weight_decay": 1e-2, "adam_epsilon": 1e-8})
@@ -976,10 +981,10 @@ def test_bf16_training_curve_tracks_fp32():
             opt.zero_grad()
             losses.append(float(loss))
         curves[precision] = np.array(losses)
-    rel = np.abs(curves["bf16"] - curves["fp32"]) / curves["fp32"]
-    print(f"loss fp32 {curves['fp32'][0]:.3f} -> {curves['fp32'][-1]:.3f}, bf16 {curves['bf16'][0]:.3f} -> {curves['bf16'][-1]:.3f}, max rel diff {rel.max():.2e}")
+    rel = np.abs(curves[H16] - curves["fp32"]) / curves["fp32"]
+    print(f"loss fp32 {curves['fp32'][0]:.3f} -> {curves['fp32'][-1]:.3f}, {H16} {curves[H16][0]:.3f} -> {curves[H16][-1]:.3f}, max rel diff {rel.max():.2e}")
     assert rel.max() < 2e-3          # measured 1.1e-4
-    assert curves["fp32"][-1] < 0.8 * curves["fp32"][0] and curves["bf16"][-1] < 0.8 * curves["bf16"][0]
+    assert curves["fp32"][-1] < 0.8 * curves["fp32"][0] and curves[H16][-1] < 0.8 * curves[H16][0]
 
 
 # ------------------------------------------------------------------------------------------------ the upstream driver in miniature
@@ -1040,7 +1045,7 @@ def test_upstream_continual_learning_driver_in_miniature(tmp_path, cl_algorithm)
                                  ewc_fisher_sample_percentage=0.5, ewc_loss_weight=100.0, ordered_cl_tasks=tasks, encoder_name="vilt",
                                  output_dir=str(tmp_path))
     model = create_continual_learner_map["vilt"](model_name_or_path="random-init:5", ordered_cl_tasks=tasks, model_config=model_configs["vilt"],
-                                                 task_configs=cfgs, device=dev, precision="bf16")
+                                                 task_configs=cfgs, device=dev, precision=H16)
     replay = ExperienceReplayMemory() if cl_algorithm == "experience_replay" else None
     ewc = EWC(args) if cl_algorithm == "ewc" else None
     run_dir = tmp_path / "vilt-run"

@@ -30,6 +30,27 @@ def test_abi_library_exports_every_header_symbol():
     out = subprocess.run(["nm", "-D", "--defined-only", lib], capture_output=True, text=True).stdout
     exported = {l.split()[-1] for l in out.splitlines() if " T climb_" in l}
     assert exported == set(protos), exported ^ set(protos)
+    # the IEEE-half build of the same sources: the same ABI, and it says which 16-bit type it computes in
+    from climb_amd.build import LIB_F16
+    assert os.path.exists(LIB_F16)
+    out16 = subprocess.run(["nm", "-D", "--defined-only", LIB_F16], capture_output=True, text=True).stdout
+    assert {l.split()[-1] for l in out16.splitlines() if " T climb_" in l} == set(protos)
+    so16 = ctypes.CDLL(LIB_F16)
+    so16.climb_h16.restype = ctypes.c_char_p
+    assert so16.climb_h16() == b"fp16" and _lib.h16() == os.environ.get("CLIMB_AMD_H16", "bf16")
+
+
+def test_one_process_holds_one_16_bit_operand_type():
+    """engine precision "fp16" needs libclimb_hip_f16.so; a process that already loaded the bf16 build must be told so, not silently
+    compute in the wrong type."""
+    from climb_amd import _lib
+    _lib.load()
+    other = "fp16" if _lib.h16() == "bf16" else "bf16"
+    with pytest.raises(RuntimeError, match="one 16-bit operand type"):
+        _lib.select_h16(other)
+    _lib.select_h16(_lib.h16())          # asking for the loaded one is fine
+    with pytest.raises(ValueError):
+        _lib.select_h16("fp8")
 
 
 def test_engine_refuses_cpu():
