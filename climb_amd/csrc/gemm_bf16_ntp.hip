@@ -274,7 +274,8 @@ int climb_nt256_launch(int bn, const bf16_t* A, long lda, const bf16_t* B, long 
   if (((long)M * lda + K) * 2 >= (1L << 32) || ((long)N * ldb + K) * 2 >= (1L << 32)) return CLIMB_EUNSUPPORTED;
   // 16 residual float4s per lane next to 128 accumulators spill (measured: 80 B/lane of scratch): the residual epilogue only exists
   // for the 192-wide tile, which is also the width the layer's residual GEMMs (N = 768) tile best with
-  if (epi == EPI_RESID) bn = 192;
+  // (the x GELU' epilogue at 256 columns spills 64 - 72 B/lane as well -- its pre-activation operand next to 128 accumulators -- and goes the same way)
+  if (epi == EPI_RESID || epi == EPI_DGELU) bn = 192;
   int nwg = ((M + NTP_BM - 1) / NTP_BM) * ((N + bn - 1) / bn);
   if (g_nt256_grid > 0 && nwg > g_nt256_grid) nwg = g_nt256_grid;       // persistent: one workgroup per CU walks the tiles
 #define LNTP(TO, E, NI_) return ntp_launch_one<TO, E, NI_>(nwg, st, A, lda, B, ldb, (TO*)C, ldc, M, N, K, bias, aux, ldaux, aux_out, ldauxo)
@@ -285,8 +286,15 @@ int climb_nt256_launch(int bn, const bf16_t* A, long lda, const bf16_t* B, long 
     case EPI_DGELU: LNTP(TO, EPI_DGELU, NI_); \
     default: break;                           \
   }
-  if (c_dtype == CLIMB_DT_F32 && bn == 256) { LNTP_EPI(float, 4) }
-  if (c_dtype == CLIMB_DT_BF16 && bn == 256) { LNTP_EPI(bf16_t, 4) }
+#define LNTP_EPI256(TO)                     \
+  switch (epi) {                            \
+    case EPI_NONE: LNTP(TO, EPI_NONE, 4);   \
+    case EPI_GELU: LNTP(TO, EPI_GELU, 4);   \
+    default: break;                         \
+  }
+  if (c_dtype == CLIMB_DT_F32 && bn == 256) { LNTP_EPI256(float) }
+  if (c_dtype == CLIMB_DT_BF16 && bn == 256) { LNTP_EPI256(bf16_t) }
+#undef LNTP_EPI256
   if (c_dtype == CLIMB_DT_F32 && bn == 192) { LNTP_EPI(float, 3) if (epi == EPI_RESID) LNTP(float, EPI_RESID, 3); }
   if (c_dtype == CLIMB_DT_BF16 && bn == 192) { LNTP_EPI(bf16_t, 3) if (epi == EPI_RESID) LNTP(bf16_t, EPI_RESID, 3); }
 #undef LNTP_EPI
