@@ -97,6 +97,24 @@ def test_bucketed_allreduce_world2(compress):
         assert nbytes == (4 if compress == "none" else 2) * nelem, "every reported gradient element is reduced exactly once"
 
 
+def test_payload_type_follows_the_librarys_16_bit_type():
+    """On the IEEE-half build of the library the 16-bit cast kernels produce half, whose range unscaled gradients do not fit: the reducer
+    defaults to an fp32 payload there and refuses an explicit bf16 one; on the bf16 build the throughput mode defaults to bf16."""
+    from climb_amd.layout import FlatLayout, TASK_ARITH
+    from climb_amd.parallel import GradientAllReducer
+    lay = FlatLayout(["vqa"], TASK_ARITH)
+    for h16, precision, want in (("bf16", "bf16", "bf16"), ("fp16", "bf16", "none"), (None, "fp32", "none")):
+        eng = _FakeEngine(lay, 0)
+        eng.h16, eng.precision = h16, precision
+        r = GradientAllReducer()
+        r.attach(eng)
+        assert r.compress == want, (h16, r.compress)
+    eng = _FakeEngine(lay, 0)
+    eng.h16, eng.precision = "fp16", "bf16"
+    with pytest.raises(ValueError, match="IEEE half"):
+        GradientAllReducer(compress="bf16").attach(eng)
+
+
 def test_bucket_merging_single_process():
     """Small adjacent ranges (final norm + pooler) ride with the neighbouring layer instead of paying their own collective."""
     from climb_amd.parallel import GradientAllReducer
