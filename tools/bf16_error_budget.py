@@ -43,7 +43,8 @@ def run(precision):
     return keep
 
 
-ref, low = run("fp32"), run("bf16")
+H16 = os.environ.get("CLIMB_AMD_H16", "bf16")          # CLIMB_AMD_H16=fp16: the same table for the IEEE-half build
+ref, low = run("fp32"), run(H16)
 
 
 def err(a, b):
@@ -51,7 +52,7 @@ def err(a, b):
     return float(d.abs().max() / (b.double().abs().max() + 1e-30)), float(d.pow(2).mean().sqrt() / (b.double().pow(2).mean().sqrt() + 1e-30))
 
 
-print("bf16 mode vs fp32 mode, B = 64, valid token rows only.  columns: max|d|/max|ref|   rms(d)/rms(ref)")
+print(f"{H16} mode vs fp32 mode, B = 64, valid token rows only.  columns: max|d|/max|ref|   rms(d)/rms(ref)")
 print(f"{'layer':>5s} | " + " | ".join(f"{n:^19s}" for n in ("x (residual in)", "LN1(x)", "qkv", "ctx", "h1 = x+attn", "LN2(h1)", "u (pre-GELU)", "a = GELU(u)")))
 for i in range(12):
     cells = []
