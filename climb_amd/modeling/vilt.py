@@ -584,6 +584,10 @@ class ViltContinualLearner(ContinualLearner):
                 (self.training and self.task_configs[task_key]["model_type"] == "multi-choice"):
             return self.fused_forward_backward(task_key, images, texts, target, ewc, dropout_keep)
         eng = host.engine()
+        if eng.h16 == "fp16" and eng._grad_dirty:
+            # accumulating onto earlier (unscaled) sums needs the pre-scaling pass of begin_scaled_backward(), which a graph captured
+            # from clean gradients does not contain
+            return self.fused_forward_backward(task_key, images, texts, target, ewc, dropout_keep)
         img = images if isinstance(images, dict) else {"pixel_values": images}
         flags = tuple(sorted(n for n, p in host._params.items() if not p.requires_grad))
         key = (task_key, self.training, eng.active_adapter, hash(flags), tuple(target.shape), target.dtype,
@@ -619,6 +623,7 @@ class ViltContinualLearner(ContinualLearner):
         cs["target"].copy_(target, non_blocking=True)
         eng.refresh_shadow()
         cs["graph"].replay()
+        eng._grad_dirty = True
         eng.touched.extend(t for t in cs["touched"] if t not in eng.touched)
         loss, output, _, _ = cs["out"]
         ewc_task, ewc_loss = None, None
