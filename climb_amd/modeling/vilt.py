@@ -27,7 +27,8 @@ logger = logging.getLogger(__name__)
 
 
 def default_precision() -> str:
-    return os.environ.get("CLIMB_AMD_PRECISION", "bf16")
+    """CLIMB_AMD_PRECISION, else the 16-bit throughput mode of the library build the process is pinned to (CLIMB_AMD_H16, default bf16)."""
+    return os.environ.get("CLIMB_AMD_PRECISION") or ("fp16" if os.environ.get("CLIMB_AMD_H16") == "fp16" else "bf16")
 
 
 # ----------------------------------------------------------------------------------------------- parameter tree
