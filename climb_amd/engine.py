@@ -548,11 +548,15 @@ class ViltEngine:
 
     def _ready(self, lo, hi):
         for a, b in self._trainable_runs(lo, hi):
-            if self.loss_scale != 1.0:          # fp16 operands: this backward's contributions (and, pre-scaled, earlier sums) carry the loss scale
+            hook = self.grad_ready_hook
+            # fp16 operands: this backward's contributions (and, pre-scaled, earlier sums) carry the loss scale.  A data-parallel reducer
+            # with a half payload wants them that way (unscaled gradients do not fit half's range) and divides the scale out itself.
+            keep_scaled = hook is not None and getattr(getattr(hook, "__self__", None), "takes_scaled", False)
+            if self.loss_scale != 1.0 and not keep_scaled:
                 _lib.call("climb_scale_f32", self.grad[a:b], b - a, 1.0 / self.loss_scale, _stream())
             self.touched.append((a, b))
-            if self.grad_ready_hook is not None:
-                self.grad_ready_hook(a, b)
+            if hook is not None:
+                hook(a, b)
 
     def encoder_backward(self, dpooled: torch.Tensor, first_layer: int = 0, embeddings: bool = True):
         """Accumulates parameter gradients into the flat grad buffer.  `first_layer` / `embeddings` let frozen prefixes

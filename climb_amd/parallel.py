@@ -17,7 +17,7 @@ Why it is shaped like this on MI355X
     (identical on every rank, so it must NOT be summed) and the fused AdamW enqueued.  The fused optimizer calls `finish()` itself
     as a backstop, so paths that never reach the encoder backward (frozen encoder on the reference-style autograd path) are reduced too.
   * ReduceOp.AVG on RCCL; SUM followed by a scale on backends without AVG (gloo, used by the CPU tests).
-  * Payload: fp32 (bit-faithful averaging, the parity default) or bf16 (`compress="bf16"`, the default of the bf16 throughput
+  * Payload: fp32 (bit-faithful averaging, the parity default) or 16 bit (`compress="bf16"`, the default of the bf16 throughput
     mode; SURVEY.md §8(e) "prefer bf16 payload"): the range is cast into a persistent bf16 staging buffer laid out like the
     gradient buffer (`climb_cast_bf16`), reduced there, and cast back with the averaging scale folded in
     (`climb_uncast_bf16_scale`).  Halves the bytes every xGMI link carries (480 -> 240 MB per step) for two extra streaming
@@ -73,6 +73,7 @@ class GradientAllReducer:
                  compress: Optional[str] = None, overlap: Optional[bool] = None):
         self.pg = process_group
         self.compress = compress            # None = decide at attach() from the engine's precision
+        self.h16_payload, self.payload_dtype = False, torch.float32
         self._stage = None                  # bf16 payload staging, laid out like the gradient buffer
         self._pack = None                   # packed payload of non-contiguous small fragments (payload dtype)
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
@@ -98,15 +99,27 @@ class GradientAllReducer:
         self.eng = eng
         eng.grad_ready_hook = self.on_ready
         mode = os.environ.get("CLIMB_AMD_DP_COMPRESS") or self.compress
-        fp16_lib = getattr(eng, "h16", None) == "fp16"       # the library's 16-bit cast is IEEE half there: unscaled gradients do not fit its range
+        fp16_lib = getattr(eng, "h16", None) == "fp16"
+        # 16-bit payload: "bf16" on the bf16 build; on the IEEE-half build the cast kernels produce half, whose range only holds the gradients
+        # while they still carry the engine's loss scale -- "fp16": the engine hands ranges over BEFORE unscaling them (takes_scaled) and
+        # finish() divides the scale out together with the averaging factor
         if mode is None:
-            mode = "bf16" if (getattr(eng, "precision", "fp32") == "bf16" and not fp16_lib) else "none"
-        if mode not in ("none", "bf16"):
+            mode = ("fp16" if fp16_lib else "bf16") if getattr(eng, "precision", "fp32") == "bf16" else "none"
+        if mode not in ("none", "bf16", "fp16"):
             raise ValueError(f"unknown gradient compression {mode!r}")
-        if mode == "bf16" and fp16_lib:
-            raise ValueError("gradient compression 'bf16' is not available on the fp16-operand build of the library (its 16-bit cast is IEEE half)")
+        if (mode == "bf16" and fp16_lib) or (mode == "fp16" and not fp16_lib):
+            raise ValueError(f"gradient compression {mode!r} needs the {mode} build of the library (this one casts to "
+                             f"{'IEEE half' if fp16_lib else 'bf16'})")
+        self.h16_payload = mode in ("bf16", "fp16")
+        self.payload_dtype = (torch.float16 if mode == "fp16" else torch.bfloat16) if self.h16_payload else torch.float32
         self.compress = mode
         self._stage = self._pack = None
+
+    @property
+    def takes_scaled(self) -> bool:
+        """True when ranges must reach on_ready() still multiplied by the engine's loss scale (half payload, more than one rank: with one
+        rank nothing is cast and the engine unscales as usual)."""
+        return self.compress == "fp16" and self.world > 1
 
     def begin(self):
         self._works.clear()
@@ -126,9 +139,9 @@ class GradientAllReducer:
         if self.world == 1:
             return
         chunk = self.eng.grad[lo:hi]
-        if self.compress == "bf16":
+        if self.h16_payload:
             if self._stage is None:
-                self._stage = torch.empty(self.eng.grad.numel(), dtype=torch.bfloat16, device=self.eng.grad.device)
+                self._stage = torch.empty(self.eng.grad.numel(), dtype=self.payload_dtype, device=self.eng.grad.device)
             _cast_to_bf16(self._stage[lo:hi], chunk)
             chunk = self._stage[lo:hi]
         self._reduce(chunk, [(lo, hi)], None)
@@ -138,13 +151,13 @@ class GradientAllReducer:
         if self.world == 1:
             return
         n = sum(hi - lo for lo, hi in ranges)
-        dt = torch.bfloat16 if self.compress == "bf16" else torch.float32
+        dt = self.payload_dtype
         if self._pack is None or self._pack.numel() < n or self._pack.dtype != dt:
             self._pack = torch.empty(max(n, self.min_bucket), dtype=dt, device=self.eng.grad.device)
         buf = self._pack[:n]
         at = 0
         for lo, hi in ranges:
-            if dt == torch.bfloat16:
+            if self.h16_payload:
                 _cast_to_bf16(buf[at:at + hi - lo], self.eng.grad[lo:hi])
             else:
                 buf[at:at + hi - lo].copy_(self.eng.grad[lo:hi])
@@ -198,13 +211,15 @@ class GradientAllReducer:
         self._deferred.clear()
         self._flush_small()
         scale = 1.0 if (self._avg or self.world == 1) else 1.0 / self.world
+        if self.takes_scaled:            # the half payload was cast from gradients that still carried the loss scale
+            scale /= float(getattr(self.eng, "loss_scale", 1.0))
         for work, ranges, packed in self._works:
             work.wait()
             if packed is not None:
                 at = 0
                 for lo, hi in ranges:
                     src = packed[at:at + hi - lo]
-                    if packed.dtype == torch.bfloat16:
+                    if self.h16_payload:
                         _uncast_scaled(self.eng.grad[lo:hi], src, scale)
                     else:
                         self.eng.grad[lo:hi].copy_(src)
@@ -212,7 +227,7 @@ class GradientAllReducer:
                     at += hi - lo
             else:
                 lo, hi = ranges[0]
-                if self.compress == "bf16":
+                if self.h16_payload:
                     _uncast_scaled(self.eng.grad[lo:hi], self._stage[lo:hi], scale)
                 else:
                     _scale(self.eng.grad[lo:hi], scale)

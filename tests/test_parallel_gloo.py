@@ -51,6 +51,10 @@ def _worker(rank, world, port, q, compress="none"):
         layout = FlatLayout(["vqa", "nlvr2"], TASK_ARITH)
         eng = _FakeEngine(layout, rank)
         expect = sum(_FakeEngine(layout, r).grad for r in range(world)) / world
+        S = 1024.0
+        if compress == "fp16":          # the IEEE-half build: ranges reach the hook still multiplied by the engine's loss scale
+            eng.h16, eng.precision, eng.loss_scale = "fp16", "bf16", S
+            eng.grad.mul_(S)
         mine = eng.grad.clone()
         red = GradientAllReducer(None, compress=compress)
         red.attach(eng)
@@ -60,6 +64,9 @@ def _worker(rank, world, port, q, compress="none"):
         red.finish()
         if compress == "bf16":     # what the wire carried: each rank's gradient rounded to bf16, summed in bf16
             expect = (sum(_FakeEngine(layout, r).grad.bfloat16() for r in range(world))).float() / world
+        if compress == "fp16":     # scaled, rounded to half, summed in half; the reducer divides the scale out with the average
+            assert red.takes_scaled
+            expect = (sum((_FakeEngine(layout, r).grad * S).half() for r in range(world))).float() / (world * S)
         lo, hi = layout.head_range["nlvr2"]          # the head that got no gradient is not touched by any collective
         ok_untouched = torch.equal(eng.grad[lo:hi], mine[lo:hi])
         mask = torch.ones(layout.total, dtype=torch.bool)
@@ -78,7 +85,7 @@ def _worker(rank, world, port, q, compress="none"):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("compress", ["none", "bf16"])
+@pytest.mark.parametrize("compress", ["none", "bf16", "fp16"])
 def test_bucketed_allreduce_world2(compress):
     world = 2
     ctx = mp.get_context("spawn")
@@ -98,12 +105,13 @@ def test_bucketed_allreduce_world2(compress):
 
 
 def test_payload_type_follows_the_librarys_16_bit_type():
-    """On the IEEE-half build of the library the 16-bit cast kernels produce half, whose range unscaled gradients do not fit: the reducer
-    defaults to an fp32 payload there and refuses an explicit bf16 one; on the bf16 build the throughput mode defaults to bf16."""
+    """On the IEEE-half build of the library the 16-bit cast kernels produce half, whose range holds the gradients only while they carry the
+    loss scale: the reducer's 16-bit payload is "fp16" there (scaled ranges, scale divided out in finish()) and an explicit bf16 one is
+    refused; on the bf16 build the throughput mode defaults to bf16."""
     from climb_amd.layout import FlatLayout, TASK_ARITH
     from climb_amd.parallel import GradientAllReducer
     lay = FlatLayout(["vqa"], TASK_ARITH)
-    for h16, precision, want in (("bf16", "bf16", "bf16"), ("fp16", "bf16", "none"), (None, "fp32", "none")):
+    for h16, precision, want in (("bf16", "bf16", "bf16"), ("fp16", "bf16", "fp16"), (None, "fp32", "none")):
         eng = _FakeEngine(lay, 0)
         eng.h16, eng.precision = h16, precision
         r = GradientAllReducer()
@@ -113,6 +121,12 @@ def test_payload_type_follows_the_librarys_16_bit_type():
     eng.h16, eng.precision = "fp16", "bf16"
     with pytest.raises(ValueError, match="IEEE half"):
         GradientAllReducer(compress="bf16").attach(eng)
+    r = GradientAllReducer(compress="fp16")
+    r.attach(eng)
+    assert not r.takes_scaled          # one rank: nothing is cast, the engine unscales as usual
+    eng.h16 = "bf16"
+    with pytest.raises(ValueError, match="needs the fp16 build"):
+        GradientAllReducer(compress="fp16").attach(eng)
 
 
 def test_bucket_merging_single_process():
