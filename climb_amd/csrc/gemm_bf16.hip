@@ -339,7 +339,7 @@ extern "C" int climb_set_option(int key, int value) {
   if (key == 4) { g_nt_96 = value; return CLIMB_OK; }
   if (key == 5) { g_nt_192 = value; return CLIMB_OK; }
   if (key == 7 && value >= 0 && value <= 4) { g_nt_256 = value; return CLIMB_OK; }
-  if (key == 8) { climb_nt256_set_probe(value != 0); return CLIMB_OK; }
+  if (key == 8) { climb_nt256_set_probe(value); return CLIMB_OK; }            // 1: k-loop only; 256 * gm: supertile height override
   if (key == 10 && (value == 0 || value == 1)) { g_tn_p = value; return CLIMB_OK; }
   if (key == 11 && value >= 0) { climb_nt2_set_dephase(value); return CLIMB_OK; }
   if (key == 12 && value >= 0 && value <= 2) { climb_attn_set_qb(value); return CLIMB_OK; }

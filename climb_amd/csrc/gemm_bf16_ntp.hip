@@ -172,6 +172,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_ntp_kernel(const bf16_t* __rest
   const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wr = wid >> 1, wc = wid & 1, grp = wid >> 2, half = lane >> 5, l31 = lane & 31;
   const int nbm = (M + NTP_BM - 1) / NTP_BM, nbn = (N + BN - 1) / BN;
+  const int gm = (probe >> 8) ? (probe >> 8) : ((nbm % 8 == 0) ? nbm / 8 : 8);       // M-tiles per supertile (see nt_tile_id_gm); bits 8.. of `probe`: A/B override
+  probe &= 1;
   // fragment read offsets: row (wr*64 | wc*32) + l31 (+ 32 for the second m-block), k-chunk 2 ks + half, swizzled
   unsigned aoff[4], boff[4];
 #pragma unroll
@@ -183,7 +185,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_ntp_kernel(const bf16_t* __rest
   const int nk = K / GB_BK;                                  // >= 2 (launcher)
   for (int id = blockIdx.x; id < nbm * nbn; id += gridDim.x) {
     int tm, tn;
-    nt_tile_id<8>(id, nbm, nbn, tm, tn);
+    nt_tile_id_gm(gm, id, nbm, nbn, tm, tn);
     const int m0 = tm * NTP_BM, n0 = tn * BN;
     // LDS-DMA plan: a 1 KB piece = 8 rows x 8 chunks; wave w issues pieces 2w, 2w + 1 of A0 and of A1 and piece w of every B unit
     NtpStage<NI> sg;
@@ -249,7 +251,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_ntp_kernel(const bf16_t* __rest
 }
 
 static int g_nt256_probe = 0, g_nt256_grid = 256;
-void climb_nt256_set_probe(int v) { g_nt256_probe = v; }
+void climb_nt256_set_probe(int v) { g_nt256_probe = v; }      // bit 0: k-loop only; v >> 8: supertile height override (measurement)
 void climb_nt256_set_grid(int v) { g_nt256_grid = v; }
 
 template <typename TO, int EPI, int NI>
