@@ -850,7 +850,9 @@ def test_hipgraph_replay_matches_eager():
         del model, opt
     # the dW kernels accumulate split partial sums with fp32 atomics, so runs agree to rounding, not bitwise
     _close(res["graph"][0], res["eager"][0], 1e-3, "loss curve graph vs eager")   # atomics: run-to-run sum order
-    _close(res["graph"][2], res["eager"][2], 1e-3, "final logits")
+    # (final logits after 4 Adam steps at 10x the reference's learning rate: the +-lr steps of near-zero gradient entries described below
+    # reach the logits at the 1e-3 level -- measured 0.3 - 1.01e-3 over ten runs of the SAME mode pair)
+    _close(res["graph"][2], res["eager"][2], 3e-3, "final logits")
     # weights: Adam's g/sqrt(v) turns rounding-level gradient differences of near-zero entries into +-lr steps, so compare the
     # update as a whole (norm of the 4-step delta) rather than element-wise
     P0 = vo.init_params(["vqa"], 42)
