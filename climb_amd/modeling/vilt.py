@@ -291,6 +291,7 @@ class _EncoderFn(torch.autograd.Function):
                 dpooled = dpooled * eng.begin_scaled_backward(float(dpooled.abs().max()))
             eng._scaled_by_head = False
         host._engine.encoder_backward(dpooled, first_layer=first, embeddings=emb)
+        eng.finish_scaled_backward()
         host.after_backward()
         if host.ddp is not None:
             host.ddp.finish()
@@ -315,9 +316,10 @@ class _HeadFn(torch.autograd.Function):
             dlogits = dlogits * eng.begin_scaled_backward(float(dlogits.abs().max()))
             eng._scaled_by_head = True
         dx = eng.head_backward(ctx.hs, dlogits)
-        host.after_backward()
-        if eng.h16 == "fp16" and not ctx.needs_input_grad[0]:
+        if eng.h16 == "fp16" and not ctx.needs_input_grad[0]:       # nothing upstream of the head needs a gradient: the backward ends here
             eng._scaled_by_head = False
+            eng.finish_scaled_backward()
+        host.after_backward()
         return dx, None, None, None, None
 
 
@@ -567,6 +569,7 @@ class ViltContinualLearner(ContinualLearner):
         first, emb = host.frozen_prefix()
         if host.any_encoder_grad() is not None:
             eng.encoder_backward(dpool.reshape(B, -1).contiguous(), first_layer=first, embeddings=emb)
+        eng.finish_scaled_backward()
         if host.ddp is not None:
             host.ddp.finish()
         ewc_task, ewc_loss = None, None
