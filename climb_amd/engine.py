@@ -20,6 +20,7 @@ from . import _lib
 from .layout import ENC, FlatLayout, VILT_CFG, TASK_ARITH
 
 F32, BF16 = 0, 1
+_FUSED_ADAPTER = os.environ.get("CLIMB_AMD_FUSED_ADAPTER", "1") != "0"       # measurement knob: 0 = the two skinny GEMMs
 _UNSCALE_MODE = os.environ.get("CLIMB_AMD_FP16_UNSCALE", "end")      # measurement knob: "range" (per finished range), "end" (one pass), "none" (timing only)
 EPI_NONE, EPI_GELU, EPI_RESID, EPI_DGELU, EPI_TANH, EPI_SILU, EPI_DSILU, EPI_RESID2 = 0, 1, 2, 3, 4, 5, 6, 7
 
@@ -481,8 +482,7 @@ class ViltEngine:
             else:   # h1 = x + y + up(silu(down(y))),  y = Wo ctx + bo
                 a_ = f"{l}attention.output.adapters.{ad}."
                 self.linear_fwd(ws.ctx[i], l + "attention.output.dense.weight", l + "attention.output.dense.bias", ws.ya[i], M, H, H)
-                self.linear_fwd(ws.ya[i], a_ + "adapter_down.0.weight", a_ + "adapter_down.0.bias", ws.sa[i], M, r, H, EPI_SILU, None, ws.za[i])
-                self.linear_fwd(ws.sa[i], a_ + "adapter_up.weight", a_ + "adapter_up.bias", ws.h1[i], M, H, r, EPI_RESID2, x, None, ws.ya[i], out_f32=True)
+                self.adapter_fwd(a_, ws.ya[i], x, ws.za[i], ws.sa[i], ws.h1[i], M, H, r)
             _lib.call("climb_layernorm_fwd", ws.h1[i], H, self.p(l + "layernorm_after.weight"), self.p(l + "layernorm_after.bias"), cfg["ln_eps"],
                       ws.hn[i], H, adt, ws.mean2[i], ws.rstd2[i], M, H, st)
             self.linear_fwd(ws.hn[i], l + "intermediate.dense.weight", l + "intermediate.dense.bias", ws.a[i], M, Fd, H, EPI_GELU, None, ws.u[i])
@@ -491,9 +491,7 @@ class ViltEngine:
             else:
                 a_ = f"{l}output.adapters.{ad}."
                 self.linear_fwd(ws.a[i], l + "output.dense.weight", l + "output.dense.bias", ws.yo[i], M, H, Fd)
-                self.linear_fwd(ws.yo[i], a_ + "adapter_down.0.weight", a_ + "adapter_down.0.bias", ws.so[i], M, r, H, EPI_SILU, None, ws.zo[i])
-                self.linear_fwd(ws.so[i], a_ + "adapter_up.weight", a_ + "adapter_up.bias", ws.x[i + 1], M, H, r, EPI_RESID2, ws.h1[i], None, ws.yo[i],
-                                out_f32=True)
+                self.adapter_fwd(a_, ws.yo[i], ws.h1[i], ws.zo[i], ws.so[i], ws.x[i + 1], M, H, r)
         xL = ws.x[cfg["layers"]]
         # final LayerNorm only on the row the pooler consumes (token 0 = text [CLS]); `last_hidden_state` is never
         # used by CLiMB (REF/modeling/vilt.py:123-124), so the other S-1 rows are dead work we skip
@@ -655,6 +653,16 @@ class ViltEngine:
         if embeddings and first_layer == 0:
             self.embedding_backward(ws, sv)
             self._ready(*lay.embed_range)
+
+    def adapter_fwd(self, a_: str, y, resid, z_pre, s_act, out, M, H, r):
+        """out = resid + y + up(silu(down(y))), saving z = down(y) and s = silu(z) for the backward.  16-bit mode: one launch
+        (`climb_adapter_fwd_bf16`) where the shape allows, else -- and always in the fp32 mode -- the two skinny GEMMs."""
+        if self.precision != "fp32" and H % 128 == 0 and r % 16 == 0 and r <= 64 and _FUSED_ADAPTER:
+            _lib.call("climb_adapter_fwd_bf16", y, H, resid, H, self.sp(a_ + "adapter_down.0.weight"), self.p(a_ + "adapter_down.0.bias"),
+                      self.sp(a_ + "adapter_up.weight"), self.p(a_ + "adapter_up.bias"), z_pre, s_act, r, out, H, M, H, r, _stream())
+            return
+        self.linear_fwd(y, a_ + "adapter_down.0.weight", a_ + "adapter_down.0.bias", s_act, M, r, H, EPI_SILU, None, z_pre)
+        self.linear_fwd(s_act, a_ + "adapter_up.weight", a_ + "adapter_up.bias", out, M, H, r, EPI_RESID2, resid, None, y, out_f32=True)
 
     def adapter_backward(self, ws: Workspace, a_: str, s_act, z_pre, y_in, M, H, r):
         """Backward of out = resid + y + up(silu(down(y))) given d(out) in ws.dres (fp32) / ws.dres_c (operand dtype).

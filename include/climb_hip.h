@@ -126,6 +126,11 @@ int climb_transpose_bf16_batched(const void* src, void* dst, const long* table, 
  * epi 2: aux = fp32 residual [M,N]; epi 3: aux = bf16 pre-activation (multiplies by gelu'); epi 5/6: SiLU / silu' likewise;
  * epi 7: aux = fp32 residual, aux2 = bf16 residual (Houlsby adapter up-projection: out = up(s) + sublayer_out + x). */
 int climb_gemm_bf16_nt(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int c_dtype, int M, int N, int K, const float* bias, int epi, const void* aux, long ldaux, void* aux_out, long ldauxo, const void* aux2, long ldaux2, void* stream);
+/* Houlsby bottleneck adapter forward in one launch (16-bit mode; replaces the two skinny NT GEMMs of engine.py's adapter branch, which follow
+ * the GLAMOR fork's arithmetic as restated in climb_amd/cl_algorithms/adapters.py): z = y wd^T + bd; s = silu(z); out = resid + y + s wu^T + bu.
+ * y [M,H] 16-bit, resid / out [M,H] fp32, wd [r,H] / wu [H,r] 16-bit, bd [r] / bu [H] fp32, z / s [M,r] 16-bit (saved for the backward).
+ * H % 128 == 0, r % 16 == 0, r <= 64; CLIMB_EUNSUPPORTED otherwise (the caller keeps the two-GEMM path). */
+int climb_adapter_fwd_bf16(const void* y, long ldy, const float* resid, long ldr, const void* wd, const float* bd, const void* wu, const float* bu, void* z, void* s, long ldz, float* out, long ldo, int M, int H, int r, void* stream);
 /* weight gradient: C[N,K] (fp32) += A[M,N]^T B[M,K]; reduction over tokens via LDS transpose reads, split over M with fp32 atomics;
  * dbias (optional, fp32 [N]) += column sums of A = the bias gradient of the same layer (one extra MFMA against an all-ones operand) */
 int climb_gemm_bf16_tn(const void* A, long lda, const void* B, long ldb, float* C, long ldc, int M, int N, int K, float* dbias, void* stream);

@@ -514,6 +514,34 @@ def test_attention_bf16_edge_inputs(case):
         assert (c[1] == 0).all() and (dq[1] == 0).all()
 
 
+@pytest.mark.parametrize("M,r", [(12288, 48), (77, 48), (1000, 64), (96, 16)])
+def test_adapter_forward_fused(M, r):
+    """The one-launch Houlsby adapter forward against float64 of the same 16-bit-rounded operands: z, s = silu(z), out = resid + y + s Wu^T + bu."""
+    from climb_amd import _lib
+    dev = _dev()
+    H = 768
+    g = torch.Generator().manual_seed(M + r)
+    y = _bf(torch.randn(M, H, generator=g))
+    resid = torch.randn(M, H, generator=g)
+    wd, wu = _bf(torch.randn(r, H, generator=g) * 0.05), _bf(torch.randn(H, r, generator=g) * 0.05)
+    bd, bu = torch.randn(r, generator=g) * 0.1, torch.randn(H, generator=g) * 0.1
+    z = torch.full((M, r), float("nan"), device=dev, dtype=_h16())
+    s = torch.full((M, r), float("nan"), device=dev, dtype=_h16())
+    out = torch.full((M, H), float("nan"), device=dev)
+    _lib.call("climb_adapter_fwd_bf16", y.to(dev), H, resid.to(dev), H, wd.to(dev), bd.to(dev), wu.to(dev), bu.to(dev), z, s, r, out, H, M, H, r, _st())
+    zr = y.double() @ wd.double().t() + bd.double()
+    sr = zr * torch.sigmoid(zr)
+    s16 = sr.to(_h16()).double()                      # the up-projection consumes the 16-bit s
+    outr = resid.double() + y.double() + s16 @ wu.double().t() + bu.double()
+    assert _rel(z.float(), zr) < 6e-3 and _rel(s.float(), sr) < 6e-3
+    assert _rel(out, outr) < 1e-3        # s is rounded to 16 bits from the kernel's own fp32 z: one-ulp differences against the float64 s reach out at ~3e-4
+    if r == 48 and M == 12288:      # the two-GEMM path it replaces computes the same thing
+        z2 = torch.empty_like(z); s2 = torch.empty_like(s); out2 = torch.empty_like(out)
+        _lib.call("climb_gemm_bf16_nt", y.to(dev), H, wd.to(dev), H, s2, r, 1, M, r, H, bd.to(dev), 5, None, 0, z2, r, None, 0, _st())
+        _lib.call("climb_gemm_bf16_nt", s2, r, wu.to(dev), r, out2, H, 0, M, H, r, bu.to(dev), 7, resid.to(dev), H, None, 0, y.to(dev), H, _st())
+        assert _rel(out, out2.double().cpu()) < 1e-3 and _rel(s.float(), s2.float().double().cpu()) < 6e-3
+
+
 def test_weight_shadow_cast_and_batched_transpose():
     from climb_amd import _lib
     dev = _dev()
