@@ -50,6 +50,7 @@ __global__ __launch_bounds__(256) void adapter_fwd_kernel(const bf16_t* __restri
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[nb][q] = 0.f;
   const int kq = H / 4;
+#pragma unroll 4
   for (int k0 = wid * kq; k0 < (wid + 1) * kq; k0 += 16) {
     const bf16x8 a = ad_frag(*reinterpret_cast<const ad_u32x4*>(smem + l31 * ystride + (k0 + 8 * half) * 2));
 #pragma unroll
@@ -89,6 +90,7 @@ __global__ __launch_bounds__(256) void adapter_fwd_kernel(const bf16_t* __restri
 #pragma unroll
   for (int ks = 0; ks < AD_MAXR / 16; ++ks)
     if (ks < ksteps) sf[ks] = ad_frag(*reinterpret_cast<const ad_u32x4*>(reinterpret_cast<const unsigned char*>(sbuf) + l31 * 128 + (16 * ks + 8 * half) * 2));
+#pragma unroll 1
   for (int nb = 0; nb < kq / 32; ++nb) {
     const int n = wid * kq + nb * 32 + l31;
     f32x16 o;
