@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void adapter_fwd_kernel(const bf16_t* __restri
     if (n < r) {
       v = zred[(0 * AD_ROWS + m) * 64 + n] + zred[(1 * AD_ROWS + m) * 64 + n] + zred[(2 * AD_ROWS + m) * 64 + n] + zred[(3 * AD_ROWS + m) * 64 + n] + bd[n];
       sv = silu_f(v);                                              // of the fp32 value, like the GEMM's EPI_SILU epilogue
-      if (m0 + m < M) {
+      if (m0 + m < M && blockIdx.y == 0) {
         z[(long)(m0 + m) * ldz + n] = f32_to_bf16(v);
         s[(long)(m0 + m) * ldz + n] = f32_to_bf16(sv);
       }
@@ -84,15 +84,17 @@ __global__ __launch_bounds__(256) void adapter_fwd_kernel(const bf16_t* __restri
     sbuf[m * 64 + n] = f32_to_bf16(sv);
   }
   __syncthreads();
-  // ---- up-projection + both residuals: wave w owns columns [w H/4, (w+1) H/4), 32 at a time
+  // ---- up-projection + both residuals: workgroup (., c) of gridDim.y column slices, wave w of it: columns [(4 c + w) H / (4 gridDim.y), ...), 32 at a time.
+  // (The down-projection above is repeated by every column slice; see the launcher for why there is one.)
   const int ksteps = r / 16;
   bf16x8 sf[AD_MAXR / 16];
 #pragma unroll
   for (int ks = 0; ks < AD_MAXR / 16; ++ks)
     if (ks < ksteps) sf[ks] = ad_frag(*reinterpret_cast<const ad_u32x4*>(reinterpret_cast<const unsigned char*>(sbuf) + l31 * 128 + (16 * ks + 8 * half) * 2));
+  const int cw = H / (4 * gridDim.y);                              // columns per wave
 #pragma unroll 1
-  for (int nb = 0; nb < kq / 32; ++nb) {
-    const int n = wid * kq + nb * 32 + l31;
+  for (int nb = 0; nb < cw / 32; ++nb) {
+    const int n = (blockIdx.y * 4 + wid) * cw + nb * 32 + l31;
     f32x16 o;
 #pragma unroll
     for (int q = 0; q < 16; ++q) o[q] = 0.f;
@@ -131,7 +133,8 @@ extern "C" int climb_adapter_fwd_bf16(const void* y, long ldy, const float* resi
     if (e != hipSuccess) return (int)e;
     lds_set = lds;
   }
-  hipLaunchKernelGGL(adapter_fwd_kernel, dim3((M + AD_ROWS - 1) / AD_ROWS), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)y, ldy, resid, ldr,
+  const int slices = 1;      // column slices per row block (2 measured 42 us against 32: the repeated y tile costs more than the extra workgroups bring)
+  hipLaunchKernelGGL(adapter_fwd_kernel, dim3((M + AD_ROWS - 1) / AD_ROWS, slices), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)y, ldy, resid, ldr,
                      (const bf16_t*)wd, bd, (const bf16_t*)wu, bu, (bf16_t*)z, (bf16_t*)s, ldz, out, ldo, M, H, r);
   LAUNCH_CHECK();
   return CLIMB_OK;
