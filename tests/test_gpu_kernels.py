@@ -392,11 +392,14 @@ def test_gemm_bf16_nt_256_race_screen_full_size(N, K, force):
         _lib.call("climb_set_option", 7, force)
         out = torch.empty(M, N, device=dev)
         for it in range(6):
+            # the tile -> (XCD, supertile) map must stay a bijection for every supertile height: automatic (one XCD's share: 6), the old 8, an odd one
+            _lib.call("climb_set_option", 8, 256 * (0, 8, 5)[it % 3])
             out.fill_(float("nan"))
             _lib.call("climb_gemm_bf16_nt", Ad, K, Wd, K, out, N, 0, M, N, K, None, 0, None, 0, None, 0, None, 0, _st())
             bad = int((out != ref).sum())
             assert bad == 0, f"iteration {it}: {bad} elements differ from the two-barrier kernel"
     finally:
+        _lib.call("climb_set_option", 8, 0)
         _lib.call("climb_set_option", 7, 1)
         _lib.call("climb_set_option", 5, 1)
 
