@@ -4,17 +4,25 @@ The reference keeps theta* and the Fisher diagonal on the CPU and re-uploads 0.8
 (ewc.py:84-85), then runs 206 x (sub, pow, mul, sum) tiny kernels.  Here both live in HBM as flat fp32 vectors laid out
 exactly like the encoder range of the parameter buffer, so the penalty and its gradient are ONE streaming kernel
 (20 B per encoder parameter), and the Fisher estimate never leaves the device.  `fisher_dict` / `param_dict` keep the
-reference's shape (task -> {encoder-relative name `vilt.*` -> tensor}) as views of those vectors."""
+reference's shape (task -> {encoder-relative name `vilt.*` -> tensor}) as views of those vectors.
+
+Data parallel: theta* and F are replicated per rank.  The Fisher estimate squares gradients that ACCUMULATE across
+batches in order (:56-64), so its value depends on the batch sequence and sharding it would change the result: every rank runs the pass on
+the WHOLE global batches (sharded loader switched to `replicated()`, gradient reducer suspended) -- the single-process arithmetic -- and
+rank 0's F is then broadcast so that replicas stay bit-identical even where a kernel's summation order is not (split-K atomics).  The task
+draw of `compute_ewc_loss` uses Python's `random`, seeded identically on every rank; the penalty gradient is added after the all-reduce."""
 from __future__ import annotations
 
 import argparse
+import contextlib
 import logging
 import random
 from typing import Dict
 
 import torch
 
-from .. import _lib
+from .. import _lib, parallel
+from ..data.sharding import replicated
 
 logger = logging.getLogger(__name__)
 
@@ -86,14 +94,20 @@ class EWC:
         optimizer = model.create_optimizer(task_trainer.hparams)
         optimizer.zero_grad()
         num_samples_completed = 0
-        for step, batch in enumerate(dataloader):
-            task_trainer.train_step(model, batch)
-            eng = host.engine()
-            eng.fisher_accumulate(fisher)
-            num_samples_completed += _num_examples(batch["raw_texts"])
-            if num_samples_completed >= fisher_sample_size:
-                break
+        world = parallel.rank_world()[1]
+        reducer = host.ddp if world > 1 else None
+        with replicated(dataloader), (reducer.suspended() if reducer is not None else contextlib.nullcontext()):
+            for step, batch in enumerate(dataloader):
+                task_trainer.train_step(model, batch)
+                eng = host.engine()
+                eng.fisher_accumulate(fisher)
+                num_samples_completed += _num_examples(batch["raw_texts"])
+                if num_samples_completed >= fisher_sample_size:
+                    break
         _lib.call("climb_scale", fisher, n, 1.0 / max(1, num_samples_completed), torch.cuda.current_stream().cuda_stream)
+        if world > 1:
+            import torch.distributed as dist
+            dist.broadcast(fisher, src=0)
         self.fisher_flat[task_key] = fisher
         self.fisher_dict[task_key] = _views(fisher, eng)
         self.param_dict[task_key] = _views(self.param_flat[task_key], eng)

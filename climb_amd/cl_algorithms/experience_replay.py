@@ -7,6 +7,10 @@ What is preserved, because the trainers, the upstream driver and the parity fixt
     :93-98) of those indices, re-collates them, builds a FRESH optimizer (zero moments, the task's base lr, no scheduler, :61) and
     runs one ordinary `train_step` on the replayed task's own head and loss (:63).
 The reference does NOT mix replay samples into the current minibatch; neither does this.
+
+Data parallel: `random` is seeded identically on every rank, so the memory indices, `sample_replay_task()` and the
+replay batch drawn here agree across ranks; each rank then loads only its strided share of that (global) replay batch and weights its
+d(loss) like a training shard (climb_amd/data/sharding.py); the step's gradients are all-reduced like any other step's.
 """
 from __future__ import annotations
 
@@ -16,6 +20,7 @@ from typing import Dict, List
 
 import torch
 
+from ..data.sharding import dp_rank_world, shard_of
 from ..utils import wandb_logger
 
 logger = logging.getLogger(__name__)
@@ -47,8 +52,13 @@ class TaskMemoryBuffer:
         return len(self.memory_idxs)
 
     def sample_replay_batch(self) -> Dict:
-        picked = random.sample(self.memory_idxs, self.batch_size)
-        return self.batch_collate_fn([self.dataset[idx] for idx in picked])
+        picked = random.sample(self.memory_idxs, self.batch_size)          # the same draw on every rank
+        rank, world = dp_rank_world()
+        mine, weight = shard_of(picked, rank, world)
+        batch = self.batch_collate_fn([self.dataset[idx] for idx in mine])
+        if world > 1:
+            batch["dp_weight"] = weight
+        return batch
 
 
 class ExperienceReplayMemory:

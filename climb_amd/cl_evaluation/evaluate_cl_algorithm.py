@@ -18,6 +18,13 @@ from ..configs.task_configs import task_configs
 logger = logging.getLogger(__name__)
 
 
+def _sync_ranks():
+    """Data-parallel runs: every rank writes results.json with identical content (the scores are all-reduced); wait until all of them have,
+    before anyone reads it back.  No-op in a single process."""
+    from ..parallel import barrier
+    barrier()
+
+
 def _relative_percent(gain: float, span: float) -> float:
     return 100.0 * gain / span
 
@@ -26,6 +33,7 @@ def upstream_knowledge_transfer_eval(args, results_file: str) -> Dict:
     """REF/cl_evaluation/evaluate_cl_algorithm.py:32-72.  Relative gain of the CL score of every task over direct fine-tuning
     of the pretrained encoder on that task alone, in percent of the single-task margin over the random baseline.
     Reads `<output_dir>/<encoder>-singletask_ft-task0_<task>/results.json` for the single-task scores."""
+    _sync_ranks()
     with open(results_file) as f:
         cl_results = json.load(f)
     assert len(cl_results) == len(args.ordered_cl_tasks)
@@ -51,6 +59,7 @@ def catastrophic_forgetting_eval(args, results_file: str, model, task_trainers, 
     earlier task j < i (`trainer.eval_forgetting(model, <ckpt>/model)`) and report the score drop in percent of the margin
     the task had over its random baseline when it was learned."""
     model_config = model_configs[args.encoder_name]
+    _sync_ranks()
     with open(results_file) as f:
         cl_results = json.load(f)
     assert len(cl_results) == len(args.ordered_cl_tasks)

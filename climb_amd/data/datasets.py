@@ -195,6 +195,13 @@ def _tokenize(tokenizer, text: str) -> List[int]:
 
 
 def _loader(dataset, args, batch_size: int, shuffle: bool, collate) -> DataLoader:
+    """One process: the reference's plain DataLoader.  Under torch.distributed (one process per GPU): `batch_size`
+    is the GLOBAL batch and the loader yields this rank's strided share of it (climb_amd/data/sharding.py) -- training shares are padded so
+    that every rank runs every step, evaluation shares are exact."""
+    from .sharding import ShardedDataLoader, dp_rank_world
+    rank, world = dp_rank_world()
+    if world > 1:
+        return ShardedDataLoader(dataset, batch_size, shuffle, collate, num_workers=getattr(args, "num_workers", 0), rank=rank, world=world, pad=shuffle)
     return DataLoader(dataset, num_workers=getattr(args, "num_workers", 0), batch_size=batch_size, shuffle=shuffle, collate_fn=collate)
 
 

@@ -230,13 +230,15 @@ class ViltEngine:
                 return True
         return False
 
-    def workspace(self, B: int, T: int, gh: int = None, gw: int = None, nseq: int = None) -> Workspace:
+    def workspace(self, B: int, T: int, gh: int = None, gw: int = None, nseq: int = None, tag: str = None) -> Workspace:
         g0 = self.cfg["image"] // self.cfg["patch"]
-        key = (B, T, gh or g0, gw or g0, nseq)
+        key = (B, T, gh or g0, gw or g0, nseq, tag)
         ws = self._ws.get(key)
         if ws is None:
             if len(self._ws) >= 3:      # bound HBM use when batch shapes vary (last partial batch, replay batches, canvases)
-                self._ws.pop(next(iter(self._ws)))
+                pending = self.saved["ws"] if self.saved is not None else None
+                victim = next(k for k, w in self._ws.items() if w is not pending)      # never the one a pending backward will read
+                self._ws.pop(victim)
             ws = self._ws[key] = Workspace(self, B, T, gh, gw, nseq)
         return ws
 
@@ -444,6 +446,10 @@ class ViltEngine:
             if nseq is None or T + 1 + nseq > 288:
                 raise NotImplementedError(f"sequence of {T + 1 + (nseq or gh * gw)} tokens exceeds the 288 this build sizes its attention tiles for")
         ws = self.workspace(B, T, gh, gw, nseq)
+        if not save and self.saved is not None and self.saved["ws"] is ws:
+            # a grad-enabled forward of this shape is still waiting for its backward (reference-style autograd path: an evaluation or a
+            # teacher pass between `model(...)` and `loss.backward()`): its saved activations live in `ws`, so this pass gets its own
+            ws = self.workspace(B, T, gh, gw, nseq, tag="nograd")
         st = _stream()
         adt = self.adt
         self.refresh_shadow()
@@ -506,8 +512,11 @@ class ViltEngine:
         self._unused = {e + "text_embeddings.word_embeddings.weight"} if inputs_embeds is not None else set()
         if save:
             self._generation = getattr(self, "_generation", 0) + 1
+            # ViLT-BERT: `inputs_embeds` is BertParams' reusable output buffer, which the next BERT forward of this shape overwrites -- the
+            # embedding backward reads it, so the saved copy is its own tensor (7.9 MB at bs = 64)
             self.saved = dict(ws=ws, input_ids=input_ids, token_type_ids=token_type_ids, adapter=ad, var=var, generation=self._generation,
-                              inputs_embeds=inputs_embeds)
+                              inputs_embeds=inputs_embeds.clone() if inputs_embeds is not None else None)
+            self.last_ws = ws
         return ws.pooled
 
     def linear_fwd_f32out(self, X, wname, bname, Y, M, N, K):
@@ -653,6 +662,7 @@ class ViltEngine:
         if embeddings and first_layer == 0:
             self.embedding_backward(ws, sv)
             self._ready(*lay.embed_range)
+        self.saved = None          # the activations are consumed: a later no-grad forward may use this workspace again
 
     def adapter_fwd(self, a_: str, y, resid, z_pre, s_act, out, M, H, r):
         """out = resid + y + up(silu(down(y))), saving z = down(y) and s = silu(z) for the backward.  16-bit mode: one launch

@@ -132,7 +132,14 @@ class _EngineHost:
         self.ddp = None                 # climb_amd.parallel.GradientAllReducer, when data-parallel
 
     def __deepcopy__(self, memo):
-        return _EngineHost(copy.deepcopy(self.encoder, memo), copy.deepcopy(self.heads, memo), self.tasks, self.task_configs, self.precision)
+        new = _EngineHost(copy.deepcopy(self.encoder, memo), copy.deepcopy(self.heads, memo), self.tasks, self.task_configs, self.precision)
+        # ViLT-BERT's encoder-level create_optimizer() forwards to the owning learner: the copy must point at the COPIED learner (already in
+        # `memo` when the host is reached through it).  The data-parallel reducer is deliberately not carried: a snapshot (best_model) is saved,
+        # not trained, and the reducer's engine hook belongs to the live model.
+        learner = getattr(self, "learner", None)
+        if learner is not None:
+            new.learner = memo.get(id(learner), learner)
+        return new
 
     def named(self) -> Dict[str, nn.Parameter]:
         out = {ENC + n: p for n, p in self.encoder.vilt.named_parameters()}
@@ -542,7 +549,9 @@ class ViltContinualLearner(ContinualLearner):
 
     # --- fused training step: forward + loss + backward (+ EWC term) with no autograd graph.  This is what
     # climb_amd.train.*Trainer.train_step runs; semantics = REF/train/visionlanguage_tasks/train_vqa.py:135-166.
-    def fused_forward_backward(self, task_key: str, images, texts, target: torch.Tensor, ewc=None, dropout_keep=None):
+    def fused_forward_backward(self, task_key: str, images, texts, target: torch.Tensor, ewc=None, dropout_keep=None, grad_weight: float = 1.0):
+        """`grad_weight` multiplies d(loss) (not the returned loss): a data-parallel rank's share of an uneven global batch,
+        climb_amd/data/sharding.py."""
         host = self._host
         eng = host.engine()
         host.before_backward()
@@ -563,12 +572,13 @@ class ViltContinualLearner(ContinualLearner):
         if task_key == "vqa":
             target = target.float()
         # fp16 operands: d(logits) is produced already multiplied by the loss scale (every |d logit| of both losses is <= 1 / rows)
-        gs = eng.begin_scaled_backward(1.0 / max(1, logits.shape[0]))
+        gs = eng.begin_scaled_backward(1.0 / max(1, logits.shape[0])) * float(grad_weight)
         loss, dlogits = eng.loss_and_grad(task_key, logits, target, gscale=gs, hs=hs)
         dpool = eng.head_backward(hs, dlogits)
         first, emb = host.frozen_prefix()
         if host.any_encoder_grad() is not None:
             eng.encoder_backward(dpool.reshape(B, -1).contiguous(), first_layer=first, embeddings=emb)
+        eng.saved = None           # (also when the encoder is frozen and its backward never ran)
         eng.finish_scaled_backward()
         if host.ddp is not None:
             host.ddp.finish()
@@ -582,8 +592,10 @@ class ViltContinualLearner(ContinualLearner):
     # --- the same step captured once into a hipGraph and replayed: the ~330 kernel launches of a step become one graph launch
     # (HIP streams and graphs instead of a tracing compiler).  Inputs are copied into static buffers; the returned tensors are
     # the graph's static outputs (overwritten by the next replay).  Falls back to the eager path under data parallelism / EWC.
-    def graphed_forward_backward(self, task_key: str, images, texts, target: torch.Tensor, ewc=None, dropout_keep=None):
+    def graphed_forward_backward(self, task_key: str, images, texts, target: torch.Tensor, ewc=None, dropout_keep=None, grad_weight: float = 1.0):
         host = self._host
+        if grad_weight != 1.0:
+            return self.fused_forward_backward(task_key, images, texts, target, ewc, dropout_keep, grad_weight)
         if host.ddp is not None or dropout_keep is not None or not isinstance(texts, dict) or hasattr(self._enc, "bert") or \
                 (self.training and self.task_configs[task_key]["model_type"] == "multi-choice"):
             return self.fused_forward_backward(task_key, images, texts, target, ewc, dropout_keep)
@@ -618,7 +630,7 @@ class ViltContinualLearner(ContinualLearner):
             # the captured kernels hold raw pointers into this Workspace: the cache entry keeps it alive past the engine's
             # own three-shape eviction
             cs = graphs[key] = dict(graph=g, texts=st_texts, img=st_img, target=st_target, out=out, touched=touched, engine=eng,
-                                    ws=eng.saved["ws"])
+                                    ws=eng.last_ws)
         host.before_backward()
         for k, v in texts.items():
             cs["texts"][k].copy_(v, non_blocking=True)

@@ -30,6 +30,7 @@ Why it is shaped like this on MI355X
 """
 from __future__ import annotations
 
+import contextlib
 import os
 from typing import List, Optional, Tuple
 
@@ -75,7 +76,9 @@ class GradientAllReducer:
         self.compress = compress            # None = decide at attach() from the engine's precision
         self.h16_payload, self.payload_dtype = False, torch.float32
         self._stage = None                  # bf16 payload staging, laid out like the gradient buffer
-        self._pack = None                   # packed payload of non-contiguous small fragments (payload dtype)
+        self._packs: List[torch.Tensor] = []   # packed payloads of non-contiguous small fragments (payload dtype), recycled every step
+        self._packs_used = 0
+        self.enabled = True                 # False inside suspended(): ranges are not reduced (the replicated Fisher pass)
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.min_bucket = min_bucket_elems
         self.eng = None
@@ -113,7 +116,8 @@ class GradientAllReducer:
         self.h16_payload = mode in ("bf16", "fp16")
         self.payload_dtype = (torch.float16 if mode == "fp16" else torch.bfloat16) if self.h16_payload else torch.float32
         self.compress = mode
-        self._stage = self._pack = None
+        self._stage = None
+        self._packs, self._packs_used = [], 0
 
     @property
     def takes_scaled(self) -> bool:
@@ -125,6 +129,17 @@ class GradientAllReducer:
         self._works.clear()
         self._small.clear()
         self._deferred.clear()
+        self._packs_used = 0            # finish() of the previous step waited for every collective: its pack buffers are free again
+
+    @contextlib.contextmanager
+    def suspended(self):
+        """Inside: backward passes reduce nothing.  For passes every rank runs on IDENTICAL data (EWC's Fisher estimate: REF/cl_algorithms/
+        ewc.py:56-68 accumulates gradients across batches in order and cannot be sharded without changing the result)."""
+        prev, self.enabled = self.enabled, False
+        try:
+            yield self
+        finally:
+            self.enabled = prev
 
     # ------------------------------------------------------------------ collectives
     def _reduce(self, payload: torch.Tensor, ranges, packed):
@@ -152,9 +167,14 @@ class GradientAllReducer:
             return
         n = sum(hi - lo for lo, hi in ranges)
         dt = self.payload_dtype
-        if self._pack is None or self._pack.numel() < n or self._pack.dtype != dt:
-            self._pack = torch.empty(max(n, self.min_bucket), dtype=dt, device=self.eng.grad.device)
-        buf = self._pack[:n]
+        k = self._packs_used            # the k-th packed collective of a step reuses the k-th buffer of the pool (no allocation in the step)
+        if k == len(self._packs):
+            self._packs.append(None)
+        pk = self._packs[k]
+        if pk is None or pk.numel() < n or pk.dtype != dt:
+            pk = self._packs[k] = torch.empty(max(n, self.min_bucket), dtype=dt, device=self.eng.grad.device)
+        self._packs_used += 1
+        buf = pk[:n]
         at = 0
         for lo, hi in ranges:
             if self.h16_payload:
@@ -162,8 +182,7 @@ class GradientAllReducer:
             else:
                 buf[at:at + hi - lo].copy_(self.eng.grad[lo:hi])
             at += hi - lo
-        self._reduce(buf, list(ranges), buf)
-        self._pack = None            # in flight until finish(); the next packed bucket of this step gets its own buffer
+        self._reduce(buf, list(ranges), buf)          # in flight until finish(); the next packed bucket of this step takes the next buffer
 
     def _flush_small(self):
         if not self._small:
@@ -183,7 +202,7 @@ class GradientAllReducer:
     def on_ready(self, lo: int, hi: int):
         """Ranges arrive in backward order (head, final norm + pooler, layer 11 ... layer 0, embeddings; only trainable sub-ranges).
         A range worth a collective goes at once, in place; smaller ones wait for neighbours and go together."""
-        if hi <= lo:
+        if hi <= lo or not self.enabled:
             return
         if not self.overlap:
             self._deferred.append((lo, hi))
@@ -206,6 +225,8 @@ class GradientAllReducer:
 
     def finish(self):
         """Block the compute stream on every outstanding collective (no host sync on RCCL) and put the averaged gradients back."""
+        if not self.enabled:
+            return
         for lo, hi in self._deferred:
             self._dispatch(lo, hi)
         self._deferred.clear()
@@ -232,6 +253,7 @@ class GradientAllReducer:
                 else:
                     _scale(self.eng.grad[lo:hi], scale)
         self._works.clear()
+        self._packs_used = 0            # every collective was waited for: the pack buffers are free (also on paths that never call begin())
 
     def replicas_in_sync(self) -> bool:
         """Cross-rank parameter equality check (the race detector this path gets: every rank must hold bit-identical
@@ -245,3 +267,81 @@ class GradientAllReducer:
         dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.pg)
         dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.pg)
         return bool(torch.equal(lo, hi))
+
+
+# ---------------------------------------------------------------------------------------------------------------- job-level helpers
+def rank_world(group=None) -> Tuple[int, int]:
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(group), dist.get_world_size(group)
+    return 0, 1
+
+
+def barrier(group=None):
+    """No-op outside a data-parallel job."""
+    if rank_world(group)[1] > 1:
+        dist.barrier(group=group)
+
+
+def ensure_reducer(model) -> Optional[GradientAllReducer]:
+    """What a trainer's train() does first under N > 1 ranks: attach the gradient all-reducer to the model's engine (once; later tasks and
+    re-bound engines keep it) after broadcasting rank 0's parameters.  Returns None in a single-process run."""
+    if rank_world()[1] == 1:
+        return None
+    host = model._host
+    if host.ddp is None:
+        GradientAllReducer(model)
+    return host.ddp
+
+
+def init_data_parallel(backend: Optional[str] = None):
+    """One process per GPU under torchrun (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment): bind this process to its GPU
+    and join the job.  Returns (rank, world, device).  RCCL ("nccl") on GPUs; gloo is for the CPU tests."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local % torch.cuda.device_count())
+        device = torch.device("cuda", local % torch.cuda.device_count())
+    else:
+        device = torch.device("cpu")
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        kw = {"device_id": device} if (device.type == "cuda" and (backend or "nccl") == "nccl") else {}
+        dist.init_process_group(backend or ("nccl" if device.type == "cuda" else "gloo"), rank=rank, world_size=world, **kw)
+    return rank, world, device
+
+
+_real_torch_save = None
+_real_makedirs = None
+
+
+def rank0_only_io():
+    """Makes the reference driver's file IO safe for N processes running the same code.  It saves checkpoints with `torch.save` from its only
+    process (REF/train/train_upstream_continual_learning.py:261-267): under N ranks the replicas are bit-identical, so one copy is enough --
+    on ranks > 0 `torch.save` of a path becomes a no-op, and every rank leaves the call through a barrier so that a file exists for all
+    ranks once any of them has moved on.  It creates directories with `if not isdir: makedirs` (:118-119, :261-262), which two processes
+    race through: `os.makedirs` tolerates an existing directory.  (results.json / eval_results.json are written by every rank with
+    identical content; their readers in this package barrier first.)  Idempotent; `restore_io()` undoes it."""
+    global _real_torch_save, _real_makedirs
+    rank, world = rank_world()
+    if world == 1 or _real_torch_save is not None:
+        return
+    _real_torch_save, _real_makedirs = torch.save, os.makedirs
+
+    def makedirs(name, mode=0o777, exist_ok=False):
+        return _real_makedirs(name, mode, exist_ok=True)
+    os.makedirs = makedirs
+
+    def save(obj, f, *a, **kw):
+        if rank == 0 or not isinstance(f, (str, os.PathLike)):
+            _real_torch_save(obj, f, *a, **kw)
+        if isinstance(f, (str, os.PathLike)):
+            dist.barrier()
+    torch.save = save
+
+
+def restore_io():
+    global _real_torch_save, _real_makedirs
+    if _real_torch_save is not None:
+        torch.save, os.makedirs = _real_torch_save, _real_makedirs
+        _real_torch_save = _real_makedirs = None

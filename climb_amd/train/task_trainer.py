@@ -7,6 +7,12 @@ Semantics follow REF/train/visionlanguage_tasks/train_vqa.py (:121-282) and its 
 but for names, dataloaders and the loss -- verified by diff).  `train_step` runs the fused HIP step
 (forward + loss + backward [+ EWC term], no autograd graph); the optimizer is the fused AdamW.
 
+Data parallel (the reference is single-process): when torch.distributed is initialised the loaders this class builds
+are rank-sharded (`--batch_size` stays the GLOBAL batch: climb_amd/data/sharding.py), `train()` attaches the gradient all-reducer to the
+model (parameters broadcast from rank 0, per-range all-reduce under the backward: climb_amd/parallel.py), `train_step` weights the shard's
+d(loss) so that the averaged gradient IS the global-batch gradient, and `eval()` all-reduces the score sum.  Python's `random` (EWC's task
+draw, the replay memory) is seeded identically on every rank and data order uses torch's generator, so every rank makes the same draws.
+
 Construction matches the reference's call `Trainer(args, task_configs, model_config, device)`
 (REF/train/train_upstream_continual_learning.py:240, :254, :314): the train / validation loaders are built from
 `args.climb_data_dir` + the task's `data_dir` with climb_amd.data.datasets (the reference's file formats).  Tests and pipelines that
@@ -21,6 +27,7 @@ from typing import Dict, Optional, Tuple
 import torch
 from torch import nn
 
+from .. import parallel
 from ..modeling.vilt import convert_batch_to_vilt_input_dict
 from ..utils import wandb_logger
 
@@ -99,7 +106,8 @@ class VLTaskTrainer(TaskTrainer):
     def train_step(self, model, batch: Dict, optimizer=None, scheduler=None, ewc=None):
         inputs = self.batch2inputs_converter(batch)
         target = batch[self.target_field]
-        loss, output, ewc_task, ewc_loss = model.fused_forward_backward(self.task_key, inputs["images"], inputs["texts"], target, ewc)
+        loss, output, ewc_task, ewc_loss = model.fused_forward_backward(self.task_key, inputs["images"], inputs["texts"], target, ewc,
+                                                                        grad_weight=batch.get("dp_weight", 1.0))
         if optimizer is not None:
             optimizer.step()
             if scheduler is not None:
@@ -110,6 +118,7 @@ class VLTaskTrainer(TaskTrainer):
     # ---- REF train_vqa.py:176-244
     def train(self, model, replay_memory=None, ewc=None):
         model.to(self.device)
+        parallel.ensure_reducer(model)        # N > 1 ranks: broadcast rank 0's parameters, all-reduce gradient ranges under the backward
         do_replay = do_ewc = False
         if self.args.cl_algorithm == "experience_replay":
             assert replay_memory is not None
@@ -153,10 +162,18 @@ class VLTaskTrainer(TaskTrainer):
         for step, batch in enumerate(self.val_dataloader):
             output = self.forward_pass(model, batch, do_eval=True)
             score += self.batch_score(output[1], batch).double()      # accumulated on device: one sync per eval, not per batch
+        if parallel.rank_world()[1] > 1 and self._val_is_sharded():
+            import torch.distributed as dist
+            dist.all_reduce(score)            # every rank scored its own shard of the validation set (REF train_vqa.py:258-263 sums over all of it)
         model.train()
         return float(score.item()) / len(self.val_dataloader.dataset) * 100.0
 
+    def _val_is_sharded(self) -> bool:
+        from ..data.sharding import ShardedDataLoader
+        return isinstance(self.val_dataloader, ShardedDataLoader)
+
     def eval_forgetting(self, model, model_path: str) -> float:
+        parallel.barrier()                    # rank 0 wrote the checkpoint (parallel.rank0_only_io); nobody reads it before it is complete
         model.to(self.device)
         model.load_state_dict(torch.load(model_path))
         return self.eval(model)
@@ -240,6 +257,7 @@ class LowShotMixin:
 
     def train(self, model):
         model.to(self.device)
+        parallel.ensure_reducer(model)
         optimizer = model.create_optimizer(self.hparams)
         scheduler = polynomial_decay_schedule_with_warmup(optimizer, int(self.max_steps * self.warmup_ratio), self.max_steps, 0.0, 1.0)
         best_score = 0

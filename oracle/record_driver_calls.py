@@ -50,6 +50,12 @@ def install_fake_c_abi():
     _lib.load = lambda: None
     _lib.call = fake_call
     _lib.query = lambda name: 32
+    # everything ViltEngine asks the library about itself (r02's fp16 build added these).  tests/test_dp_training.py (a CPU test) runs whole
+    # driver scenarios -- engines constructed, fused steps, plug-ins -- on this stand-in, so the recorder cannot silently rot again when the
+    # host code grows another query
+    _lib.select_h16 = lambda name: None
+    _lib.h16 = lambda: os.environ.get("CLIMB_AMD_H16") or "bf16"
+    _lib.torch_h16 = lambda: torch.float16 if _lib.h16() == "fp16" else torch.bfloat16
     engine._lib = _lib
 
     def allocate(self):

@@ -120,3 +120,62 @@ def test_lowshot_driver_scenario_matches_the_reference_drivers_call_sequence(nam
         assert {k: v for k, v in r.items() if k != "best_low_shot_score"} == {k: v for k, v in g.items() if k != "best_low_shot_score"}
         assert r["best_low_shot_score"] == pytest.approx(g["best_low_shot_score"], abs=1e-4), (r, g)
     assert all(bool(torch.isfinite(p).all()) for p in out["model"].parameters())
+
+
+# ------------------------------------------------------------------------------------------------ data-parallel driver runs
+@pytest.fixture(scope="module")
+def dp_tree(tmp_path_factory):
+    root = str(tmp_path_factory.mktemp("climb_dp"))
+    # 19 training examples at a global batch of 8 / 4 / 2 (VQA, SNLI-VE / NLVR2 / VCR): last batches of 3, 3 and 1 -- uneven shares
+    # (weights 4/3, 2/3) and a rank with no example of its own (weight 0)
+    synth_data.make_climb_data_tree(os.path.join(root, "data"), n_train=19, n_val=sc.N_VAL, seed=sc.SEED, easy_answer=sc.EASY_ANSWER)
+    return os.path.join(root, "data"), synth_data.write_vocab(os.path.join(root, "vocab.txt"))
+
+
+def _rel(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).norm() / (b.norm() + 1e-300))
+
+
+@pytest.mark.parametrize("name", ["ewc", "experience_replay"])
+def test_two_rank_data_parallel_driver_run_equals_the_single_process_run(name, dp_tree, tmp_path, golden_dir):
+    """BASELINE.json configs[3] / configs[4] AS data-parallel jobs, on the real engine: two processes (gloo on device tensors; both on the
+    box's one GPU) run the four-task EWC / ER driver scenario with rank-sharded loaders, the reducer the trainers attach, all-reduced
+    evaluation, the replicated + broadcast Fisher pass, sharded replay batches and rank-0 checkpoints (fp32 arithmetic so that the
+    comparison with ONE process on the global batches is tight).  Required: the reference driver's call sequence on every rank, replicas
+    bit-identical at the end, the single-process results.json, and -- EWC -- theta* / Fisher of every finished task equal to the
+    single-process ones up to fp32 summation order (global batch k of the two-rank run IS batch k of the single-process run)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from tests.test_dp_training import _files, _pinned, _same, _scenario
+    env = {"CLIMB_AMD_PRECISION": "fp32"}
+    out1, rep1 = _scenario(1, name, dp_tree, tmp_path, abi="hip", env_extra=env, extra=["--pin"])
+    out2, rep2 = _scenario(2, name, dp_tree, tmp_path, abi="hip", env_extra=env, extra=["--pin"])
+    golden = json.load(open(os.path.join(golden_dir, "driver_calls.json")))["scenarios"][name]
+    for rep in rep2 + rep1:
+        assert rep["calls"] == golden["calls"]
+    for rep in rep2:
+        assert rep["reducer_attached"] and rep["replicas_in_sync"] and rep["collectives"] > 0
+        assert rep["results"] == rep2[0]["results"] and rep["eval_results"] == rep2[0]["eval_results"]
+        assert rep["params"] == rep2[0]["params"]
+        _same(_pinned(rep["results"]), _pinned(rep1[0]["results"]))
+    run1, run2 = os.path.join(out1, golden["experiment_dir"]), os.path.join(out2, golden["experiment_dir"])
+    assert _files(run2) == _files(run1) == golden["files"]
+    if name == "ewc":
+        assert rep2[0]["fisher"] == rep2[1]["fisher"] and rep2[0]["theta_star"] == rep2[1]["theta_star"]      # broadcast / in-sync: identical bits
+        e1 = torch.load(os.path.join(out1, "report_0.json.ewc.pt"))
+        e2 = torch.load(os.path.join(out2, "report_0.json.ewc.pt"))
+        worst = 0.0
+        for task in ("vqa", "nlvr2", "snli-ve"):
+            dt, df = _rel(e2["theta_star"][task], e1["theta_star"][task]), _rel(e2["fisher"][task], e1["fisher"][task])
+            worst = max(worst, dt, df)
+            assert dt < 1e-4 and df < 2e-3, (task, dt, df)
+        print(f"two-rank EWC run vs single process: worst relative L2 difference of theta* / Fisher {worst:.2e}")
+    else:
+        assert rep2[0]["memory_idxs"] == rep2[1]["memory_idxs"] == rep1[0]["memory_idxs"]
+        # up to the end of the third task nothing is stochastic (VCR's head dropout draws per-rank masks): compare that checkpoint
+        a = torch.load(os.path.join(run1, "checkpoints", "task2_snli-ve", "encoder"))
+        b = torch.load(os.path.join(run2, "checkpoints", "task2_snli-ve", "encoder"))
+        worst = max(_rel(b[k].float(), a[k].float()) for k in a if a[k].numel() > 1000 and float(a[k].float().norm()) > 0)
+        print(f"two-rank ER run vs single process: worst per-tensor relative difference after three tasks {worst:.2e}")
+        assert worst < 1e-3

@@ -811,7 +811,7 @@ def test_mixed_orientation_batch_packs_valid_patches(precision, tol):
     images = dict(pixel_values=enc["pixel_values"], pixel_mask=enc["pixel_mask"])
     model.train()
     loss, (pooled, logits), _, _ = model.fused_forward_backward("vqa", images, texts, target)
-    ws = model._host._engine.saved["ws"]
+    ws = model._host._engine.last_ws
     assert ws.compact and ws.NP == 400 and ws.NS == 240 and ws.S_pad == 288
     oloss, (opooled, ologits), _, oG = vo.train_step(P, "vqa", enc, target)
     _close(pooled, opooled, tol, "pooled")

@@ -31,7 +31,7 @@ def run(precision):
     model.to(dev)
     model.train()
     loss, (pooled, logits), _, _ = model.fused_forward_backward("vqa", enc["pixel_values"], texts, target)
-    ws = model._host._engine.saved["ws"]
+    ws = model._host._engine.last_ws
     S = ws.S
     keep = {"pooled": pooled.float().cpu(), "logits": logits.float().cpu()}
     for name in ("x", "xn", "qkv", "ctx", "h1", "hn", "u", "a"):
