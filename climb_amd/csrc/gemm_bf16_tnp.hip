@@ -338,3 +338,222 @@ int climb_tnp_launch(const bf16_t* A, long lda, const bf16_t* B, long ldb, float
   if (best_ni == 4) return tnp_launch_one<4>(nwg, st, A, lda, B, ldb, C, ldc, M, N, K, best_rows, best_splits, dbias);
   return tnp_launch_one<3>(nwg, st, A, lda, B, ldb, C, ldc, M, N, K, best_rows, best_splits, dbias);
 }
+
+// ======================================================================================================================================
+// Grouped weight gradients (r03): ONE persistent launch for the dW GEMMs of several layers, no token split for whole tiles.
+//
+// Nothing reads a weight gradient before the optimizer, so the host defers the four dW GEMMs of a layer (dW2, dW1, dWo, dWqkv: 108 output
+// tiles of 256 x 256 at ViLT-B's shapes) and hands a group of layers to this kernel: 6 / 12 layers = 648 / 1296 tiles = 2.5 / 5 rounds of
+// 256 CUs.  A tile now reduces over ALL tokens inside one workgroup (192 reduction tiles at 12288 tokens instead of ~38 per split), adds
+// its sum to C with a plain read-modify-write, and needs neither the 47 MB of split partials per GEMM nor the reduce launch.  What does not
+// fill a whole round -- the last `tiles mod 256` tiles -- is cut stream-K style into equal shares of reduction tiles, one per CU, whose
+// partial sums meet in C through fp32 atomics (<= 2 partial tiles per CU and launch).
+//
+// The work list is data: `items` (tile, reduction range) sorted by workgroup, `first[b] .. first[b + 1]` = workgroup b's items;
+// climb_tn_grouped_plan() builds it on the host, once per shape (the tables live in HBM and are reused every step).
+struct TnGroupProblem {      // 72 bytes; include/climb_hip.h documents this layout
+  const bf16_t* A;           // [M, N] token-major (lda)   -- dY
+  const bf16_t* B;           // [M, K] token-major (ldb)   -- X
+  float* C;                  // [N, K] (ldc), accumulated into
+  float* dbias;              // [N] += column sums of A, or NULL
+  long lda, ldb, ldc;
+  int M, N, K, reserved;
+};
+struct TnGroupItem { int prob, tn, tk, kt0, kt1, partial, r0, r1; };      // 32 bytes; reduction tiles [kt0, kt1) of 64 tokens, kt1 - kt0 >= 2
+
+__global__ __launch_bounds__(512) void gemm_bf16_tn_grouped_kernel(const TnGroupProblem* __restrict__ probs, const TnGroupItem* __restrict__ items,
+                                                                   const int* __restrict__ first) {
+  constexpr int NI = 4, BK_ = 256;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wid >> 1, wc = wid & 1, grp = wid >> 2, half = lane >> 5, l31 = lane & 31;
+  const int g16 = lane >> 4, i16 = lane & 15, trow = (g16 >> 1) * 8 + (i16 >> 2), tcol = (g16 & 1) * 16 + 4 * (i16 & 3);
+  unsigned aoff[2], boff;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int col = wr * 64 + j * 32 + tcol;
+    aoff[j] = trow * 512 + (((col >> 3) ^ tnp_aswz(trow)) << 4) + (col & 7) * 2;
+  }
+  {
+    const int col = wc * 32 + tcol;
+    boff = trow * 128 + (((col >> 3) ^ tnp_bswz(trow)) << 4) + (col & 7) * 2;
+  }
+  const int it_end = __builtin_amdgcn_readfirstlane(first[blockIdx.x + 1]);
+  for (int it = __builtin_amdgcn_readfirstlane(first[blockIdx.x]); it < it_end; ++it) {
+    const TnGroupItem item = items[it];
+    const TnGroupProblem P = probs[__builtin_amdgcn_readfirstlane(item.prob)];
+    const int tn = __builtin_amdgcn_readfirstlane(item.tn), tk = __builtin_amdgcn_readfirstlane(item.tk);
+    const int kt0 = __builtin_amdgcn_readfirstlane(item.kt0), nk = __builtin_amdgcn_readfirstlane(item.kt1) - kt0;
+    const bool partial = __builtin_amdgcn_readfirstlane(item.partial) != 0;
+    const int N = P.N, K = P.K, nbk = K / BK_;
+    const long lda = P.lda, ldb = P.ldb, ldc = P.ldc;
+    const int n0 = tn * NTP_BM, k0 = tk * BK_;
+    const long a_tile = 64 * lda * 2, b_tile = 64 * ldb * 2;
+    const unsigned char* A = reinterpret_cast<const unsigned char*>(P.A) + (long)kt0 * a_tile;
+    const unsigned char* B = reinterpret_cast<const unsigned char*>(P.B) + (long)kt0 * b_tile;
+    TnpStage<NI> sg;
+    sg.wid = wid;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int slot = (wid * 2 + i) * 64 + lane, r = u * 32 + (slot >> 5), c = (slot & 31) ^ tnp_aswz(r);
+        sg.a_off[u * 2 + i] = (unsigned)(((long)r * lda + n0 + c * 8) * 2);
+      }
+#pragma unroll
+    for (int p = 0; p < NI; ++p) {
+      const int slot = wid * 64 + lane, r = slot >> 3, c = (slot & 7) ^ tnp_bswz(r);
+      sg.b_off[p] = (unsigned)(((long)r * ldb + k0 + (c >> 2) * (32 * NI) + p * 32 + (c & 3) * 8) * 2);
+    }
+    f32x16 acc[NI][2];
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    float bsum[2] = {0.f, 0.f};
+    const bool do_bias = P.dbias != nullptr && wc == 0;
+    const int tb = (tk - kt0 % nbk + nbk) % nbk;        // reduction tile T of this item is dealt to k-tile column (kt0 + T) % nbk
+    bf16x8 a[2][4];
+    tnp_prologue<NI>(sg, A, a_tile, B, b_tile, smem);
+    wait_vmcnt<ntp_wait(NI, 6, -1, NI - 1)>();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    int T = 0;
+    for (; T + 2 < nk; ++T) tnp_ktile<NI, 0>(acc, a, bsum, do_bias && (T % nbk) == tb, sg, A, a_tile, B, b_tile, smem, T, aoff, boff);
+    tnp_ktile<NI, 1>(acc, a, bsum, do_bias && (T % nbk) == tb, sg, A, a_tile, B, b_tile, smem, T, aoff, boff);
+    tnp_ktile<NI, 2>(acc, a, bsum, do_bias && ((T + 1) % nbk) == tb, sg, A, a_tile, B, b_tile, smem, T + 1, aoff, boff);
+    if (grp == 0) __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    float* Cb = P.C + (long)(n0 + wr * 64 + 4 * half) * ldc + k0 + wc * (32 * NI) + l31;
+    if (partial) {
+#pragma unroll
+      for (int p = 0; p < NI; ++p)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) atomicAdd(Cb + (long)(j * 32 + (r & 3) + 8 * (r >> 2)) * ldc + p * 32, acc[p][j][r]);
+    } else {
+      // whole tile: the only writer of these elements in this launch.  All 16 loads of a (p, j) block are issued before its first store
+      // (a load behind a store drains the store queue on gfx9: one vmcnt for both kinds)
+#pragma unroll
+      for (int p = 0; p < NI; ++p)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          float old[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) old[r] = Cb[(long)(j * 32 + (r & 3) + 8 * (r >> 2)) * ldc + p * 32];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) Cb[(long)(j * 32 + (r & 3) + 8 * (r >> 2)) * ldc + p * 32] = old[r] + acc[p][j][r];
+        }
+    }
+    if (do_bias) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const float s = bsum[j] + __shfl_xor(bsum[j], 32, 64);
+        if (half == 0) atomicAdd(P.dbias + n0 + wr * 64 + j * 32 + l31, s);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();       // the next item's prologue overwrites the buffers
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// Host-side planner (no device work).  M[p] % 128 == 0 (whole 64-token reduction tiles, an even number of them, so that every cut of the
+// stream-K tail leaves >= 2 tiles on both sides), N[p] % 256 == 0, K[p] % 256 == 0.  Workgroup b of `nwg` (a multiple of 8: XCD = b % 8)
+// gets items first[b] .. first[b + 1] - 1.  Returns the number of items written, CLIMB_EINVAL for shapes outside the contract, or
+// CLIMB_EUNSUPPORTED when `cap` items do not suffice (at most tiles + nwg + 1 are ever needed).
+extern "C" int climb_tn_grouped_plan(int nprob, const int* M, const int* N, const int* K, int nwg, int* items_out, int cap, int* first_out) {
+  if (nprob <= 0 || nwg <= 0 || (nwg % 8) || !M || !N || !K || !items_out || !first_out) return CLIMB_EINVAL;
+  struct Tile { int prob, tn, tk, nkt; };
+  long ntiles = 0;
+  for (int p = 0; p < nprob; ++p) {
+    if (M[p] < 128 || (M[p] % 128) || N[p] <= 0 || (N[p] % 256) || K[p] <= 0 || (K[p] % 256)) return CLIMB_EINVAL;
+    ntiles += (long)(N[p] / 256) * (K[p] / 256);
+  }
+  if (ntiles + nwg + 1 > cap) return CLIMB_EUNSUPPORTED;
+  Tile* tiles = new Tile[ntiles];
+  long t = 0;
+  for (int p = 0; p < nprob; ++p) {
+    const int nbn = N[p] / 256, nbk = K[p] / 256;
+    for (int i = 0; i < nbn * nbk; ++i) {
+      // consecutive tiles (= the CUs of one XCD) walk the narrower operand fastest: the XCD's L2 re-reads the smaller panels
+      Tile x;
+      x.prob = p;
+      x.tn = nbn > nbk ? i / nbk : i % nbn;
+      x.tk = nbn > nbk ? i % nbk : i / nbn;
+      x.nkt = M[p] / 64;
+      tiles[t++] = x;
+    }
+  }
+  const int per_xcd = nwg / 8;
+  // per-workgroup item lists, indexed by RANK r = xcd * per_xcd + idx (consecutive ranks share an XCD); blockIdx b <-> rank (b % 8) * per_xcd + b / 8
+  int* count = new int[nwg]();
+  const long rounds = ntiles / nwg, tail0 = rounds * nwg;
+  long units = 0;
+  for (long i = tail0; i < ntiles; ++i) units += tiles[i].nkt;
+  long q = (units + nwg - 1) / nwg;
+  q += q & 1;                                              // even share: cuts fall on even reduction-tile indices
+  // pass 1 counts, pass 2 writes (first[] needs the counts of all lower block indices)
+  int* rank_first = new int[nwg + 1];
+  for (int pass = 0; pass < 2; ++pass) {
+    if (pass == 1) {
+      int at = 0;
+      for (int b = 0; b < nwg; ++b) {
+        const int r = (b % 8) * per_xcd + b / 8;
+        first_out[b] = at;
+        rank_first[r] = at;
+        at += count[r];
+      }
+      first_out[nwg] = at;
+      for (int r = 0; r < nwg; ++r) count[r] = 0;
+    }
+    auto emit = [&](int r, const Tile& x, int kt0, int kt1) {
+      if (pass == 1) {
+        int* o = items_out + 8L * (rank_first[r] + count[r]);
+        o[0] = x.prob; o[1] = x.tn; o[2] = x.tk; o[3] = kt0; o[4] = kt1; o[5] = (kt0 != 0 || kt1 != x.nkt) ? 1 : 0; o[6] = o[7] = 0;
+      }
+      ++count[r];
+    };
+    for (long j = 0; j < rounds; ++j)
+      for (int r = 0; r < nwg; ++r) emit(r, tiles[j * nwg + r], 0, tiles[j * nwg + r].nkt);
+    int r = 0;
+    long rem = q;
+    for (long i = tail0; i < ntiles; ++i) {
+      int pos = 0;
+      while (pos < tiles[i].nkt) {
+        const int take = (int)((tiles[i].nkt - pos) < rem ? (tiles[i].nkt - pos) : rem);
+        emit(r, tiles[i], pos, pos + take);
+        pos += take;
+        rem -= take;
+        if (rem == 0) { ++r; rem = q; }
+      }
+    }
+  }
+  const int total = first_out[nwg];
+  delete[] tiles;
+  delete[] count;
+  delete[] rank_first;
+  return total;
+}
+
+// probs: TnGroupProblem[...] in device memory, items / first: the planner's tables copied to device memory (ints).  nwg workgroups
+// (what the plan was made for; 256 on MI355X).
+extern "C" int climb_gemm_bf16_tn_grouped(const void* probs, const void* items, const void* first, int nwg, void* stream) {
+  if (!probs || !items || !first || nwg <= 0) return CLIMB_EINVAL;
+  constexpr int LDS = 2 * (NTP_A_BYTES + 4 * NTP_B_UNIT);
+  static bool configured = false;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_tn_grouped_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) return (int)e;
+    configured = true;
+  }
+  hipLaunchKernelGGL(gemm_bf16_tn_grouped_kernel, dim3(nwg), dim3(512), LDS, (hipStream_t)stream, (const TnGroupProblem*)probs, (const TnGroupItem*)items,
+                     (const int*)first);
+  LAUNCH_CHECK();
+  return CLIMB_OK;
+}

@@ -21,6 +21,10 @@ from .layout import ENC, FlatLayout, VILT_CFG, TASK_ARITH
 
 F32, BF16 = 0, 1
 _FUSED_ADAPTER = os.environ.get("CLIMB_AMD_FUSED_ADAPTER", "1") != "0"       # measurement knob: 0 = the two skinny GEMMs
+# weight gradients of the encoder layers as grouped launches (csrc/gemm_bf16_tnp.hip: gemm_bf16_tn_grouped_kernel): layers per launch.
+# "0" = off (one split GEMM + reduce per weight, the r02 path); default: all layers in one launch, 4 per launch under a data-parallel hook
+# (ranges must become ready in a few chunks for the all-reduce to overlap the rest of the backward)
+_DW_GROUP = os.environ.get("CLIMB_AMD_DW_GROUP")
 _UNSCALE_MODE = os.environ.get("CLIMB_AMD_FP16_UNSCALE", "end")      # measurement knob: "range" (per finished range), "end" (one pass), "none" (timing only)
 EPI_NONE, EPI_GELU, EPI_RESID, EPI_DGELU, EPI_TANH, EPI_SILU, EPI_DSILU, EPI_RESID2 = 0, 1, 2, 3, 4, 5, 6, 7
 
@@ -122,6 +126,21 @@ class Workspace:
             self.dz = buf((M, r), adt)
             self.dy = buf((M, H), adt)
         self.ones = torch.ones((max(B, 8),), dtype=f32, device=dev)
+        self.dw_plans = {}           # grouped weight-gradient launches: problem / item tables in HBM, built once per set of GEMMs
+        self.dx_c = self.dh_c = self.du_l = self.dqkv_l = None
+
+    def ensure_deferred(self, eng: "ViltEngine"):
+        """Per-LAYER copies of the four weight-gradient operands the backward produces (d(x_{i+1}), d(u_i), d(h1_i), d(qkv_i), 16 bit): the
+        grouped dW launch reads them after the whole group's backward has run, so they cannot share one scratch buffer any more
+        (170 MB per layer at 12288 tokens, 2 GB for ViLT-B: nothing on a 288 GB part).  The producing kernels write them directly."""
+        if self.dx_c is not None:
+            return
+        cfg, dev, t16 = eng.cfg, eng.device, eng.t16
+        H, Fd, L, M = cfg["hidden"], cfg["ffn"], cfg["layers"], self.M
+        self.dx_c = [torch.empty((M, H), dtype=t16, device=dev) for _ in range(L + 1)]
+        self.dh_c = [torch.empty((M, H), dtype=t16, device=dev) for _ in range(L)]
+        self.du_l = [torch.empty((M, Fd), dtype=t16, device=dev) for _ in range(L)]
+        self.dqkv_l = [torch.empty((M, 3 * H), dtype=t16, device=dev) for _ in range(L)]
 
 
 class HeadState:
@@ -547,6 +566,53 @@ class ViltEngine:
         else:   # the bf16 kernel computes delta in its first phase (`delta` is its scratch)
             _lib.call("climb_attn_bwd_bf16", qkv, key_bias, dctx, ctx, lse, delta, dqkv, B, S_pad, cfg["heads"], cfg["head_dim"], st)
 
+    # ------------------------------------------------------------------ deferred, grouped weight gradients
+    def _dw_group_size(self, ws: Workspace, ad) -> int:
+        """Layers per grouped weight-gradient launch for this backward; 0 = the immediate per-GEMM path."""
+        if self.precision != "bf16" or ad is not None or (ws.M % 128) or self.overlap_dw:
+            return 0
+        if _DW_GROUP is not None:
+            return max(0, int(_DW_GROUP))
+        return 4 if self.grad_ready_hook is not None else self.cfg["layers"]
+
+    def _dw_defer(self, pending: list, dY, X, wname, M, N, K, bname=None, ws=None):
+        """linear_dw, but recorded for the group's launch when the shape fits its 256 x 256 tiles (else run now)."""
+        want_b = bname is not None and self.requires_grad[bname]
+        if not self.requires_grad[wname] or (M % 128) or (N % 256) or (K % 256):
+            return self.linear_dw(dY, X, wname, M, N, K, bname, ws)
+        pending.append((dY, X, wname, bname if want_b else None, M, N, K))
+
+    def _dw_flush(self, ws: Workspace, pending: list):
+        if not pending:
+            return
+        import numpy as np
+        key = tuple((w, b, dY.data_ptr(), X.data_ptr()) for dY, X, w, b, M, N, K in pending)
+        plan = ws.dw_plans.get(key)
+        if plan is None:
+            nwg = max(8, torch.cuda.get_device_properties(self.device).multi_processor_count // 8 * 8)
+            rec = np.zeros(len(pending), dtype=[("A", "<u8"), ("B", "<u8"), ("C", "<u8"), ("dbias", "<u8"), ("lda", "<i8"), ("ldb", "<i8"), ("ldc", "<i8"),
+                                                ("M", "<i4"), ("N", "<i4"), ("K", "<i4"), ("reserved", "<i4")])
+            assert rec.dtype.itemsize == 72
+            for r, (dY, X, w, b, M, N, K) in zip(rec, pending):
+                r["A"], r["B"], r["C"], r["dbias"] = dY.data_ptr(), X.data_ptr(), self.g(w), (self.g(b) if b is not None else 0)
+                r["lda"], r["ldb"], r["ldc"], r["M"], r["N"], r["K"] = N, K, K, M, N, K
+            Ms, Ns, Ks = (np.ascontiguousarray(rec[f], dtype=np.int32) for f in ("M", "N", "K"))
+            cap = int(sum((n // 256) * (k // 256) for n, k in zip(Ns, Ks))) + nwg + 1
+            items = np.zeros((cap, 8), dtype=np.int32)
+            first = np.zeros(nwg + 1, dtype=np.int32)
+            n_items = _lib.load().climb_tn_grouped_plan(len(pending), Ms.ctypes.data, Ns.ctypes.data, Ks.ctypes.data, nwg, items.ctypes.data, cap, first.ctypes.data)
+            if n_items <= 0:
+                raise RuntimeError(f"climb_tn_grouped_plan failed: {_lib.error_string(n_items)} (code {n_items})")
+            dev = self.device
+            plan = dict(probs=torch.from_numpy(rec.view(np.uint8).copy()).to(dev), items=torch.from_numpy(items[:n_items].copy()).to(dev),
+                        first=torch.from_numpy(first).to(dev), nwg=nwg, flops=float(sum(2.0 * M * N * K for _, _, _, _, M, N, K in pending)),
+                        keep=[(dY, X) for dY, X, *_ in pending])
+            if len(ws.dw_plans) >= 16:           # requires_grad patterns / group sizes seen on this shape: bounded
+                ws.dw_plans.pop(next(iter(ws.dw_plans)))
+            ws.dw_plans[key] = plan
+        self._timed_call("gemm_bf16_tn", plan["flops"], "climb_gemm_bf16_tn_grouped", plan["probs"], plan["items"], plan["first"], plan["nwg"], _stream())
+        pending.clear()
+
     # ------------------------------------------------------------------ encoder backward
     def _trainable_runs(self, lo, hi):
         """maximal runs of TRAINABLE tensors inside the flat range [lo, hi): what a data-parallel reducer has to carry (a frozen base
@@ -618,49 +684,76 @@ class ViltEngine:
         # d(x_L): cast for the GEMMs (bf16 mode) + column sums for the last layer's output bias
         csr = _lib.query("climb_colsum_rows_per_block")
         last = f"{ENC}encoder.layer.{cfg['layers'] - 1}."
-        _lib.call("climb_colsum", ws.dres, H, F32, None if self.precision == "fp32" else ws.dres_c, H, ws.part, M, H, st)
+        G = self._dw_group_size(ws, ad)          # > 0: weight gradients are recorded per layer and launched per group of G layers
+        pending, group = [], []
+        if G:
+            ws.ensure_deferred(self)
+        dxc = (lambda i: ws.dx_c[i]) if G else (lambda i: ws.dres_c)          # 16-bit d(x_i) / d(h1_i) / d(u_i) / d(qkv_i): per layer when deferred
+        dhc = (lambda i: ws.dh_c[i]) if G else (lambda i: ws.dres_c)
+        du_ = (lambda i: ws.du_l[i]) if G else (lambda i: ws.du)
+        dqkv_ = (lambda i: ws.dqkv_l[i]) if G else (lambda i: ws.dqkv)
+        dw = (lambda *a, **k: self._dw_defer(pending, *a, **k)) if G else self.dw_async
+        nL = cfg["layers"]
+        _lib.call("climb_colsum", ws.dres, H, F32, None if self.precision == "fp32" else dxc(nL), H, ws.part, M, H, st)
         if first_layer < cfg["layers"] and ad is None:
             self.bias_grad_from_part(ws.part.data_ptr(), H, (M + csr - 1) // csr, last + "output.dense.bias", H)
         for i in range(cfg["layers"] - 1, first_layer - 1, -1):
             l = f"{ENC}encoder.layer.{i}."
             # MLP: x_{i+1} = h1 + W2 gelu(u) + b2,  u = W1 hn + b1
             if ad is None:
-                dy = ws.dres_c
-                self.dw_async(dy, ws.a[i], l + "output.dense.weight", M, H, Fd)
+                dy = dxc(i + 1)
+                dw(dy, ws.a[i], l + "output.dense.weight", M, H, Fd)
             else:   # x_{i+1} = h1 + y + up(silu(down(y))): d(y) = d(x_{i+1}) + down^T(silu'(z) * up^T d(x_{i+1}))
                 dy = self.adapter_backward(ws, f"{l}output.adapters.{ad}.", ws.so[i], ws.zo[i], ws.yo[i], M, H, r)
                 self.dw_async(dy, ws.a[i], l + "output.dense.weight", M, H, Fd, l + "output.dense.bias", ws)
-            self.linear_dx(dy, l + "output.dense.weight", ws.du, M, H, Fd, EPI_DGELU, ws.u[i])
-            self.dw_async(ws.du, ws.hn[i], l + "intermediate.dense.weight", M, Fd, H, l + "intermediate.dense.bias", ws)
-            self.linear_dx(ws.du, l + "intermediate.dense.weight", ws.dhn, M, Fd, H)
+            du = du_(i)
+            self.linear_dx(dy, l + "output.dense.weight", du, M, H, Fd, EPI_DGELU, ws.u[i])
+            dw(du, ws.hn[i], l + "intermediate.dense.weight", M, Fd, H, l + "intermediate.dense.bias", ws)
+            self.linear_dx(du, l + "intermediate.dense.weight", ws.dhn, M, Fd, H)
             self.join_side()          # LN backward overwrites d(residual) that dW2 is reading
             _lib.call("climb_layernorm_bwd", ws.dhn, H, adt, ws.h1[i], H, ws.mean2[i], ws.rstd2[i], self.p(l + "layernorm_after.weight"),
-                      ws.dres, H, ws.dres, H, None if self.precision == "fp32" else ws.dres_c, H, ws.part, M, H, st)
+                      ws.dres, H, ws.dres, H, None if self.precision == "fp32" else dhc(i), H, ws.part, M, H, st)
             self.reduce3(ws.part, nlnb, H, l + "layernorm_after.weight", l + "layernorm_after.bias",
                          l + "attention.output.dense.bias" if ad is None else None)
             # attention: h1 = x + Wo ctx + bo
             if ad is None:
-                dy = ws.dres_c
-                self.dw_async(dy, ws.ctx[i], l + "attention.output.dense.weight", M, H, H)
+                dy = dhc(i)
+                dw(dy, ws.ctx[i], l + "attention.output.dense.weight", M, H, H)
             else:
                 dy = self.adapter_backward(ws, f"{l}attention.output.adapters.{ad}.", ws.sa[i], ws.za[i], ws.ya[i], M, H, r)
                 self.dw_async(dy, ws.ctx[i], l + "attention.output.dense.weight", M, H, H, l + "attention.output.dense.bias", ws)
             self.linear_dx(dy, l + "attention.output.dense.weight", ws.dctx, M, H, H)
-            self.attn_bwd(ws.qkv[i], ws.key_bias, ws.dctx, ws.ctx[i], ws.lse[i], ws.delta, ws.dqkv, B, ws.S_pad)
+            dqkv = dqkv_(i)
+            self.attn_bwd(ws.qkv[i], ws.key_bias, ws.dctx, ws.ctx[i], ws.lse[i], ws.delta, dqkv, B, ws.S_pad)
             # q/k/v weights and biases are adjacent: one [2304,768] weight-gradient GEMM + one [2304] bias reduction
-            self.dw_async(ws.dqkv, ws.xn[i], l + "attention.attention.query.weight", M, 3 * H, H, l + "attention.attention.query.bias", ws)
+            dw(dqkv, ws.xn[i], l + "attention.attention.query.weight", M, 3 * H, H, l + "attention.attention.query.bias", ws)
             need_dx = i > first_layer or embeddings
             if need_dx:
-                self.linear_dx(ws.dqkv, l + "attention.attention.query.weight", ws.dxn, M, 3 * H, H)
+                self.linear_dx(dqkv, l + "attention.attention.query.weight", ws.dxn, M, 3 * H, H)
                 self.join_side()      # LN backward overwrites d(residual) (read by dWo); next layer overwrites du / dqkv
                 _lib.call("climb_layernorm_bwd", ws.dxn, H, adt, ws.x[i], H, ws.mean1[i], ws.rstd1[i], self.p(l + "layernorm_before.weight"),
-                          ws.dres, H, ws.dres, H, None if self.precision == "fp32" else ws.dres_c, H, ws.part, M, H, st)
+                          ws.dres, H, ws.dres, H, None if self.precision == "fp32" else dxc(i), H, ws.part, M, H, st)
                 self.reduce3(ws.part, nlnb, H, l + "layernorm_before.weight", l + "layernorm_before.bias",
                              f"{ENC}encoder.layer.{i - 1}.output.dense.bias" if (i > first_layer and ad is None) else None)
             self.join_side()
-            self._ready(*lay.layer_range[i])
-        if embeddings and first_layer == 0:
-            self.embedding_backward(ws, sv)
+            if not G:
+                self._ready(*lay.layer_range[i])
+                continue
+            group.append(i)
+            last_group = i == first_layer
+            if len(group) >= G and not last_group:
+                self._dw_flush(ws, pending)
+                for j in group:
+                    self._ready(*lay.layer_range[j])
+                group = []
+        do_emb = embeddings and first_layer == 0
+        if do_emb:
+            self.embedding_backward(ws, sv, pending if G else None)          # the patch projection's dW rides in the last group
+        if G:
+            self._dw_flush(ws, pending)
+            for j in group:
+                self._ready(*lay.layer_range[j])
+        if do_emb:
             self._ready(*lay.embed_range)
         self.saved = None          # the activations are consumed: a later no-grad forward may use this workspace again
 
@@ -683,7 +776,7 @@ class ViltEngine:
         self.linear_dx(ws.dz, a_ + "adapter_down.0.weight", ws.dy, M, r, H, EPI_RESID, ws.dres)
         return ws.dy
 
-    def embedding_backward(self, ws: Workspace, sv):
+    def embedding_backward(self, ws: Workspace, sv, pending: Optional[list] = None):
         cfg = self.cfg
         B, T, H = ws.B, ws.T, cfg["hidden"]
         st = _stream()
@@ -697,7 +790,10 @@ class ViltEngine:
                   1 if ws.compact else 0, st)
         self.bias_grad_from_part(ws.part.data_ptr(), ntypes * H, ws.NP + 1, e + "token_type_embeddings.weight", ntypes * H)
         Kp = cfg["channels"] * cfg["patch"] ** 2
-        self.linear_dw(ws.dproj, ws.a_patch, e + "patch_embeddings.projection.weight", B * ws.NP, H, Kp, e + "patch_embeddings.projection.bias", ws)
+        if pending is not None:
+            self._dw_defer(pending, ws.dproj, ws.a_patch, e + "patch_embeddings.projection.weight", B * ws.NP, H, Kp, e + "patch_embeddings.projection.bias", ws)
+        else:
+            self.linear_dw(ws.dproj, ws.a_patch, e + "patch_embeddings.projection.weight", B * ws.NP, H, Kp, e + "patch_embeddings.projection.bias", ws)
         te = e + "text_embeddings."
         ie = sv.get("inputs_embeds")
         _lib.call("climb_embed_text_bwd", sv["input_ids"] if ie is None else None, sv["token_type_ids"],

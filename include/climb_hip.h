@@ -138,6 +138,19 @@ int climb_gemm_bf16_tn(const void* A, long lda, const void* B, long ldb, float* 
  * >= splits*N*K*4 bytes the partials are written as plain stores and summed by a second launch on the same stream; without one they
  * are accumulated with fp32 atomics.  64 MB covers every ViLT-B shape at 12288 tokens.  Caller-owned, stream-ordered use. */
 int climb_set_tn_workspace(void* ptr, long bytes);
+/* Grouped weight gradients (r03): the dW GEMMs of SEVERAL layers (HF:325-327, :366-369, :397-414: dW2, dW1, dWo, dWqkv, and the patch
+ * projection's, HF:292-300) as ONE persistent launch.  Every 256 x 256 output tile that fits a whole round of the chip reduces over all
+ * tokens inside one workgroup and is added to C with a plain read-modify-write: no token split, no partial sums, no reduce launch;
+ * the last (tiles mod nwg) tiles are cut stream-K style into equal shares whose sums meet in C through fp32 atomics.
+ *   probs : device array of 72-byte records { const void* A [M,N] 16-bit, token-major; const void* B [M,K]; float* C [N,K]; float* dbias
+ *           [N] or NULL; long lda, ldb, ldc; int M, N, K, reserved }   --  C += A^T B, dbias += column sums of A
+ *   items : device int32 [n_items][8] = { problem, tile n, tile k, first reduction tile, end reduction tile, partial, 0, 0 }
+ *   first : device int32 [nwg + 1]: workgroup b walks items first[b] .. first[b + 1] - 1
+ * climb_tn_grouped_plan fills HOST copies of `items` (capacity `cap` records) and `first` from the problems' shapes (host arrays; M % 128,
+ * N % 256, K % 256 required) for `nwg` workgroups (a multiple of 8; 256 on MI355X) and returns the number of items (or a negative code);
+ * the caller uploads them once per shape and keeps them -- the launch itself allocates and copies nothing. */
+int climb_tn_grouped_plan(int nprob, const int* M, const int* N, const int* K, int nwg, int* items_out, int cap, int* first_out);
+int climb_gemm_bf16_tn_grouped(const void* probs, const void* items, const void* first, int nwg, void* stream);
 /* HF:322-351 in bf16: same contract as the _f32 entry points, qkv/ctx/dctx/dqkv are bf16.  The backward takes the forward's ctx and
  * computes delta itself (its first phase); `delta` [B,heads,S_pad] is scratch it writes */
 int climb_attn_fwd_bf16(const void* qkv, const float* key_bias, void* ctx, float* lse, int B, int S_pad, int heads, int head_dim, void* stream);

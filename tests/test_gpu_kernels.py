@@ -195,6 +195,52 @@ def test_gemm_bf16_tn_persistent_tiles(M, N, K):
             assert _rel(out[mode][1], db0.double().cpu() + dY.double().cpu().sum(0)) < 1e-5
 
 
+@pytest.mark.parametrize("nwg", [256, 8, 24])
+def test_gemm_bf16_tn_grouped_launch(nwg):
+    """The grouped weight-gradient launch (r03: several dW GEMMs in one persistent kernel, whole tiles reduce over all tokens and
+    read-modify-write C, the stream-K tail meets through atomics) against float64 of the same 16-bit operands: problems of different
+    token counts and shapes, accumulation into non-zero C, fused bias gradients on some, nwg = 256 (everything is tail), 8 and 24 (whole
+    rounds + tail).  Repeated launches must agree (to the atomics' order)."""
+    from climb_amd import _lib
+    dev = _dev()
+    shapes = [(2048, 768, 768, True), (2048, 256, 512, False), (1024, 512, 256, True), (3072, 256, 256, False), (1152, 768, 256, True)]
+    g = torch.Generator(device=dev).manual_seed(5 + nwg)
+    ops = []
+    for M, N, K, bias in shapes:
+        ops.append((_bf(torch.randn(M, N, device=dev, generator=g)), _bf(torch.randn(M, K, device=dev, generator=g)),
+                    torch.randn(N, K, device=dev, generator=g), torch.randn(N, device=dev, generator=g) if bias else None))
+    rec = np.zeros(len(shapes), dtype=[("A", "<u8"), ("B", "<u8"), ("C", "<u8"), ("dbias", "<u8"), ("lda", "<i8"), ("ldb", "<i8"), ("ldc", "<i8"),
+                                       ("M", "<i4"), ("N", "<i4"), ("K", "<i4"), ("reserved", "<i4")])
+
+    def run():
+        Cs = [c.clone() for _, _, c, _ in ops]
+        dbs = [b.clone() if b is not None else None for *_, b in ops]
+        for r, (M, N, K, _), (dY, X, _, _), C, db in zip(rec, shapes, ops, Cs, dbs):
+            r["A"], r["B"], r["C"], r["dbias"] = dY.data_ptr(), X.data_ptr(), C.data_ptr(), (db.data_ptr() if db is not None else 0)
+            r["lda"], r["ldb"], r["ldc"], r["M"], r["N"], r["K"] = N, K, K, M, N, K
+        Ms, Ns, Ks = (np.ascontiguousarray(rec[f], dtype=np.int32) for f in ("M", "N", "K"))
+        cap = int(sum((n // 256) * (k // 256) for n, k in zip(Ns, Ks))) + nwg + 1
+        items, first = np.zeros((cap, 8), dtype=np.int32), np.zeros(nwg + 1, dtype=np.int32)
+        n = _lib.load().climb_tn_grouped_plan(len(shapes), Ms.ctypes.data, Ns.ctypes.data, Ks.ctypes.data, nwg, items.ctypes.data, cap, first.ctypes.data)
+        assert n > 0
+        d_rec = torch.from_numpy(rec.view(np.uint8).copy()).to(dev)
+        d_items, d_first = torch.from_numpy(items[:n].copy()).to(dev), torch.from_numpy(first).to(dev)
+        _lib.call("climb_gemm_bf16_tn_grouped", d_rec, d_items, d_first, nwg, _st())
+        torch.cuda.synchronize()
+        return Cs, dbs, items[:n]
+    Cs, dbs, items = run()
+    if nwg != 256:
+        assert (items[:, 5] == 0).any() and (items[:, 5] == 1).any()        # both epilogues ran
+    for (dY, X, C0, b0), C, db in zip(ops, Cs, dbs):
+        ref = C0.double().cpu() + dY.double().cpu().t() @ X.double().cpu()
+        assert _rel(C, ref) < 1e-5
+        if b0 is not None:
+            assert _rel(db, b0.double().cpu() + dY.double().cpu().sum(0)) < 1e-5
+    Cs2, dbs2, _ = run()
+    for a, b in zip(Cs, Cs2):
+        assert _rel(a, b) < 1e-5
+
+
 @pytest.mark.parametrize("S_pad,valid", [(64, 50), (192, 185), (224, 200), (288, 281)])
 def test_attention_f32_fwd_bwd(S_pad, valid):
     from climb_amd import _lib

@@ -223,3 +223,36 @@ def test_fp32_gemm_does_not_spill():
     for name, vgpr, scratch in rows:
         if not any(k in name for k in cs.KNOWN):
             assert scratch == 0, (name, vgpr, scratch)
+
+
+@pytest.mark.parametrize("layers,nwg", [(12, 256), (6, 256), (4, 256), (1, 256), (12, 64)])
+def test_grouped_weight_gradient_plan_covers_every_reduction_tile_once(layers, nwg):
+    """climb_tn_grouped_plan (host function of the library): for ViLT-B's four weight gradients per layer (+ the patch projection's, with
+    its own token count) every (tile, 64-token reduction tile) unit appears in exactly one item, items hold >= 2 reduction tiles, whole
+    tiles are never marked partial (they use the plain read-modify-write), and no workgroup carries more than its share + one tile."""
+    from climb_amd import _lib
+    lib = _lib.load()
+    shapes = [(12288, 768, 3072), (12288, 3072, 768), (12288, 768, 768), (12288, 2304, 768)] * layers + [(9216, 768, 3072)]
+    M, N, K = (np.ascontiguousarray([s[i] for s in shapes], dtype=np.int32) for i in range(3))
+    tiles = int(sum((n // 256) * (k // 256) for _, n, k in shapes))
+    cap = tiles + nwg + 1
+    items = np.zeros((cap, 8), dtype=np.int32)
+    first = np.zeros(nwg + 1, dtype=np.int32)
+    n = lib.climb_tn_grouped_plan(len(shapes), M.ctypes.data, N.ctypes.data, K.ctypes.data, nwg, items.ctypes.data, cap, first.ctypes.data)
+    assert 0 < n <= cap and first[0] == 0 and first[-1] == n and (np.diff(first) >= 0).all()
+    items = items[:n]
+    seen = {}
+    for p, tn, tk, k0, k1, partial, _, _ in items:
+        nkt = shapes[p][0] // 64
+        assert 0 <= tn < shapes[p][1] // 256 and 0 <= tk < shapes[p][2] // 256 and 0 <= k0 < k1 <= nkt and k1 - k0 >= 2
+        assert bool(partial) == (k0 != 0 or k1 != nkt)
+        cover = seen.setdefault((p, tn, tk), np.zeros(nkt, dtype=np.int32))
+        cover[k0:k1] += 1
+    assert len(seen) == tiles and all((c == 1).all() for c in seen.values())
+    load = np.array([sum(int(k1 - k0) for _, _, _, k0, k1, _, _, _ in items[first[b]:first[b + 1]]) for b in range(nwg)])
+    total = sum(s[0] // 64 * (s[1] // 256) * (s[2] // 256) for s in shapes)
+    assert load.sum() == total and load.max() <= total / nwg + 192 + 2          # balanced to within one tile's reduction
+    assert lib.climb_tn_grouped_plan(1, M.ctypes.data, N.ctypes.data, K.ctypes.data, 100, items.ctypes.data, cap, first.ctypes.data) == -1      # nwg % 8
+    bad = np.array([12288 + 64], dtype=np.int32)
+    assert lib.climb_tn_grouped_plan(1, bad.ctypes.data, N.ctypes.data, K.ctypes.data, 256, items.ctypes.data, cap, first.ctypes.data) == -1   # M % 128
+    assert lib.climb_tn_grouped_plan(len(shapes), M.ctypes.data, N.ctypes.data, K.ctypes.data, nwg, items.ctypes.data, 8, first.ctypes.data) == -2

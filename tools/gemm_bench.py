@@ -71,3 +71,23 @@ if __name__ == "__main__":
         tt += t; tf += f
         print(f"TN {name:14s} N={N:5d} K={K:5d}: {t*1e6:8.1f} us  {f/t/1e12:7.1f} TF")
     print(f"TN total {tt*1e3:.3f} ms/layer  {tf/tt/1e12:.1f} TF")
+    # r03: the same weight gradients as grouped launches (one launch per `layers` layers; per-layer operands like the engine keeps them)
+    import numpy as np
+    L = int(os.environ.get("GROUP_LAYERS_MAX", 12))
+    shapes = [(768, 3072), (3072, 768), (768, 768), (2304, 768)]
+    ops = [[(torch.randn(M, N, device=dev).bfloat16(), torch.randn(M, K, device=dev).bfloat16(), torch.zeros(N, K, device=dev)) for N, K in shapes] for _ in range(L)]
+    for layers in [g for g in (12, 6, 4, 3, 2, 1) if g <= L]:
+        flat = [o for lay in ops[:layers] for o in lay]
+        rec = np.zeros(len(flat), dtype=[("A", "<u8"), ("B", "<u8"), ("C", "<u8"), ("dbias", "<u8"), ("lda", "<i8"), ("ldb", "<i8"), ("ldc", "<i8"),
+                                         ("M", "<i4"), ("N", "<i4"), ("K", "<i4"), ("reserved", "<i4")])
+        for r, (dY, X, C) in zip(rec, flat):
+            r["A"], r["B"], r["C"], r["lda"], r["ldb"], r["ldc"], r["M"], r["N"], r["K"] = dY.data_ptr(), X.data_ptr(), C.data_ptr(), dY.shape[1], X.shape[1], X.shape[1], M, dY.shape[1], X.shape[1]
+        nwg = int(os.environ.get("NWG", 256))
+        Ms, Ns, Ks = (np.ascontiguousarray(rec[f], dtype=np.int32) for f in ("M", "N", "K"))
+        cap = int(sum((n // 256) * (k // 256) for n, k in zip(Ns, Ks))) + nwg + 1
+        items, first = np.zeros((cap, 8), dtype=np.int32), np.zeros(nwg + 1, dtype=np.int32)
+        n = _lib.load().climb_tn_grouped_plan(len(flat), Ms.ctypes.data, Ns.ctypes.data, Ks.ctypes.data, nwg, items.ctypes.data, cap, first.ctypes.data)
+        d = [torch.from_numpy(rec.view(np.uint8).copy()).to(dev), torch.from_numpy(items[:n].copy()).to(dev), torch.from_numpy(first).to(dev)]
+        t = timeit(lambda: _lib.call("climb_gemm_bf16_tn_grouped", d[0], d[1], d[2], nwg, st()), iters=10)
+        f = sum(2.0 * M * N * K for N, K in shapes) * layers
+        print(f"TN grouped, {layers:2d} layers per launch ({n} items, {int((items[:n, 5] == 1).sum())} partial): {t*1e6/layers:8.1f} us/layer  {f/t/1e12:7.1f} TF")
