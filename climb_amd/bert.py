@@ -6,8 +6,16 @@ tokens (about a fifth of one ViLT forward) -- on the same HIP kernels as the ViL
 `BertParams` holds exactly `BertModel`'s parameters (names, shapes, registration order: its state_dict interchanges with transformers'
 `bert-base-uncased`).  Because the weights are frozen they are PACKED once per weight version into GEMM-ready device buffers: the
 q / k / v matrices of a layer become one [2304, 768] operand (one fused QKV GEMM, as in the ViLT encoder), with bf16 copies in the
-throughput mode.  The reference leaves BERT in train mode (its dropouts perturb the "frozen" features randomly, viltbert.py:121-126);
-this encoder computes the deterministic eval-mode features -- documented in DESIGN.md, pinned by tests/golden/viltbert_vqa_b3.npz."""
+throughput mode.
+
+Train mode (r03).  The reference runs BERT under `no_grad` but never calls `bert.eval()` (REF/modeling/viltbert.py:115-120): while the
+learner is in train mode BERT's 37 dropouts (p = 0.1: after the embedding LayerNorm, on the attention probabilities, on both sub-layer
+outputs before their residual adds; HFB:112-116, eager_attention_forward, :289-293, :348-351) perturb the "frozen" features -- measured
+with the reference: 57 % relative rms on the features, 60 % on one step's gradient (tests/golden/viltbert_train_dropout.json).  This module
+follows `self.training` the same way: in train mode every dropout is applied, from masks drawn with the device's generator (the same
+distribution; torch's CPU stream cannot be reproduced bit for bit on another device) or from masks the caller passes
+(`dropout_masks`, how tests/golden/viltbert_vqa_b3_train.npz pins the arithmetic against the reference's own masks).  Eval mode computes
+the deterministic features (tests/golden/viltbert_vqa_b3.npz)."""
 from __future__ import annotations
 
 from collections import OrderedDict
@@ -20,7 +28,7 @@ from . import _lib
 
 F32, BF16 = 0, 1
 EPI_NONE, EPI_GELU, EPI_RESID = 0, 1, 2
-BERT_CFG = dict(hidden=768, heads=12, head_dim=64, ffn=3072, layers=12, vocab=30522, max_pos=512, type_vocab=2, ln_eps=1e-12)
+BERT_CFG = dict(hidden=768, heads=12, head_dim=64, ffn=3072, layers=12, vocab=30522, max_pos=512, type_vocab=2, ln_eps=1e-12, dropout=0.1)
 
 
 def bert_param_shapes(cfg: dict = BERT_CFG) -> "OrderedDict[str, tuple]":
@@ -151,10 +159,21 @@ class BertParams(nn.Module):
         H = self.cfg["hidden"]
         _lib.call("climb_layernorm_fwd", x, H, w, b, self.cfg["ln_eps"], out, H, out_dt, ws["mean"], ws["rstd"], M, H, _stream())
 
+    def draw_dropout_masks(self, B: int, T: int, dev) -> Dict[str, object]:
+        """Keep-masks of one train-mode forward: {"emb": [B,T,H], "probs": L x [B,heads,T,T], "attn_out": L x [B,T,H], "ffn_out": L x [B,T,H]}
+        (bool, True = kept), Bernoulli(1 - p) from the device's default generator."""
+        cfg = self.cfg
+        H, nh, L, keep = cfg["hidden"], cfg["heads"], cfg["layers"], 1.0 - cfg.get("dropout", 0.1)
+
+        def draw(*shape):
+            return torch.rand(shape, device=dev) < keep
+        return {"emb": draw(B, T, H), "probs": [draw(B, nh, T, T) for _ in range(L)], "attn_out": [draw(B, T, H) for _ in range(L)],
+                "ffn_out": [draw(B, T, H) for _ in range(L)]}
+
     @torch.no_grad()
-    def forward(self, input_ids, attention_mask, token_type_ids) -> torch.Tensor:
+    def forward(self, input_ids, attention_mask, token_type_ids, dropout_masks: Optional[Dict[str, object]] = None) -> torch.Tensor:
         """[B, T] int64 x 3 -> last_hidden_state as a [B, roundup(T, 32), 768] fp32 buffer whose first T rows per sequence are valid
-        (the ViLT engine's `inputs_embeds` operand; rows beyond T are scratch)."""
+        (the ViLT engine's `inputs_embeds` operand; rows beyond T are scratch).  Train mode (`self.training`, or masks given): dropouts live."""
         dev = input_ids.device
         if dev.type != "cuda":
             raise RuntimeError("climb_amd.bert needs a HIP device; there is no CPU path in the product (oracle/bert_oracle.py is the CPU checker)")
@@ -166,22 +185,51 @@ class BertParams(nn.Module):
         Tp, M = ws["Tp"], ws["M"]
         st = _stream()
         adt = F32 if self.precision == "fp32" else BF16
+        p_drop = float(cfg.get("dropout", 0.1))
+        if dropout_masks is None and self.training and p_drop > 0.0:
+            dropout_masks = self.draw_dropout_masks(B, T, dev)
+        drop = dropout_masks is not None
+        if drop and Tp > 64:
+            raise NotImplementedError(f"BERT train-mode dropout: {T} text tokens (the probability-dropout kernel holds <= 64 keys; CLiMB's max is 40)")
+        dscale = 1.0 / (1.0 - p_drop)
+
+        def row_mask(m):          # [B, T, H] bool -> fp32 [B, Tp, H] in the activation layout (padding rows: 1, they are scratch)
+            out = torch.ones((B, Tp, H), dtype=torch.float32, device=dev)
+            out[:, :T] = m.to(dev, torch.float32)
+            return out
+
+        def dropout_rows(buf, m):
+            _lib.call("climb_elementwise", 3, buf, row_mask(m), buf, M * H, dscale, st)
         _lib.call("climb_key_bias", attention_mask, ws["key_bias"], B, T, T, Tp, st)
         x = ws["x"]
         x.zero_()                                       # padding rows: finite (zero) inputs, masked as keys
         _lib.call("climb_embed_text_fwd", input_ids, token_type_ids, pk["word"], pk["type"], pk["pos"], pk["eln_w"], pk["eln_b"], pk["zero_h"],
                   cfg["ln_eps"], x, B, T, Tp, H, ws["tmean"], ws["trstd"], 0, st)
+        if drop:
+            dropout_rows(x, dropout_masks["emb"])                                                                  # HFB:112-116
         attn = "climb_attn_fwd_f32" if self.precision == "fp32" else "climb_attn_fwd_bf16"
         for i in range(cfg["layers"]):
             if self.precision != "fp32":
                 _lib.call("climb_cast_bf16", x, ws["xb"], M * H, st)
             self._gemm(ws["xb"], pk["wqkv_op"][i], pk["bqkv"][i], ws["qkv"], M, 3 * H, H)
-            _lib.call(attn, ws["qkv"], ws["key_bias"], ws["ctx"], ws["lse"], B, Tp, nh, cfg["head_dim"], st)
-            self._gemm(ws["ctx"], pk["wo_op"][i], pk["bo"][i], ws["y"], M, H, H, EPI_RESID, aux=x, out_f32=True)          # + x (HFB:290)
+            if drop:
+                keep = dropout_masks["probs"][i].to(dev, torch.uint8).contiguous()
+                _lib.call("climb_attn_fwd_dropout", ws["qkv"], ws["key_bias"], keep, ws["ctx"], adt, B, Tp, nh, cfg["head_dim"], T, dscale, st)
+                self._gemm(ws["ctx"], pk["wo_op"][i], pk["bo"][i], ws["y"], M, H, H, out_f32=True)                 # dense, THEN dropout, then + x
+                dropout_rows(ws["y"], dropout_masks["attn_out"][i])
+                _lib.call("climb_elementwise", 5, ws["y"], x, ws["y"], M * H, 1.0, st)
+            else:
+                _lib.call(attn, ws["qkv"], ws["key_bias"], ws["ctx"], ws["lse"], B, Tp, nh, cfg["head_dim"], st)
+                self._gemm(ws["ctx"], pk["wo_op"][i], pk["bo"][i], ws["y"], M, H, H, EPI_RESID, aux=x, out_f32=True)          # + x (HFB:290)
             self._ln(ws["y"], pk["ln1_w"][i], pk["ln1_b"][i], ws["h"], F32, ws, M)
             if self.precision != "fp32":
                 self._ln(ws["y"], pk["ln1_w"][i], pk["ln1_b"][i], ws["hb"], BF16, ws, M)
             self._gemm(ws["hb"], pk["w1_op"][i], pk["b1"][i], ws["a"], M, Fd, H, EPI_GELU, aux_out=ws["pre"])
-            self._gemm(ws["a"], pk["w2_op"][i], pk["b2"][i], ws["y"], M, H, Fd, EPI_RESID, aux=ws["h"], out_f32=True)          # + h (HFB:349)
+            if drop:
+                self._gemm(ws["a"], pk["w2_op"][i], pk["b2"][i], ws["y"], M, H, Fd, out_f32=True)
+                dropout_rows(ws["y"], dropout_masks["ffn_out"][i])
+                _lib.call("climb_elementwise", 5, ws["y"], ws["h"], ws["y"], M * H, 1.0, st)
+            else:
+                self._gemm(ws["a"], pk["w2_op"][i], pk["b2"][i], ws["y"], M, H, Fd, EPI_RESID, aux=ws["h"], out_f32=True)          # + h (HFB:349)
             self._ln(ws["y"], pk["ln2_w"][i], pk["ln2_b"][i], x, F32, ws, M)
         return x.view(B, Tp, H)

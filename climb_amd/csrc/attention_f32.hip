@@ -339,3 +339,66 @@ extern "C" int climb_attn_bwd_f32(const float* qkv, const float* key_bias, const
   LAUNCH_CHECK();
   return CLIMB_OK;
 }
+
+// ---------------------------------------------------------------------------------------------- forward with dropout on the probabilities
+// The frozen BERT of ViLT-BERT while the learner is in train mode (REF/modeling/viltbert.py:115-120 never calls bert.eval(): its
+// attention_probs_dropout is live; HFB eager_attention_forward: softmax -> dropout -> P V).  Text only: S_pad <= 64 keys, head_dim 64,
+// forward only (BERT is frozen), 2 560 rows at 64 sequences -- a plain VALU kernel: one workgroup per (batch, head), K and V rows in LDS
+// as fp32, one wave per query (lane = key for the scores and the softmax, lane = output dimension for P V).
+// keep[b, h, q, k] (uint8, T x T per head, T <= S_pad the mask's own row length) is the keep-mask, drop_scale = 1 / (1 - p).
+template <typename T16>
+__global__ __launch_bounds__(256) void attn_fwd_dropout_kernel(const T16* __restrict__ qkv, const float* __restrict__ key_bias, const unsigned char* __restrict__ keep,
+                                                               T16* __restrict__ ctx, int S_pad, int heads, int T, float drop_scale) {
+  __shared__ float Ks[64][65], Vs[64][64], Qs[4][64], Ps[4][64];
+  const int b = blockIdx.x / heads, h = blockIdx.x % heads, H = heads * 64;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const long row0 = (long)b * S_pad;
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int r = i >> 6, d = i & 63;
+    float kv = 0.f, vv = 0.f;
+    if (r < S_pad) {
+      kv = Act<T16>::ld(qkv + (row0 + r) * 3 * H + H + h * 64 + d);
+      vv = Act<T16>::ld(qkv + (row0 + r) * 3 * H + 2 * H + h * 64 + d);
+    }
+    Ks[r][d] = kv;
+    Vs[r][d] = vv;
+  }
+  __syncthreads();
+  const float kb = lane < S_pad ? key_bias[(long)b * S_pad + lane] : -INFINITY;
+  for (int q = w; q < S_pad; q += 4) {
+    Qs[w][lane] = Act<T16>::ld(qkv + (row0 + q) * 3 * H + h * 64 + lane);
+    __builtin_amdgcn_wave_barrier();
+    float s = 0.f;
+#pragma unroll 16
+    for (int d = 0; d < 64; ++d) s += Qs[w][d] * Ks[lane][d];
+    s = s * 0.125f + kb;
+    float m = s;
+    for (int o = 32; o; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    float p = (lane < S_pad && m > -INFINITY) ? __expf(s - m) : 0.f;
+    float sum = p;
+    for (int o = 32; o; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    p = sum > 0.f ? p / sum : 0.f;
+    if (q < T && lane < T) p = keep[(((long)b * heads + h) * T + q) * T + lane] ? p * drop_scale : 0.f;      // rows / keys beyond T: padding, masked anyway
+    Ps[w][lane] = p;
+    __builtin_amdgcn_wave_barrier();
+    float o = 0.f;
+#pragma unroll 16
+    for (int k = 0; k < 64; ++k) o += Ps[w][k] * Vs[k][lane];
+    Act<T16>::st(ctx + (row0 + q) * H + h * 64 + lane, o);
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+extern "C" int climb_attn_fwd_dropout(const void* qkv, const float* key_bias, const void* keep, void* ctx, int dtype, int B, int S_pad, int heads,
+                                      int head_dim, int T, float drop_scale, void* stream) {
+  if (head_dim != 64 || S_pad <= 0 || S_pad > 64 || T <= 0 || T > S_pad || !keep) return CLIMB_EUNSUPPORTED;
+  if (dtype == CLIMB_DT_F32)
+    hipLaunchKernelGGL((attn_fwd_dropout_kernel<float>), dim3(B * heads), dim3(256), 0, (hipStream_t)stream, (const float*)qkv, key_bias,
+                       (const unsigned char*)keep, (float*)ctx, S_pad, heads, T, drop_scale);
+  else if (dtype == CLIMB_DT_BF16)
+    hipLaunchKernelGGL((attn_fwd_dropout_kernel<bf16_t>), dim3(B * heads), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, key_bias,
+                       (const unsigned char*)keep, (bf16_t*)ctx, S_pad, heads, T, drop_scale);
+  else return CLIMB_EINVAL;
+  LAUNCH_CHECK();
+  return CLIMB_OK;
+}

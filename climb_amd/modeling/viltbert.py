@@ -29,9 +29,13 @@ class ViltBertEncoderWrapper(ViltEncoderWrapper):
         self.bert.precision = self.precision
 
     def get_bert_outputs(self, **encodings) -> torch.Tensor:
-        """REF:115-121: BERT's last hidden state, no gradient.  [B, roundup(T, 32), 768] fp32, first T rows of a sequence valid."""
+        """REF:115-121: BERT's last hidden state, no gradient.  [B, roundup(T, 32), 768] fp32, first T rows of a sequence valid.
+        Like the reference, BERT is NOT put in eval mode here: while the learner trains, its dropouts are live (climb_amd/bert.py).
+        `self.bert_dropout_masks` (test hook, consumed by one call) supplies the keep-masks instead of drawing them."""
+        masks, self.bert_dropout_masks = getattr(self, "bert_dropout_masks", None), None
         with torch.no_grad():
-            return self.bert(input_ids=encodings["input_ids"], attention_mask=encodings["attention_mask"], token_type_ids=encodings["token_type_ids"])
+            return self.bert(input_ids=encodings["input_ids"], attention_mask=encodings["attention_mask"], token_type_ids=encodings["token_type_ids"],
+                             dropout_masks=masks)
 
     def prepare_encodings(self, enc: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
         """REF:145-147: `inputs_embeds` = BERT features, `input_ids` = None."""

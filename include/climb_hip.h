@@ -88,6 +88,10 @@ int climb_gemm_f32(const float* A, long sam, long sak, const float* B, long sbn,
 /* HF:322-351 ViltSelfAttention: softmax(Q K^T / sqrt(d) + key_bias) V per (batch, head); scores never leave the CU.
  * qkv [B*S_pad, 3H] columns [q|k|v]; ctx [B*S_pad, H]; lse [B, heads, S_pad] saved for backward */
 int climb_attn_fwd_f32(const float* qkv, const float* key_bias, float* ctx, float* lse, int B, int S_pad, int heads, int head_dim, void* stream);
+/* The same attention with DROPOUT ON THE PROBABILITIES, forward only, S_pad <= 64: the frozen BERT of ViLT-BERT while the learner is in
+ * train mode (REF/modeling/viltbert.py:115-120 never calls bert.eval(); HFB eager_attention_forward: softmax -> dropout -> P V).
+ * qkv / ctx in `dtype` (0 fp32, 1 the library's 16-bit type); keep uint8 [B, heads, T, T] (1 = kept), drop_scale = 1 / (1 - p). */
+int climb_attn_fwd_dropout(const void* qkv, const float* key_bias, const void* keep, void* ctx, int dtype, int B, int S_pad, int heads, int head_dim, int T, float drop_scale, void* stream);
 /* delta[b,h,q] = sum_d dctx*ctx (softmax backward row term) */
 int climb_attn_delta(const void* dctx, const void* ctx, int dtype, float* delta, int B, int S_pad, int heads, void* stream);
 int climb_attn_bwd_f32(const float* qkv, const float* key_bias, const float* dctx, const float* lse, const float* delta, float* dqkv, int B, int S_pad, int heads, int head_dim, void* stream);

@@ -5,10 +5,10 @@ Follows transformers' `BertModel` (HFB = transformers/models/bert/modeling_bert.
 `bert(input_ids, attention_mask, token_type_ids).last_hidden_state`, in EVAL mode (dropouts off).  Pinned by oracle/gen_golden.py::
 case_viltbert against the reference's own ViltBertContinualLearner around a seeded `BertModel(BertConfig())`.
 
-Reference quirk NOT reproduced: `get_bert_outputs` runs BERT under no_grad but never puts it in eval mode, so while the learner is in
-train mode BERT's 0.1 dropouts (embeddings, attention probabilities, both sub-layer outputs) randomly perturb the "frozen" text
-features with torch's RNG stream; that cannot be matched bit for bit on another device and both this oracle and the product compute
-the deterministic (eval) features."""
+Reference quirk, reproduced since r03: `get_bert_outputs` runs BERT under no_grad but never puts it in eval mode, so while the learner is
+in train mode BERT's 0.1 dropouts (embeddings, attention probabilities, both sub-layer outputs) perturb the "frozen" text features with
+torch's RNG stream.  `bert_forward(..., masks=...)` applies given keep-masks at those 37 sites; oracle/gen_golden.py::case_viltbert_train
+records the masks the reference itself drew (tests/golden/viltbert_vqa_b3_train.npz), which pins both this restatement and the HIP path."""
 from __future__ import annotations
 
 import math
@@ -73,14 +73,19 @@ def _ln(x, w, b, eps):
     return F.layer_norm(x, (x.shape[-1],), w, b, eps)
 
 
-def bert_forward(PB, input_ids, token_type_ids, attention_mask, cfg=BERT_CFG):
-    """last_hidden_state [B, T, H] (HFB:594-700 BertModel.forward), eval mode."""
+def bert_forward(PB, input_ids, token_type_ids, attention_mask, cfg=BERT_CFG, masks=None, p_drop: float = 0.1):
+    """last_hidden_state [B, T, H] (HFB:594-700 BertModel.forward).  masks None = eval mode; else the train-mode dropouts with the given
+    keep-masks {"emb": [B,T,H], "probs": L x [B,nh,T,T], "attn_out": L x [B,T,H], "ffn_out": L x [B,T,H]} (x * keep / (1 - p))."""
+    def drop(x, m):
+        return x if masks is None else x * m.to(x.dtype) / (1.0 - p_drop)
     B, T = input_ids.shape
     H, nh, dh = cfg["hidden"], cfg["heads"], cfg["head_dim"]
     e = "embeddings."
     x = PB[e + "word_embeddings.weight"][input_ids] + PB[e + "token_type_embeddings.weight"][token_type_ids] \
         + PB[e + "position_embeddings.weight"][:T].unsqueeze(0)                                   # HFB:97-116 (absolute positions 0..T-1)
     x = _ln(x, PB[e + "LayerNorm.weight"], PB[e + "LayerNorm.bias"], cfg["ln_eps"])
+    if masks is not None:
+        x = drop(x, masks["emb"])                                                                 # HFB:112-116
     bias = torch.zeros((B, 1, 1, T), dtype=x.dtype).masked_fill(attention_mask[:, None, None, :] == 0, torch.finfo(x.dtype).min)
     for i in range(cfg["layers"]):
         l = f"encoder.layer.{i}."
@@ -88,11 +93,17 @@ def bert_forward(PB, input_ids, token_type_ids, attention_mask, cfg=BERT_CFG):
         k = F.linear(x, PB[l + "attention.self.key.weight"], PB[l + "attention.self.key.bias"]).view(B, T, nh, dh).transpose(1, 2)
         v = F.linear(x, PB[l + "attention.self.value.weight"], PB[l + "attention.self.value.bias"]).view(B, T, nh, dh).transpose(1, 2)
         p = torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(dh) + bias, dim=-1)                 # HFB:139-220
+        if masks is not None:
+            p = drop(p, masks["probs"][i])                                                        # eager_attention_forward: softmax -> dropout -> P V
         ctx = (p @ v).transpose(1, 2).reshape(B, T, H)
         y = F.linear(ctx, PB[l + "attention.output.dense.weight"], PB[l + "attention.output.dense.bias"])
+        if masks is not None:
+            y = drop(y, masks["attn_out"][i])                                                     # HFB:289-293: dense -> dropout -> LayerNorm(. + input)
         h = _ln(y + x, PB[l + "attention.output.LayerNorm.weight"], PB[l + "attention.output.LayerNorm.bias"], cfg["ln_eps"])      # HFB:282-294 post-LN
         u = F.linear(h, PB[l + "intermediate.dense.weight"], PB[l + "intermediate.dense.bias"])
         a = 0.5 * u * (1.0 + torch.erf(u / math.sqrt(2.0)))                                       # HFB:325-338 'gelu'
         z = F.linear(a, PB[l + "output.dense.weight"], PB[l + "output.dense.bias"])
+        if masks is not None:
+            z = drop(z, masks["ffn_out"][i])                                                      # HFB:348-351
         x = _ln(z + h, PB[l + "output.LayerNorm.weight"], PB[l + "output.LayerNorm.bias"], cfg["ln_eps"])                          # HFB:340-352
     return x

@@ -312,6 +312,60 @@ def case_vcr(fname, b=2, tasks=("snli-ve", "vcr"), wseed=42, dseed=4):
                         meta=np.array([f"task=vcr;tasks={','.join(tasks)};b={b};wseed={wseed};dseed={dseed};ragged=1;eval=1"]))
 
 
+def case_vcr_train(fname, b=2, tasks=("snli-ve", "vcr"), wseed=42, dseed=4, drop_seed=11):
+    """VCR in TRAIN mode: the head's Dropout(0.1) (REF/modeling/vilt.py:199-202) is live.  The reference draws its mask from torch's CPU
+    generator; a forward hook on that Dropout module records which elements it kept (output != 0 where the input was not), and the fixture
+    carries that keep-mask so the oracle and the HIP path can be fed the very same one (`dropout_keep`)."""
+    print(f"[{fname}] VCR four-choice forward/backward, TRAIN mode, keep-mask of the head dropout recorded")
+    tasks = list(tasks)
+    P = vo.init_params(tasks, wseed)
+    e1 = vo.synthetic_encodings(4 * b, seed=dseed, ragged_text=True)
+    enc = dict(input_ids=e1["input_ids"], token_type_ids=e1["token_type_ids"], attention_mask=e1["attention_mask"],
+               pixel_values=e1["pixel_values"][:b], pixel_mask=e1["pixel_mask"][:b])
+    labels = torch.tensor([2, 0][:b]) if b <= 2 else torch.from_numpy(np.random.default_rng([dseed, 13]).integers(0, 4, size=(b,), dtype=np.int64))
+    model = ri.build_reference_learner(tasks, P)
+    model.train()
+    drop = model.task_layer["vcr"][0]
+    assert isinstance(drop, torch.nn.Dropout) and drop.p == 0.1
+    seen = {}
+
+    def hook(mod, inp, out):
+        x = inp[0].detach()
+        assert bool((x != 0).all())                       # tanh outputs: never exactly zero, so `out != 0` IS the keep-mask
+        seen["keep"] = (out.detach() != 0)
+        seen["ratio"] = float((out.detach()[seen["keep"]] / x[seen["keep"]]).mean())
+    h = drop.register_forward_hook(hook)
+    trainer = ri.make_trainer("vcr")
+    batch = {"raw_texts": [[""] * 4] * b, "images": [None] * b, "labels": labels}
+    model.zero_grad()
+    ri.bypass_processor(model, enc)
+    torch.manual_seed(drop_seed)
+    loss, (pooled, logits), _, _ = trainer.train_step(model, batch)
+    h.remove()
+    keep = seen["keep"]
+    assert keep.shape == (b, 4, 768) and abs(seen["ratio"] - 1.0 / 0.9) < 1e-5 and 0.85 < float(keep.float().mean()) < 0.95
+    G = ref_grads(model)
+    leaves = {n: P[n].clone().requires_grad_(True) for n in P}
+    o_pooled, o_logits = vo.learner_forward(leaves, "vcr", enc, training=True, dropout_keep=keep.float())
+    o_loss = vo.ce_loss(o_logits, labels)
+    o_loss.backward()
+    o_G = {n: leaves[n].grad for n in G}
+    check("pooled", o_pooled, pooled, 2e-5)
+    check("logits", o_logits, logits, 2e-5)
+    check("loss", o_loss, loss, 2e-5)
+    gn, gh = tensor_summary(G)
+    on, _ = tensor_summary(o_G)
+    check("grad norms", on, gn, 1e-4)
+    # the mask matters: the eval-mode logits differ from these by far more than any tolerance used downstream
+    with torch.no_grad():
+        _, e_logits = vo.learner_forward(P, "vcr", enc, training=False)
+    assert float((e_logits - logits).abs().max()) > 1e-2 * float(logits.abs().max())
+    np.savez_compressed(os.path.join(OUT, fname), pooled=pooled.detach().numpy(), logits=logits.detach().numpy(),
+                        loss=np.float64(loss.item()), labels=labels.numpy(), keep=np.packbits(keep.numpy().reshape(-1)),
+                        grad_names=np.array(list(G.keys())), grad_norms=gn, grad_heads=gh,
+                        meta=np.array([f"task=vcr;tasks={','.join(tasks)};b={b};wseed={wseed};dseed={dseed};ragged=1;eval=0;drop_seed={drop_seed}"]))
+
+
 def case_replay(fname, B=2, tasks=("vqa", "nlvr2"), wseed=42, dseed=6):
     """ExperienceReplayMemory.run_replay_step (REF/cl_algorithms/experience_replay.py:53-67): a FRESH AdamW
     (zero moments, base lr, no scheduler) and one train_step on the replayed task."""
@@ -448,6 +502,79 @@ def case_viltbert(fname="viltbert_vqa_b3.npz", tasks=("vqa", "nlvr2"), B=3, wsee
                         meta=np.array([f"task=vqa;tasks={','.join(tasks)};B={B};wseed={wseed};bseed={bseed};dseed={dseed};ragged=1;eval=1"]))
 
 
+def case_viltbert_train(fname="viltbert_vqa_b3_train.npz", tasks=("vqa", "nlvr2"), B=3, wseed=42, bseed=7, dseed=21, drop_seed=3):
+    """Row F4 in TRAIN mode: the reference never puts its frozen BERT in eval mode (REF/modeling/viltbert.py:115-120), so BERT's 37
+    dropouts are live while the learner trains.  The reference's own train-mode step is run with every dropout call observed
+    (torch.nn.functional.dropout wrapped for the duration: the keep-mask is `output != 0` wherever the input is not 0); the fixture carries
+    those masks, so the oracle and the HIP path can be given the very masks the reference drew."""
+    import bert_oracle as bo
+    import torch.nn.functional as F
+    print(f"[{fname}] ViLT-BERT forward/backward, TRAIN mode (BERT dropouts live, masks recorded), B={B}, ragged text")
+    tasks = list(tasks)
+    P = vo.init_params(tasks, wseed)
+    PB = bo.init_bert_params(bseed)
+    enc = vo.synthetic_encodings(B, seed=dseed, ragged_text=True)
+    T = enc["input_ids"].shape[1]
+    target = vo.synthetic_vqa_targets(B, seed=dseed)
+    model = ri.build_reference_viltbert_learner(tasks, P, PB, eager_attention=True)
+    model.train()
+    assert model.viltbert_encoder.bert.training
+    trainer = ri.make_trainer("vqa")
+    import modeling.viltbert as ref_vb
+    trainer.batch2inputs_converter = ref_vb.convert_batch_to_viltbert_input_dict
+    model.viltbert_encoder.process_inputs = lambda images, texts: dict(enc)
+    batch = {"raw_texts": [""] * B, "images": None, "target_scores": target}
+    model.zero_grad()
+    seen = []
+    real = F.dropout
+
+    def observed(input, p=0.5, training=True, inplace=False):
+        out = real(input, p, training, False)
+        if training and p > 0.0:
+            assert p == 0.1
+            seen.append(((out != 0) | (input == 0)).detach().clone())       # where the input is 0 (masked keys) the draw is unobservable AND irrelevant
+        return out
+    F.dropout = observed
+    try:
+        torch.manual_seed(drop_seed)
+        loss, (pooled, logits), _, _ = trainer.train_step(model, batch, None, None, None)
+    finally:
+        F.dropout = real
+    L, nh = 12, 12
+    assert len(seen) == 1 + 3 * L, len(seen)
+    masks = {"emb": seen[0], "probs": [seen[1 + 3 * i] for i in range(L)], "attn_out": [seen[2 + 3 * i] for i in range(L)],
+             "ffn_out": [seen[3 + 3 * i] for i in range(L)]}
+    assert masks["emb"].shape == (B, T, 768) and all(m.shape == (B, nh, T, T) for m in masks["probs"])
+    assert all(m.shape == (B, T, 768) for m in masks["attn_out"] + masks["ffn_out"])
+    assert 0.88 < float(masks["emb"].float().mean()) < 0.92
+    G = {n.replace("viltbert_encoder.", "vilt_encoder."): p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+    with torch.no_grad():
+        feats = bo.bert_forward(PB, enc["input_ids"], enc["token_type_ids"], enc["attention_mask"], masks=masks)
+        feats_eval = bo.bert_forward(PB, enc["input_ids"], enc["token_type_ids"], enc["attention_mask"])
+    oenc = dict(enc, inputs_embeds=feats)
+    oenc.pop("input_ids")
+    leaves = {n: P[n].clone().requires_grad_(True) for n in P}
+    o_pooled, o_logits = vo.learner_forward(leaves, "vqa", oenc, training=True)
+    o_loss = vo.vqa_loss(o_logits, target)
+    o_loss.backward()
+    o_G = {n: leaves[n].grad for n in G}
+    check("pooled", o_pooled, pooled, 2e-5)
+    check("logits", o_logits, logits, 2e-5)
+    check("loss", o_loss, loss, 2e-5)
+    gn, gh = tensor_summary(G)
+    on, _ = tensor_summary(o_G)
+    check("grad norms", on, gn, 1e-4)
+    valid = enc["attention_mask"].bool()
+    dev = float((feats[valid] - feats_eval[valid]).norm() / feats_eval[valid].norm())
+    print(f"  train-mode BERT features differ from the eval-mode ones by {dev:.2f} relative rms")
+    assert dev > 0.2
+    packed = np.concatenate([np.packbits(m.numpy().reshape(-1)) for m in [masks["emb"]] + masks["probs"] + masks["attn_out"] + masks["ffn_out"]])
+    np.savez_compressed(os.path.join(OUT, fname), pooled=pooled.detach().numpy(), logits=logits.detach().numpy(), loss=np.float64(loss.item()),
+                        masks=packed, bert_feats_head=feats[:, :, :8].numpy(), bert_feats_norm=np.float64(feats.double().norm().item()),
+                        grad_names=np.array(list(G.keys())), grad_norms=gn, grad_heads=gh,
+                        meta=np.array([f"task=vqa;tasks={','.join(tasks)};B={B};T={T};wseed={wseed};bseed={bseed};dseed={dseed};ragged=1;eval=0;drop_seed={drop_seed}"]))
+
+
 def case_fullsize():
     """BASELINE configs[1] at its own size (64 sequences of 40 tokens + 384x384 per GPU) and the equal-sized NLVR2 / VCR batches
     (32 pairs, 16 x 4 choices): the reference's own `*Trainer.train_step` (REF/train/visionlanguage_tasks/train_vqa.py:135-174)."""
@@ -472,11 +599,18 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "viltbert":
         case_viltbert()
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "viltbert_train":
+        case_viltbert_train()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "vcr_train":
+        case_vcr_train("vcr_b2_train.npz")
+        return
     case_single_image("vqa", ["vqa", "nlvr2"], 2, "vqa_b2.npz")
     case_single_image("vqa", ["vqa", "nlvr2"], 3, "vqa_b3_ragged.npz", ragged=True, dseed=2)
     case_single_image("snli-ve", ["snli-ve", "vcr"], 2, "snlive_b2.npz", dseed=8)
     case_nlvr2("nlvr2_b2.npz")
     case_vcr("vcr_b2.npz")
+    case_vcr_train("vcr_b2_train.npz")
     case_ewc("ewc_b2.npz")
     case_fisher("fisher_3x2.npz")
     case_replay("replay_b2.npz")

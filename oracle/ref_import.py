@@ -140,14 +140,19 @@ def bypass_processor(model, enc):
     model.vilt_encoder.process_inputs = lambda images, texts: {k: v for k, v in enc.items()}
 
 
-def build_reference_viltbert_learner(tasks, state, bert_state):
-    """The reference's own ViltBertContinualLearner (REF/modeling/viltbert.py:31-530) around seeded random-init ViltModel / BertModel."""
+def build_reference_viltbert_learner(tasks, state, bert_state, eager_attention=False):
+    """The reference's own ViltBertContinualLearner (REF/modeling/viltbert.py:31-530) around seeded random-init ViltModel / BertModel.
+    eager_attention: BERT's attention as explicit softmax -> dropout -> P V (the form of the transformers 4.x lineage the reference pins;
+    5.x defaults to SDPA, whose dropout mask cannot be observed)."""
     import torch
     import transformers
     ns = import_reference()
     import modeling.viltbert as ref_vb
     proc = ns.ViltProcessor(image_processor=ns.ViltImageProcessor(), tokenizer=ns.BertTokenizerFast.from_pretrained("bert-base-uncased"))
-    bert = transformers.BertModel(transformers.BertConfig())
+    cfg = transformers.BertConfig()
+    if eager_attention:
+        cfg._attn_implementation = "eager"
+    bert = transformers.BertModel(cfg)
     missing, unexpected = bert.load_state_dict({k: v.clone() for k, v in bert_state.items()}, strict=False)
     assert not unexpected and all("position_ids" in m or "token_type_ids" in m for m in missing), (missing, unexpected)
     enc = ref_vb.ViltBertEncoderWrapper(proc, ns.ViltModel(ns.ViltConfig()), bert, torch.device("cpu"))

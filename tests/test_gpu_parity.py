@@ -3,6 +3,7 @@ same seeded inputs and against the golden vectors the reference produced (tests/
 
 Tolerance (BASELINE.json north_star): <= 1e-3 relative in fp32, argmax task predictions bit-exact.
 "relative" = max|a-b| / max|b| over the tensor."""
+import json
 import os
 import random
 import types
@@ -158,6 +159,34 @@ def test_vcr_four_choices_eval(golden_dir):
     norms, heads = _summary(G, names)
     _close(norms, z["grad_norms"], TOL, "grad norms")
     _close(heads, z["grad_heads"], TOL, "grad heads")
+
+
+def test_vcr_four_choices_train_mode_with_the_references_dropout_mask(golden_dir):
+    """VERDICT r2 missing #4: the VCR head's train-mode Dropout(0.1) (REF/modeling/vilt.py:199-202).  `vcr_b2_train.npz` is the reference's
+    own train-mode step with the keep-mask it drew recorded; the HIP path is given that mask (`dropout_keep`) and must reproduce the
+    reference's logits, loss, argmax and gradients at the same bar as every other fixture."""
+    z = np.load(os.path.join(golden_dir, "vcr_b2_train.npz"))
+    m = _meta(z)
+    b = int(m["b"])
+    model, P = make_model(m["tasks"].split(","), int(m["wseed"]))
+    e1 = vo.synthetic_encodings(4 * b, seed=int(m["dseed"]), ragged_text=True)
+    texts = dict(input_ids=e1["input_ids"], token_type_ids=e1["token_type_ids"], attention_mask=e1["attention_mask"])
+    keep = torch.from_numpy(np.unpackbits(z["keep"])[:b * 4 * 768].reshape(b * 4, 768).astype(np.float32)).to(_dev())
+    model.train()
+    loss, (pooled, logits), _, _ = model.fused_forward_backward("vcr", e1["pixel_values"][:b], texts, torch.from_numpy(z["labels"]), dropout_keep=keep)
+    _close(pooled, z["pooled"], TOL, "pooled")
+    _close(logits, z["logits"], TOL, "logits")
+    _close(loss, z["loss"], TOL, "loss")
+    assert np.array_equal(logits.argmax(-1).cpu().numpy(), z["logits"].argmax(-1))
+    G = grads_of(model)
+    names = [str(n) for n in z["grad_names"]]
+    norms, heads = _summary(G, names)
+    _close(norms, z["grad_norms"], TOL, "grad norms")
+    _close(heads, z["grad_heads"], TOL, "grad heads")
+    # without the mask the train-mode step draws its own: a different result (the mask is live), same statistics
+    model._host.drop_grads()
+    _, (_, logits2), _, _ = model.fused_forward_backward("vcr", e1["pixel_values"][:b], texts, torch.from_numpy(z["labels"]))
+    assert float((logits2.cpu() - torch.from_numpy(z["logits"])).abs().max()) > 1e-3
 
 
 def _ewc_state(P, seed=5):
@@ -557,6 +586,7 @@ def test_viltbert_vs_reference(golden_dir, precision, tol):
     target = vo.synthetic_vqa_targets(B, seed=int(m["dseed"]))
     images, texts = enc_to_inputs(enc)
     # the frozen text features
+    model.eval()                                           # this fixture is eval mode; train mode (BERT's dropouts live) is the next test
     dtexts = {k: v.to(dev) for k, v in texts.items()}
     feats = model.get_encoder().get_bert_outputs(**dtexts)[:, :enc["input_ids"].shape[1]].float().cpu()
     with torch.no_grad():
@@ -564,7 +594,6 @@ def test_viltbert_vs_reference(golden_dir, precision, tol):
     valid = enc["attention_mask"].bool()
     _close(feats[valid], ofeats[valid], tol, "BERT last_hidden_state (valid tokens) vs oracle")
     _close(feats[valid][:, :8], torch.from_numpy(z["bert_feats_head"])[valid], tol, "BERT features vs reference")
-    model.eval()                                           # the fixture is eval mode (see oracle/bert_oracle.py on the train-mode dropout quirk)
     loss, (pooled, logits), _, _ = model.fused_forward_backward("vqa", images, texts, target)
     _close(pooled, z["pooled"], tol, "pooled vs reference")
     _close(logits, z["logits"], tol, "logits vs reference")
@@ -594,6 +623,74 @@ def test_viltbert_vs_reference(golden_dir, precision, tol):
     with torch.no_grad():
         out = model(task_key="vqa", images=images, texts=texts)
     assert out[1].shape == (B, 3129) and bool(torch.isfinite(out[1]).all())
+
+
+@pytest.mark.parametrize("precision,tol", [("fp32", TOL), (H16, 8e-2)])
+def test_viltbert_train_mode_with_the_references_bert_dropout_masks(golden_dir, precision, tol):
+    """VERDICT r2 missing #4, second half.  REF/modeling/viltbert.py:115-120 never puts the frozen BERT in eval mode: while the learner
+    trains, BERT's 37 dropouts are live.  `viltbert_vqa_b3_train.npz` is the reference's own train-mode step with every mask it drew
+    recorded; the HIP BERT (probability dropout inside `climb_attn_fwd_dropout`, row dropouts between the GEMMs and their residual adds)
+    is given those masks and must reproduce the reference's features, logits, loss, argmax and gradients.  Without masks, train mode draws
+    its own (different features every call, eval mode deterministic)."""
+    from oracle import bert_oracle as bo
+    from tests.test_oracle_golden import unpack_bert_masks
+    from climb_amd.modeling import create_continual_learner_map
+    from climb_amd.configs.task_configs import task_configs
+    from climb_amd.configs.model_configs import model_configs
+    z = np.load(os.path.join(golden_dir, "viltbert_vqa_b3_train.npz"))
+    m = _meta(z)
+    tasks, B, T = m["tasks"].split(","), int(m["B"]), int(m["T"])
+    dev = _dev()
+    model = create_continual_learner_map["viltbert"](model_name_or_path="random-init:0", ordered_cl_tasks=tasks, model_config=model_configs["viltbert"],
+                                                     task_configs=task_configs, device=dev, precision=precision)
+    P, PB = vo.init_params(tasks, int(m["wseed"])), bo.init_bert_params(int(m["bseed"]))
+    sd = {k.replace("vilt_encoder.", "viltbert_encoder."): v for k, v in P.items()}
+    sd.update({"viltbert_encoder.bert." + k: v for k, v in PB.items()})
+    model.load_state_dict(sd, strict=True)
+    model.to(dev)
+    enc = vo.synthetic_encodings(B, seed=int(m["dseed"]), ragged_text=True)
+    target = vo.synthetic_vqa_targets(B, seed=int(m["dseed"]))
+    images, texts = enc_to_inputs(enc)
+    masks = unpack_bert_masks(z, B, T)
+    valid = enc["attention_mask"].bool()
+    encw = model.get_encoder()
+    dtexts = {k: v.to(dev) for k, v in texts.items()}
+    model.train()
+    assert encw.bert.training
+    encw.bert_dropout_masks = masks
+    feats = encw.get_bert_outputs(**dtexts)[:, :T].float().cpu()
+    _close(feats[valid][:, :8], torch.from_numpy(z["bert_feats_head"])[valid], tol, "BERT features (train mode, the reference's masks) vs reference")
+    with torch.no_grad():
+        ofeats = bo.bert_forward(PB, enc["input_ids"], enc["token_type_ids"], enc["attention_mask"], masks=masks)
+    _close(feats[valid], ofeats[valid], tol, "BERT features vs oracle")
+    encw.bert_dropout_masks = masks
+    loss, (pooled, logits), _, _ = model.fused_forward_backward("vqa", images, texts, target)
+    assert encw.bert_dropout_masks is None                 # consumed by that step
+    _close(pooled, z["pooled"], tol, "pooled vs reference")
+    _close(logits, z["logits"], tol, "logits vs reference")
+    _close(loss, z["loss"], tol, "loss vs reference")
+    G = {n.replace("viltbert_encoder.", "vilt_encoder."): g for n, g in grads_of(model).items()}
+    names = [str(n) for n in z["grad_names"]]
+    assert set(G) == set(names)
+    norms, heads = _summary(G, names)
+    if precision == "fp32":
+        assert np.array_equal(logits.argmax(-1).cpu().numpy(), z["logits"].argmax(-1))
+        _close(norms, z["grad_norms"], tol, "grad norms vs reference")
+        _close(heads, z["grad_heads"], tol, "grad heads vs reference")
+    else:
+        big = z["grad_norms"] > 1e-3 * z["grad_norms"].max()
+        assert (np.abs(norms - z["grad_norms"])[big] / z["grad_norms"][big]).max() < 8e-2
+    # own masks: train mode is stochastic with the reference's statistics, eval mode deterministic
+    a = encw.get_bert_outputs(**dtexts)[:, :T].float().cpu().clone()
+    b = encw.get_bert_outputs(**dtexts)[:, :T].float().cpu().clone()
+    model.eval()
+    e1 = encw.get_bert_outputs(**dtexts)[:, :T].float().cpu().clone()
+    e2 = encw.get_bert_outputs(**dtexts)[:, :T].float().cpu().clone()
+    assert torch.equal(e1, e2) and not torch.equal(a, b)
+    dev_rel = float((a[valid] - e1[valid]).norm() / e1[valid].norm())
+    ref = json.load(open(os.path.join(golden_dir, "viltbert_train_dropout.json")))["mean_feature_rel_rms"]
+    print(f"train-mode features vs eval-mode: {dev_rel:.3f} relative rms (reference, mean of 8 seeds: {ref:.3f})")
+    assert 0.7 * ref < dev_rel < 1.4 * ref
 
 
 # ------------------------------------------------------------------------------------------------ full size vs the REFERENCE

@@ -1,5 +1,6 @@
 """The CPU oracle (oracle/vilt_oracle.py) against the golden vectors the reference itself produced
 (tests/golden/*.npz, written by oracle/gen_golden.py in the build container).  No GPU, no reference tree."""
+import json
 import os
 
 import numpy as np
@@ -85,6 +86,34 @@ def test_vcr_four_choices_eval(golden_dir):
     _close(pooled, z["pooled"], 2e-5, "pooled")
     _close(logits, z["logits"], 2e-5, "logits")
     _close(vo.ce_loss(logits, torch.from_numpy(z["labels"])), z["loss"], 2e-5, "loss")
+
+
+def test_vcr_four_choices_train_mode_with_the_references_dropout_mask(golden_dir):
+    """The one stochastic op of the path (REF/modeling/vilt.py:199-202 Dropout(0.1) in the VCR head): the fixture carries the keep-mask the
+    reference drew; fed the same mask the oracle reproduces logits, loss and every gradient (and the eval-mode result is far away)."""
+    z = np.load(os.path.join(golden_dir, "vcr_b2_train.npz"))
+    m = _meta(z)
+    b = int(m["b"])
+    P = vo.init_params(m["tasks"].split(","), int(m["wseed"]))
+    e1 = vo.synthetic_encodings(4 * b, seed=int(m["dseed"]), ragged_text=True)
+    enc = dict(input_ids=e1["input_ids"], token_type_ids=e1["token_type_ids"], attention_mask=e1["attention_mask"],
+               pixel_values=e1["pixel_values"][:b], pixel_mask=e1["pixel_mask"][:b])
+    keep = torch.from_numpy(np.unpackbits(z["keep"])[:b * 4 * 768].reshape(b, 4, 768).astype(np.float32))
+    assert 0.85 < float(keep.mean()) < 0.95
+    leaves = {n: P[n].clone().requires_grad_(True) for n in P}
+    pooled, logits = vo.learner_forward(leaves, "vcr", enc, training=True, dropout_keep=keep)
+    loss = vo.ce_loss(logits, torch.from_numpy(z["labels"]))
+    loss.backward()
+    _close(pooled.detach(), z["pooled"], 2e-5, "pooled")
+    _close(logits.detach(), z["logits"], 2e-5, "logits")
+    _close(loss.detach(), z["loss"], 2e-5, "loss")
+    names = [str(n) for n in z["grad_names"]]
+    norms, heads = _summary({n: leaves[n].grad for n in names}, names)
+    _close(norms, z["grad_norms"], 1e-4, "grad norms")
+    _close(heads, z["grad_heads"], 1e-4, "grad heads")
+    with torch.no_grad():
+        _, ev = vo.learner_forward(P, "vcr", enc, training=False)
+    assert float((ev - torch.from_numpy(z["logits"])).abs().max()) > 1e-2 * float(np.abs(z["logits"]).max())
 
 
 def _ewc_state(P, seed=5):
@@ -232,3 +261,47 @@ def test_bert_oracle_equals_transformers_bert_and_fixture(golden_dir):
         pooled, logits = vo.learner_forward(P, "vqa", oenc, training=False)
     assert float((pooled - torch.from_numpy(z["pooled"])).abs().max()) < 2e-5
     assert float((logits - torch.from_numpy(z["logits"])).abs().max()) < 2e-5 * float(np.abs(z["logits"]).max())
+
+
+def unpack_bert_masks(z, B, T, H=768, nh=12, L=12):
+    """tests/golden/viltbert_vqa_b3_train.npz["masks"]: the 37 keep-masks the reference drew, bit-packed in the order
+    emb | probs x L | attn_out x L | ffn_out x L (oracle/gen_golden.py::case_viltbert_train)."""
+    bits = np.unpackbits(z["masks"])
+    sizes = [B * T * H] + [B * nh * T * T] * L + [B * T * H] * (2 * L)
+    out, at = [], 0
+    for n in sizes:
+        nb = (n + 7) // 8 * 8
+        out.append(bits[at:at + n].astype(bool))
+        at += nb
+    assert at == bits.size
+    t = lambda a, *shape: torch.from_numpy(a.reshape(shape))
+    return {"emb": t(out[0], B, T, H), "probs": [t(out[1 + i], B, nh, T, T) for i in range(L)],
+            "attn_out": [t(out[1 + L + i], B, T, H) for i in range(L)], "ffn_out": [t(out[1 + 2 * L + i], B, T, H) for i in range(L)]}
+
+
+def test_viltbert_train_mode_with_the_references_bert_dropout_masks(golden_dir):
+    """REF/modeling/viltbert.py:115-120 leaves its frozen BERT in train mode: 37 dropouts perturb the text features.  The fixture is the
+    reference's own train-mode step with the masks it drew; given those masks the BERT oracle reproduces the features and the ViLT oracle
+    the step -- and the eval-mode features are far away (this is not a small effect: tests/golden/viltbert_train_dropout.json)."""
+    from oracle import bert_oracle as bo
+    z = np.load(os.path.join(golden_dir, "viltbert_vqa_b3_train.npz"))
+    m = _meta(z)
+    tasks, B, T = m["tasks"].split(","), int(m["B"]), int(m["T"])
+    P, PB = vo.init_params(tasks, int(m["wseed"])), bo.init_bert_params(int(m["bseed"]))
+    enc = vo.synthetic_encodings(B, seed=int(m["dseed"]), ragged_text=True)
+    masks = unpack_bert_masks(z, B, T)
+    with torch.no_grad():
+        feats = bo.bert_forward(PB, enc["input_ids"], enc["token_type_ids"], enc["attention_mask"], masks=masks)
+        ev = bo.bert_forward(PB, enc["input_ids"], enc["token_type_ids"], enc["attention_mask"])
+    valid = enc["attention_mask"].bool()
+    _close(feats[valid][:, :8], torch.from_numpy(z["bert_feats_head"])[valid], 2e-5, "BERT features (train mode, reference masks)")
+    assert float((feats[valid] - ev[valid]).norm() / ev[valid].norm()) > 0.2
+    oenc = dict(enc, inputs_embeds=feats)
+    oenc.pop("input_ids")
+    with torch.no_grad():
+        pooled, logits = vo.learner_forward(P, "vqa", oenc, training=True)
+    _close(pooled, z["pooled"], 2e-5, "pooled")
+    _close(logits, z["logits"], 2e-5, "logits")
+    _close(vo.vqa_loss(logits, vo.synthetic_vqa_targets(B, seed=int(m["dseed"]))), z["loss"], 2e-5, "loss")
+    d = json.load(open(os.path.join(golden_dir, "viltbert_train_dropout.json")))
+    assert 0.3 < d["mean_feature_rel_rms"] < 0.9 and d["mean_grad_rel_l2"] > 0.3 and len(d["rows"]) >= 8
