@@ -231,6 +231,42 @@ extern "C" int climb_colreduce3(const float* part, long stride, int nblk, float*
   return CLIMB_OK;
 }
 
+// Many {dgamma, dbeta, colsum} triples in ONE launch (r03): the 24 LayerNorm backwards of a step each leave a partial buffer; reducing
+// them one launch at a time was 31 launches of ~6.5 us for ~2 us of work each.  `segs` is a device table (built once per shape by the host):
+// 48-byte records { const float* part; long stride; float* out[3]; int nblk; int ncols }, out_k[c] += sum_b part[b*stride + k*ncols + c]
+// (NULL outputs skipped).  grid = (ceil(max ncols / 32), 3, segments).
+struct ColSeg { const float* part; long stride; float* out[3]; int nblk, ncols; };
+__global__ __launch_bounds__(256) void colreduce_batched_kernel(const ColSeg* __restrict__ segs) {
+  __shared__ float red[8][33];
+  const ColSeg sg = segs[blockIdx.z];
+  const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cx, ncols = sg.ncols, nblk = sg.nblk;
+  float* out = sg.out[blockIdx.y];
+  if (!out || blockIdx.x * 32 >= ncols) return;
+  const float* src = sg.part + (long)blockIdx.y * ncols;
+  const long stride = sg.stride;
+  float s[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) s[u] = 0.f;
+  if (c < ncols) {
+    int b = ry;
+    for (; b + 56 < nblk; b += 64) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s[u] += src[(long)(b + 8 * u) * stride + c];
+    }
+    for (; b < nblk; b += 8) s[0] += src[(long)b * stride + c];
+  }
+  red[ry][cx] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+  __syncthreads();
+  if (ry == 0 && c < ncols) out[c] += ((red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx])) + ((red[4][cx] + red[5][cx]) + (red[6][cx] + red[7][cx]));
+}
+extern "C" int climb_colreduce_batched(const void* segs, int nseg, int max_cols, void* stream) {
+  if (!segs || nseg <= 0 || max_cols <= 0) return CLIMB_EINVAL;
+  hipLaunchKernelGGL(colreduce_batched_kernel, dim3((max_cols + 31) / 32, 3, nseg), dim3(256), 0, (hipStream_t)stream, (const ColSeg*)segs);
+  LAUNCH_CHECK();
+  return CLIMB_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Column sums of a [M,C] activation (bias gradients) -> part[rowblk][C]; optional fp32->TO cast of the input.
 #define CS_ROWS 64

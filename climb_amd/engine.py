@@ -127,6 +127,8 @@ class Workspace:
             self.dy = buf((M, H), adt)
         self.ones = torch.ones((max(B, 8),), dtype=f32, device=dev)
         self.dw_plans = {}           # grouped weight-gradient launches: problem / item tables in HBM, built once per set of GEMMs
+        self.red_plans = {}          # batched column reductions: segment tables in HBM
+        self.part_l = None
         self.dx_c = self.dh_c = self.du_l = self.dqkv_l = None
 
     def ensure_deferred(self, eng: "ViltEngine"):
@@ -141,6 +143,9 @@ class Workspace:
         self.dh_c = [torch.empty((M, H), dtype=t16, device=dev) for _ in range(L)]
         self.du_l = [torch.empty((M, Fd), dtype=t16, device=dev) for _ in range(L)]
         self.dqkv_l = [torch.empty((M, 3 * H), dtype=t16, device=dev) for _ in range(L)]
+        # ... and of the LayerNorm backwards' {dgamma, dbeta, bias} partial column sums: reduced by ONE launch per group instead of one per LayerNorm
+        lnb = _lib.query("climb_layernorm_bwd_rows_per_block")
+        self.part_l = [torch.empty((((M + lnb - 1) // lnb) * 3 * H,), dtype=torch.float32, device=dev) for _ in range(2 * L)]
 
 
 class HeadState:
@@ -613,6 +618,27 @@ class ViltEngine:
         self._timed_call("gemm_bf16_tn", plan["flops"], "climb_gemm_bf16_tn_grouped", plan["probs"], plan["items"], plan["first"], plan["nwg"], _stream())
         pending.clear()
 
+    def _red_flush(self, ws: Workspace, pending: list):
+        """the {dgamma, dbeta, bias} reductions recorded by a group's LayerNorm backwards, as one launch"""
+        if not pending:
+            return
+        import numpy as np
+        rg = self.requires_grad
+        key = tuple((part.data_ptr(), nblk, ncols, tuple(n if (n is not None and rg[n]) else None for n in names)) for part, nblk, ncols, names in pending)
+        plan = ws.red_plans.get(key)
+        if plan is None:
+            rec = np.zeros(len(pending), dtype=[("part", "<u8"), ("stride", "<i8"), ("out", "<u8", (3,)), ("nblk", "<i4"), ("ncols", "<i4")])
+            assert rec.dtype.itemsize == 48
+            for r, (part, nblk, ncols, names) in zip(rec, pending):
+                r["part"], r["stride"], r["nblk"], r["ncols"] = part.data_ptr(), 3 * ncols, nblk, ncols
+                r["out"] = [self.g(n) if (n is not None and rg[n]) else 0 for n in names]
+            plan = dict(segs=torch.from_numpy(rec.view(np.uint8).copy()).to(self.device), n=len(pending), cols=max(p[2] for p in pending))
+            if len(ws.red_plans) >= 16:
+                ws.red_plans.pop(next(iter(ws.red_plans)))
+            ws.red_plans[key] = plan
+        _lib.call("climb_colreduce_batched", plan["segs"], plan["n"], plan["cols"], _stream())
+        pending.clear()
+
     # ------------------------------------------------------------------ encoder backward
     def _trainable_runs(self, lo, hi):
         """maximal runs of TRAINABLE tensors inside the flat range [lo, hi): what a data-parallel reducer has to carry (a frozen base
@@ -685,9 +711,11 @@ class ViltEngine:
         csr = _lib.query("climb_colsum_rows_per_block")
         last = f"{ENC}encoder.layer.{cfg['layers'] - 1}."
         G = self._dw_group_size(ws, ad)          # > 0: weight gradients are recorded per layer and launched per group of G layers
-        pending, group = [], []
+        pending, pending_red, group = [], [], []
         if G:
             ws.ensure_deferred(self)
+        lnpart = (lambda k: ws.part_l[k]) if G else (lambda k: ws.part)          # partial sums of LayerNorm backward k (2 per layer)
+        red3 = (lambda part, *names: pending_red.append((part, nlnb, H, names))) if G else (lambda part, *names: self.reduce3(part, nlnb, H, *names))
         dxc = (lambda i: ws.dx_c[i]) if G else (lambda i: ws.dres_c)          # 16-bit d(x_i) / d(h1_i) / d(u_i) / d(qkv_i): per layer when deferred
         dhc = (lambda i: ws.dh_c[i]) if G else (lambda i: ws.dres_c)
         du_ = (lambda i: ws.du_l[i]) if G else (lambda i: ws.du)
@@ -712,9 +740,8 @@ class ViltEngine:
             self.linear_dx(du, l + "intermediate.dense.weight", ws.dhn, M, Fd, H)
             self.join_side()          # LN backward overwrites d(residual) that dW2 is reading
             _lib.call("climb_layernorm_bwd", ws.dhn, H, adt, ws.h1[i], H, ws.mean2[i], ws.rstd2[i], self.p(l + "layernorm_after.weight"),
-                      ws.dres, H, ws.dres, H, None if self.precision == "fp32" else dhc(i), H, ws.part, M, H, st)
-            self.reduce3(ws.part, nlnb, H, l + "layernorm_after.weight", l + "layernorm_after.bias",
-                         l + "attention.output.dense.bias" if ad is None else None)
+                      ws.dres, H, ws.dres, H, None if self.precision == "fp32" else dhc(i), H, lnpart(2 * i + 1), M, H, st)
+            red3(lnpart(2 * i + 1), l + "layernorm_after.weight", l + "layernorm_after.bias", l + "attention.output.dense.bias" if ad is None else None)
             # attention: h1 = x + Wo ctx + bo
             if ad is None:
                 dy = dhc(i)
@@ -732,9 +759,9 @@ class ViltEngine:
                 self.linear_dx(dqkv, l + "attention.attention.query.weight", ws.dxn, M, 3 * H, H)
                 self.join_side()      # LN backward overwrites d(residual) (read by dWo); next layer overwrites du / dqkv
                 _lib.call("climb_layernorm_bwd", ws.dxn, H, adt, ws.x[i], H, ws.mean1[i], ws.rstd1[i], self.p(l + "layernorm_before.weight"),
-                          ws.dres, H, ws.dres, H, None if self.precision == "fp32" else dxc(i), H, ws.part, M, H, st)
-                self.reduce3(ws.part, nlnb, H, l + "layernorm_before.weight", l + "layernorm_before.bias",
-                             f"{ENC}encoder.layer.{i - 1}.output.dense.bias" if (i > first_layer and ad is None) else None)
+                          ws.dres, H, ws.dres, H, None if self.precision == "fp32" else dxc(i), H, lnpart(2 * i), M, H, st)
+                red3(lnpart(2 * i), l + "layernorm_before.weight", l + "layernorm_before.bias",
+                     f"{ENC}encoder.layer.{i - 1}.output.dense.bias" if (i > first_layer and ad is None) else None)
             self.join_side()
             if not G:
                 self._ready(*lay.layer_range[i])
@@ -743,6 +770,7 @@ class ViltEngine:
             last_group = i == first_layer
             if len(group) >= G and not last_group:
                 self._dw_flush(ws, pending)
+                self._red_flush(ws, pending_red)
                 for j in group:
                     self._ready(*lay.layer_range[j])
                 group = []
@@ -751,6 +779,7 @@ class ViltEngine:
             self.embedding_backward(ws, sv, pending if G else None)          # the patch projection's dW rides in the last group
         if G:
             self._dw_flush(ws, pending)
+            self._red_flush(ws, pending_red)
             for j in group:
                 self._ready(*lay.layer_range[j])
         if do_emb:

@@ -72,6 +72,9 @@ int climb_layernorm_bwd_rows_per_block(void);
 int climb_colreduce(const float* part, long stride, int nblk, float* out, int ncols, float beta, void* stream);
 /* the {dgamma, dbeta, colsum} triple in ONE launch: out_k[c] = beta*out_k[c] + sum_b part[b*stride + k*ncols + c]; NULL outputs skipped */
 int climb_colreduce3(const float* part, long stride, int nblk, float* out0, float* out1, float* out2, int ncols, float beta, void* stream);
+/* many such triples in ONE launch (r03: the LayerNorm backwards of a whole group of layers): `segs` = device array of 48-byte records
+ * { const float* part; long stride; float* out[3] (NULL = skip); int nblk; int ncols }: out_k[c] += sum_b part[b*stride + k*ncols + c] */
+int climb_colreduce_batched(const void* segs, int nseg, int max_cols, void* stream);
 /* bias gradients: part[ceil(M/64)][C] column sums of x (optionally also writes a bf16 cast of an fp32 x) */
 int climb_colsum(const void* x, long ldx, int in_dtype, void* cast_bf16, long ldc, float* part, int M, int C, void* stream);
 int climb_colsum_rows_per_block(void);

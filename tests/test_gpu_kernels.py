@@ -195,6 +195,33 @@ def test_gemm_bf16_tn_persistent_tiles(M, N, K):
             assert _rel(out[mode][1], db0.double().cpu() + dY.double().cpu().sum(0)) < 1e-5
 
 
+def test_colreduce_batched_matches_single_reductions():
+    """r03: the {dgamma, dbeta, bias} reductions of a group of LayerNorm backwards as one launch == one climb_colreduce3 per LayerNorm
+    (bit for bit: same summation tree), accumulating into existing values, NULL outputs skipped, segments of different sizes."""
+    from climb_amd import _lib
+    dev = _dev()
+    g = torch.Generator(device=dev).manual_seed(9)
+    segs = [(768, 768, (True, True, True)), (768, 768, (True, True, False)), (96, 1536, (True, False, True)), (5, 40, (False, True, True))]
+    parts = [torch.randn(nblk * 3 * nc, device=dev, generator=g) for nblk, nc, _ in segs]
+    outs0 = [[torch.randn(nc, device=dev, generator=g) if w else None for w in want] for _, nc, want in segs]
+    ref = [[o.clone() if o is not None else None for o in oo] for oo in outs0]
+    for (nblk, nc, _), part, oo in zip(segs, parts, ref):
+        _lib.call("climb_colreduce3", part, 3 * nc, nblk, oo[0], oo[1], oo[2], nc, 1.0, _st())
+    got = [[o.clone() if o is not None else None for o in oo] for oo in outs0]
+    rec = np.zeros(len(segs), dtype=[("part", "<u8"), ("stride", "<i8"), ("out", "<u8", (3,)), ("nblk", "<i4"), ("ncols", "<i4")])
+    for r, (nblk, nc, _), part, oo in zip(rec, segs, parts, got):
+        r["part"], r["stride"], r["nblk"], r["ncols"] = part.data_ptr(), 3 * nc, nblk, nc
+        r["out"] = [o.data_ptr() if o is not None else 0 for o in oo]
+    d = torch.from_numpy(rec.view(np.uint8).copy()).to(dev)
+    _lib.call("climb_colreduce_batched", d, len(segs), 1536, _st())
+    torch.cuda.synchronize()
+    for a, b in zip(got, ref):
+        for x, y in zip(a, b):
+            assert (x is None) == (y is None)
+            if x is not None:
+                assert torch.equal(x, y)
+
+
 @pytest.mark.parametrize("nwg", [256, 8, 24])
 def test_gemm_bf16_tn_grouped_launch(nwg):
     """The grouped weight-gradient launch (r03: several dW GEMMs in one persistent kernel, whole tiles reduce over all tokens and
