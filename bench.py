@@ -166,7 +166,8 @@ def main():
         traffic = None
         try:        # HBM bytes per launch from the committed PMC passes (rocprofv3 cannot be driven from inside the timed run);
             # the file names the hash of the kernel sources it was measured on: a stale figure is reported as null, not repeated
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
+            import glob
+            tj = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_traffic.json")))[-1]))      # the latest round's passes
             if tj.get("csrc_sha16") == csrc_hash() and args.precision in ("bf16", "fp16") and B == 64:
                 traffic = tj[dominant]["hbm_bytes_per_launch"]
         except Exception:
@@ -222,14 +223,17 @@ def fp16_operand_line(args):
         return {"error": repr(e)[:200]}
 
 
+NT_SOURCES = ("common.h", "gemm_bf16.hip", "gemm_bf16_nt.h", "gemm_bf16_nt2p.hip", "gemm_bf16_ntp.hip", "gemm_bf16_phase.h")
+
+
 def csrc_hash():
-    """sha256 over the kernel sources: the key profiles/rNN_traffic.json is valid for"""
+    """sha256 over the sources of the kernel family `roofline` is about (the bf16 NT GEMMs): the key profiles/rNN_traffic.json is valid for.
+    Written ONLY by tools/summarize_profile.py, next to the PMC tables it summarises; edits to other kernels do not touch it."""
     import hashlib
     d = os.path.join(ROOT, "climb_amd", "csrc")
     h = hashlib.sha256()
-    for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".h")):
-            h.update(open(os.path.join(d, f), "rb").read())
+    for f in NT_SOURCES:
+        h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
 
 

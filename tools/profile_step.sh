@@ -1,7 +1,7 @@
 #!/bin/bash
 # rocprofv3 passes behind profiles/rNN_*: bash tools/profile_step.sh r02      (GPU box; writes gpurun_out/prof_<tag>/...)
 # separate passes: kernel-trace stats | PMC FETCH_SIZE | PMC WRITE_SIZE | PMC MFMA / wave-cycle counters  (never PMC together with traces other than kernel-trace)
-TAG=${1:-r02}
+TAG=${1:-r03}
 cd /tmp && export TMPDIR=/tmp
 R=/root/repo
 O=$R/gpurun_out/prof_$TAG

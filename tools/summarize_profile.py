@@ -10,7 +10,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(ROOT, "profiles")
 
@@ -71,7 +71,7 @@ ld, _ = read_counters("pmc_lds")
 with open(os.path.join(dst, f"{tag}_gemm_bf16_pmc_summary.csv"), "w") as f:
     f.write("kernel,launches,avg_duration_us_under_pmc,SQ_VALU_MFMA_BUSY_CYCLES,SQ_BUSY_CYCLES,SQ_WAVE_CYCLES,SQ_LDS_BANK_CONFLICT,SQ_LDS_IDX_ACTIVE,SQ_WAIT_INST_ANY,mfma_util_est\n")
     for k in sorted(mf):
-        if "gemm_bf16" not in k and "attn" not in k:
+        if "gemm_bf16" not in k and "attn" not in k and "tn_grouped" not in k:
             continue
         def avg(tab, c):
             v = list(tab.get(k, {}).get(c, {}).values())
