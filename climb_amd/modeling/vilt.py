@@ -12,6 +12,7 @@ import copy
 import itertools
 import logging
 import os
+import threading
 import types
 from typing import Dict, List, Optional, Tuple
 
@@ -24,6 +25,7 @@ from ..optim import FusedAdamW
 from .continual_learner import ContinualLearner, EncoderWrapper
 
 logger = logging.getLogger(__name__)
+_TOKENIZER_LOCK = threading.Lock()
 
 
 def default_precision() -> str:
@@ -354,7 +356,9 @@ class ViltEncoderWrapper(EncoderWrapper):
         return new
 
     # --- inputs (REF:83-96)
-    def process_inputs(self, images, texts) -> Dict[str, torch.Tensor]:
+    def process_inputs(self, images, texts, pipeline=None) -> Dict[str, torch.Tensor]:
+        """`pipeline`: a DeviceImagePipeline of the caller's own (a prefetch worker thread must not share the training thread's pinned
+        staging ring); default = this encoder's."""
         dev = self.device
         if isinstance(texts, dict):                               # pre-tokenised text + pre-processed pixel tensor(s)
             enc = dict(texts)
@@ -374,12 +378,15 @@ class ViltEncoderWrapper(EncoderWrapper):
         if dev.type == "cuda":
             # row F1: tokenise on the host, but resize / rescale / normalise / pad the images on the device from their raw bytes
             # (bit-identical to ViltProcessor's tensors, a quarter of its host->device traffic, none of its host arithmetic)
-            enc = self.processor.tokenizer(texts, max_length=self.max_text_length, padding=True, truncation=True, return_tensors="pt")
+            with _TOKENIZER_LOCK:       # the fast tokenizer mutates its padding / truncation state per call: one caller at a time
+                enc = self.processor.tokenizer(texts, max_length=self.max_text_length, padding=True, truncation=True, return_tensors="pt")
             enc = {k: v.to(dev, non_blocking=True) for k, v in enc.items()}
-            if self._image_pipeline is None:
-                from ..data import DeviceImagePipeline
-                self._image_pipeline = DeviceImagePipeline(dev)
-            enc.update(self._image_pipeline(images))
+            if pipeline is None:
+                if self._image_pipeline is None:
+                    from ..data import DeviceImagePipeline
+                    self._image_pipeline = DeviceImagePipeline(dev)
+                pipeline = self._image_pipeline
+            enc.update(pipeline(images))
             return enc
         # module left on a CPU device (host-side inspection only: the engine refuses to run there): the reference's own host call
         enc = self.processor(images=images, text=texts, max_length=self.max_text_length, padding=True, truncation=True, return_tensors="pt")
@@ -546,6 +553,27 @@ class ViltContinualLearner(ContinualLearner):
 
     def get_encoder(self):
         return self._enc
+
+    def prepare_batch(self, task_key: str, batch: Dict, converter=None, pipeline=None) -> Dict:
+        """The host half of a step, movable off the training thread (REF/modeling/vilt.py:83-96 runs it inline, every
+        step): tokenise, stage the raw image bytes, launch the device image kernels and the host->device copies on the CURRENT stream.
+        Returns the batch with `encodings` (text tensors) and `images` (pixel tensors) in place of strings / PIL images -- what
+        `forward` / `fused_forward_backward` accept directly -- and its tensor targets already on the device.  Idempotent."""
+        if "encodings" in batch and isinstance(batch.get("images"), dict):
+            return batch
+        inputs = (converter or convert_batch_to_vilt_input_dict)(batch)
+        images, texts = self._flatten_inputs(task_key, inputs["images"], inputs["texts"])
+        if isinstance(texts, dict):
+            return batch
+        enc = self._enc.process_inputs(images, texts, pipeline=pipeline)
+        out = dict(batch)
+        out["encodings"] = {k: v for k, v in enc.items() if not k.startswith("pixel_")}
+        out["images"] = {k: v for k, v in enc.items() if k.startswith("pixel_")}
+        dev = self._enc.device
+        for k in ("target_scores", "labels"):
+            if isinstance(out.get(k), torch.Tensor):
+                out[k] = out[k].to(dev, non_blocking=True)
+        return out
 
     # --- fused training step: forward + loss + backward (+ EWC term) with no autograd graph.  This is what
     # climb_amd.train.*Trainer.train_step runs; semantics = REF/train/visionlanguage_tasks/train_vqa.py:135-166.

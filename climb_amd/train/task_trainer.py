@@ -96,6 +96,19 @@ class VLTaskTrainer(TaskTrainer):
     def get_collate_fn(self):
         return self.train_dataloader.collate_fn
 
+    def prefetched(self, model, loader):
+        """The loader with the host half of every batch (tokeniser, raw-byte staging, H2D copies, device image kernels:
+        `model.prepare_batch`) moved to a worker thread and a side HIP stream, two batches ahead of the step that consumes them
+        (climb_amd/data/prefetch.py; the reference does all of it on the training thread, REF/modeling/vilt.py:83-96).
+        CLIMB_AMD_PREFETCH=0, a CPU device or a model without `prepare_batch` leave the loader as it is."""
+        if torch.device(self.device).type != "cuda" or os.environ.get("CLIMB_AMD_PREFETCH", "1") == "0" or not hasattr(model, "prepare_batch"):
+            return loader
+        from ..data import DeviceImagePipeline, PrefetchLoader
+        pipe = self.__dict__.get("_prefetch_pipeline")
+        if pipe is None:
+            pipe = self.__dict__["_prefetch_pipeline"] = DeviceImagePipeline(self.device)      # the worker's own pinned staging ring
+        return PrefetchLoader(loader, lambda b: model.prepare_batch(self.task_key, b, self.batch2inputs_converter, pipe), depth=2, device=self.device)
+
     # ---- REF train_vqa.py:121-133
     def forward_pass(self, model, batch: Dict, do_eval: bool = False) -> Tuple:
         inputs = self.batch2inputs_converter(batch)
@@ -133,7 +146,7 @@ class VLTaskTrainer(TaskTrainer):
         model.zero_grad()
         for epoch in range(self.num_epochs):
             model.train()
-            for step, batch in enumerate(self.train_dataloader):
+            for step, batch in enumerate(self.prefetched(model, self.train_dataloader)):
                 loss, output, ewc_task, ewc_loss = self.train_step(model, batch, optimizer, scheduler, ewc)
                 if do_replay and (step + 1) % self.args.replay_frequency == 0:
                     sampled_replay_task = replay_memory.sample_replay_task()
@@ -159,7 +172,7 @@ class VLTaskTrainer(TaskTrainer):
     def eval(self, model) -> float:
         model.eval()
         score = torch.zeros((), dtype=torch.float64, device=self.device)
-        for step, batch in enumerate(self.val_dataloader):
+        for step, batch in enumerate(self.prefetched(model, self.val_dataloader)):
             output = self.forward_pass(model, batch, do_eval=True)
             score += self.batch_score(output[1], batch).double()      # accumulated on device: one sync per eval, not per batch
         if parallel.rank_world()[1] > 1 and self._val_is_sharded():
@@ -265,7 +278,7 @@ class LowShotMixin:
         model.zero_grad()
         for epoch in range(self.num_epochs):
             model.train()
-            for step, batch in enumerate(self.train_dataloader):
+            for step, batch in enumerate(self.prefetched(model, self.train_dataloader)):
                 self.train_step(model, batch, optimizer, scheduler)
             if epoch in self.eval_epochs:
                 eval_score = self.eval(model)
