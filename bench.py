@@ -34,7 +34,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--child-check", action="store_true", help=argparse.SUPPRESS)       # fp16_operand_line()'s child: run the reference checker leg only
     ap.add_argument("--graph", action="store_true", help="replay the step as a captured hipGraph (measured equal to eager launches at bs=64: the GPU, not the host, is the bottleneck)")
-    ap.add_argument("--cpu-steps", type=int, default=6)
+    ap.add_argument("--cpu-steps", type=int, default=10, help="timed B=2 CPU steps (BASELINE.md section 4: 10)")
     args = ap.parse_args()
 
     import numpy as np
@@ -199,6 +199,8 @@ def main():
             out["bf16_vs_ref" if args.precision != "fp16" else "fp16_vs_ref"] = bf16_vs_reference(dev, args.precision) if args.precision != "fp32" else None
             if args.precision == "bf16":
                 out["fp16_operands"] = fp16_operand_line(args)
+            if args.precision == "bf16":
+                out["real_input"] = real_input_line(dev, args)
             out["cpu_baseline"] = cpu_baseline(args.cpu_steps)
         print(json.dumps(out), flush=True)
     if dist.is_initialized():
@@ -273,10 +275,81 @@ def bf16_vs_reference(dev, precision="bf16"):
             "grad_norm_rel_err_median": round(float(np.median(gerr)), 6), "grad_norm_rel_err_max": round(float(gerr.max()), 6)}
 
 
+def real_input_line(dev, args):
+    """Reported next to the synthetic headline, never as `value` (VERDICT r2 missing #5): the VQA TRAINER LOOP end to end -- JPEG files on
+    disk -> the reference-format dataset + collate in DataLoader worker processes -> tokeniser + raw-byte staging + H2D + device image
+    kernels on the prefetch thread / side stream (climb_amd/data/prefetch.py) -> the same fused step + AdamW -- at 64 examples per step on
+    COCO-sized (640 x 480 / 480 x 640) images.  The reference runs all of the host half inline on the training thread
+    (REF/modeling/vilt.py:83-96).  Images here are variable-resolution (padded canvases, packed patches), so a step is not the
+    fixed-384 step of the headline."""
+    import shutil
+    import tempfile
+    import types
+    import numpy as np
+    import torch
+    try:
+        from PIL import Image
+        from tests import synth_data
+        from climb_amd.configs.model_configs import model_configs
+        from climb_amd.configs.task_configs import task_configs
+        from climb_amd.modeling import create_continual_learner_map
+        from climb_amd.train.task_trainer import VQATrainer
+        work = tempfile.mkdtemp(prefix="climb_real_input_")
+        try:
+            B, steps_per_epoch = args.batch, 6
+            n = B * steps_per_epoch
+            root = synth_data.make_climb_data_tree(os.path.join(work, "data"), n_train=n, n_val=2, seed=0, easy_answer=7)
+            rng = np.random.default_rng(0)
+            coco = os.path.join(root, "ms-coco", "images")
+            for i in range(n):                                   # COCO-sized photographs stand-ins: smooth content + grain, JPEG quality 90
+                w, h = (640, 480) if i % 4 else (480, 640)
+                low = rng.integers(0, 256, size=(h // 16, w // 16, 3), dtype=np.uint8)
+                img = np.asarray(Image.fromarray(low, "RGB").resize((w, h), Image.BICUBIC), dtype=np.int16) + rng.integers(-12, 13, size=(h, w, 3), dtype=np.int16)
+                Image.fromarray(np.clip(img, 0, 255).astype(np.uint8), "RGB").save(os.path.join(coco, f"{1000 + i}.jpg"), quality=90)
+            prev_vocab = os.environ.get("CLIMB_AMD_TOKENIZER_VOCAB")
+            os.environ["CLIMB_AMD_TOKENIZER_VOCAB"] = synth_data.write_vocab(os.path.join(work, "vocab.txt"))
+            workers = max(1, min(24, (os.cpu_count() or 8) // 2))
+            a = types.SimpleNamespace(climb_data_dir=root, batch_size=B, num_workers=workers, cl_algorithm="sequential_ft", visual_input_type="pil-image")
+            model = create_continual_learner_map["vilt"](model_name_or_path="random-init:42", ordered_cl_tasks=["vqa"], model_config=model_configs["vilt"],
+                                                         task_configs=task_configs, device=dev, precision=args.precision)
+            trainer = VQATrainer(a, task_configs, model_configs["vilt"], dev)
+            opt = model.create_optimizer(trainer.hparams)
+            model.train()
+            out = {}
+            for mode in ("1", "0"):                              # prefetched (the product's default), then inline on the training thread
+                os.environ["CLIMB_AMD_PREFETCH"] = mode
+                per_epoch = []
+                for epoch in range(3):
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    k = 0
+                    for batch in trainer.prefetched(model, trainer.train_dataloader):
+                        trainer.train_step(model, batch, opt)
+                        k += 1
+                    torch.cuda.synchronize()
+                    per_epoch.append((time.perf_counter() - t0) / k)
+                out[mode] = min(per_epoch[1:])                   # epoch 0 pays worker start-up and workspace allocation
+            os.environ.pop("CLIMB_AMD_PREFETCH", None)
+            if prev_vocab is None:
+                os.environ.pop("CLIMB_AMD_TOKENIZER_VOCAB", None)
+            else:
+                os.environ["CLIMB_AMD_TOKENIZER_VOCAB"] = prev_vocab
+            return {"value": round(B / out["1"], 1), "unit": "samples/s", "ms_per_step": round(out["1"] * 1e3, 2),
+                    "inline_on_training_thread": {"value": round(B / out["0"], 1), "ms_per_step": round(out["0"] * 1e3, 2)},
+                    "dataloader_workers": workers, "examples_per_step": B,
+                    "note": "VQATrainer loop on 640x480 / 480x640 JPEGs: disk -> dataset/collate workers -> prefetch thread (tokeniser, raw-byte staging, "
+                            "H2D, device resize/normalise/pad) -> fused step + AdamW; variable-resolution canvases, so not the fixed-384 step of `value`"}
+        finally:
+            shutil.rmtree(work, ignore_errors=True)
+    except Exception as e:      # the headline must not depend on the extra line
+        return {"error": repr(e)[:300]}
+
+
 def cpu_baseline(steps: int):
     """The CPU oracle (oracle/vilt_oracle.py: a plain-PyTorch fp32 port of the reference path, pinned to the reference by
-    tests/golden) timed on this node's host cores: B=2 (BASELINE.json configs[0]) training steps, 1 warm-up excluded, and ONE
-    training step at B=64 -- the batch the GPU line is quoted on."""
+    tests/golden) timed on this node's host cores, BASELINE.md section 4's protocol: `steps` (10) training steps at B=2 (BASELINE.json
+    configs[0]) after 1 warm-up, median; and at B=64 -- the batch the GPU line is quoted on -- 1 untimed warm-up step (first-touch
+    allocations of the new shape) and the median of 3 timed steps."""
     import torch
     from oracle import vilt_oracle as vo
     # torch's default intra-op thread count already honours the cgroup / affinity limits of this container
@@ -295,20 +368,22 @@ def cpu_baseline(steps: int):
         times.append(time.perf_counter() - t0)
     times = sorted(times[1:])
     med = times[len(times) // 2]
-    # the benchmark's own batch size: one timed step (a second B=64 step would add ~15 s for no information)
-    B64 = 64
-    enc = vo.synthetic_encodings(B64, seed=7)
-    tgt = vo.synthetic_vqa_targets(B64, seed=7)
-    t0 = time.perf_counter()
-    vo.train_step(P, "vqa", enc, tgt, opt_state=state, lr=1e-4)
-    t64 = time.perf_counter() - t0
+    B64, n64 = 64, int(os.environ.get("CLIMB_CPU_B64_STEPS", "3"))
+    t64s = []
+    for s in range(n64 + 1):
+        enc = vo.synthetic_encodings(B64, seed=7 + s)
+        tgt = vo.synthetic_vqa_targets(B64, seed=7 + s)
+        t0 = time.perf_counter()
+        vo.train_step(P, "vqa", enc, tgt, opt_state=state, lr=1e-4)
+        t64s.append(time.perf_counter() - t0)
+    t64 = sorted(t64s[1:])[len(t64s[1:]) // 2]
     try:
         model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
     except Exception:
         model = "unknown"
     return {"value": round(B64 / t64, 3), "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"1 fp32 training step (fwd+BCE+bwd+AdamW) at batch {B64} = the GPU line's batch, 384x384 + 40 tokens, {t64:.2f}s; "
-                      f"and {steps} steps at batch {B} (BASELINE configs[0]), median step {med:.3f}s, 1 warm-up excluded",
+            "sample": f"fp32 training steps (fwd+BCE+bwd+AdamW), 384x384 + 40 tokens: median of {n64} steps at batch {B64} = the GPU line's batch "
+                      f"({t64:.2f}s per step, 1 warm-up excluded); and {steps} steps at batch {B} (BASELINE configs[0]), median step {med:.3f}s, 1 warm-up excluded",
             "value_b2": round(B / med, 3), "cpu": model}
 
 
