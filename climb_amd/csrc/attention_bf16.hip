@@ -437,12 +437,14 @@ extern "C" int climb_attn_fwd_bf16(const void* qkv, const float* key_bias, void*
 // NW = ceil(NB / 2) waves, two outer blocks per wave.
 // dynamic LDS: NB blocks of (X rows | Y rows) | bias_s | lse_s | delta_s (AB_VEC(S_pad) floats each)
 // launch bound 576 (= 9 waves, 3 per SIMD) caps the kernel at 168 VGPRs: three workgroups stay resident per CU at S_pad = 192
-template <int PHASE>
-__global__ __launch_bounds__(576) void attn_bwd_bf16_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ key_bias,
-                                                            const bf16_t* __restrict__ dctx, const bf16_t* __restrict__ ctx,
-                                                            const float* __restrict__ lse, float* __restrict__ delta,
-                                                            bf16_t* __restrict__ dqkv, int S_pad, int heads, float scale) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+// FUSED (r03): both phases in ONE launch, one after the other in the same workgroup.  The second phase then finds K, V, Q, dO of its
+// head where the first one just read them (the XCD's L2 / the MALL instead of HBM), delta goes from phase 0 to phase 1 through LDS
+// instead of through memory, and a launch per layer disappears.
+template <int PHASE, bool FUSED>
+__device__ __forceinline__ void attn_bwd_body(unsigned char* smem, const bf16_t* __restrict__ qkv, const float* __restrict__ key_bias,
+                                              const bf16_t* __restrict__ dctx, const bf16_t* __restrict__ ctx,
+                                              const float* __restrict__ lse, float* __restrict__ delta,
+                                              bf16_t* __restrict__ dqkv, int S_pad, int heads, float scale) {
   float* bias_s = reinterpret_cast<float*>(smem + S_pad * 256);
   float* lse_s = bias_s + AB_VEC(S_pad);
   float* delta_s = lse_s + AB_VEC(S_pad);
@@ -466,7 +468,7 @@ __global__ __launch_bounds__(576) void attn_bwd_bf16_kernel(const bf16_t* __rest
   __builtin_amdgcn_sched_barrier(0);
   // the vectors every lane needs for the INNER index: LDS, raw
   if (PHASE == 0) vec_issue(bias_s, key_bias + (long)b * S_pad, S_pad, wid, nwaves, lane);
-  else { vec_issue(lse_s, lse + rowv, S_pad, wid, nwaves, lane); vec_issue(delta_s, delta + rowv, S_pad, wid, nwaves, lane); }
+  else { vec_issue(lse_s, lse + rowv, S_pad, wid, nwaves, lane); if (!FUSED) vec_issue(delta_s, delta + rowv, S_pad, wid, nwaves, lane); }
   Streamer sw;
   if (PHASE == 0) sw.init(smem, Kg, ld, Vg, ld, S_pad / 8, wid, nwaves, lane);
   else            sw.init(smem, Qg, ld, dOg, H, S_pad / 8, wid, nwaves, lane);
@@ -570,6 +572,9 @@ __global__ __launch_bounds__(576) void attn_bwd_bf16_kernel(const bf16_t* __rest
       }
     }
     bf16_t* orow = dqkv + ((long)b * S_pad + my) * ld + h * AB_D;
+    // FUSED: delta goes to phase 1 through LDS.  Written here -- the staging stream ended inside the first outer block and the next block's
+    // register loads are not yet in flight, so the vmcnt(0) hipcc puts in front of a DS store that may follow LDS DMA waits for nothing
+    if (FUSED && PHASE == 0 && half == 0) delta_s[my] = my_delta;
     // the next outer block's register operands are requested BEFORE this block's results are stored: they are not queued behind 19-38 MB
     // of stores, and their latency overlaps the store issue
     const float was_c = my_c;
@@ -583,7 +588,7 @@ __global__ __launch_bounds__(576) void attn_bwd_bf16_kernel(const bf16_t* __rest
     if ((AB_PROBE & 4) && was_c != 12345.f) {}
     else if (PHASE == 0) {
       store_acc(orow, acc1, half, scale);
-      if (half == 0) delta[rowv + my] = my_delta;
+      if (half == 0 && !FUSED) delta[rowv + my] = my_delta;
     } else {
       store_acc(orow + H, acc1, half, -scale);
       store_acc(orow + 2 * H, acc2, half, 1.0f);
@@ -599,6 +604,26 @@ __global__ __launch_bounds__(576) void attn_bwd_bf16_kernel(const bf16_t* __rest
   }
 }
 
+template <int PHASE>
+__global__ __launch_bounds__(576) void attn_bwd_bf16_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ key_bias,
+                                                            const bf16_t* __restrict__ dctx, const bf16_t* __restrict__ ctx,
+                                                            const float* __restrict__ lse, float* __restrict__ delta,
+                                                            bf16_t* __restrict__ dqkv, int S_pad, int heads, float scale) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  attn_bwd_body<PHASE, false>(smem, qkv, key_bias, dctx, ctx, lse, delta, dqkv, S_pad, heads, scale);
+}
+__global__ __launch_bounds__(576) void attn_bwd_bf16_fused_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ key_bias,
+                                                                  const bf16_t* __restrict__ dctx, const bf16_t* __restrict__ ctx,
+                                                                  const float* __restrict__ lse, float* __restrict__ delta,
+                                                                  bf16_t* __restrict__ dqkv, int S_pad, int heads, float scale) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  attn_bwd_body<0, true>(smem, qkv, key_bias, dctx, ctx, lse, delta, dqkv, S_pad, heads, scale);
+  __syncthreads();          // every wave is done with the K / V images and has left its rows' delta in LDS
+  attn_bwd_body<1, true>(smem, qkv, key_bias, dctx, ctx, lse, delta, dqkv, S_pad, heads, scale);
+}
+static int g_attn_bwd_fused = 1;     // measurement knob (climb_set_option 13): 0 = the two launches
+void climb_attn_set_bwd_fused(int v) { g_attn_bwd_fused = v; }
+
 extern "C" int climb_attn_bwd_bf16(const void* qkv, const float* key_bias, const void* dctx, const void* ctx, const float* lse, float* delta,
                                    void* dqkv, int B, int S_pad, int heads, int head_dim, void* stream) {
   if (head_dim != AB_D || S_pad % 32 || S_pad <= 0 || S_pad > 512) return CLIMB_EUNSUPPORTED;
@@ -609,12 +634,20 @@ extern "C" int climb_attn_bwd_bf16(const void* qkv, const float* key_bias, const
     if (e != hipSuccess) return (int)e;
     e = hipFuncSetAttribute((const void*)attn_bwd_bf16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute((const void*)attn_bwd_bf16_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
     lds_set = lds;
   }
   const float scale = 1.0f / sqrtf((float)head_dim);
   // two outer blocks per wave: 64 nw >= S_pad threads (one element of the LDS vectors each) and 4 NB units over nw waves is at most 8 rounds;
   // measured at S_pad = 192: 3 waves 63 us, 6 waves 78 us per layer (register pressure: 3 workgroups x 3 waves fill the 168-VGPR budget)
   const int nthreads = 64 * ((S_pad / 32 + 1) / 2);
+  if (g_attn_bwd_fused) {
+    hipLaunchKernelGGL(attn_bwd_bf16_fused_kernel, dim3(B * heads), dim3(nthreads), lds, (hipStream_t)stream, (const bf16_t*)qkv, key_bias,
+                       (const bf16_t*)dctx, (const bf16_t*)ctx, lse, delta, (bf16_t*)dqkv, S_pad, heads, scale);
+    LAUNCH_CHECK();
+    return CLIMB_OK;
+  }
   hipLaunchKernelGGL((attn_bwd_bf16_kernel<0>), dim3(B * heads), dim3(nthreads), lds, (hipStream_t)stream, (const bf16_t*)qkv, key_bias,
                      (const bf16_t*)dctx, (const bf16_t*)ctx, lse, delta, (bf16_t*)dqkv, S_pad, heads, scale);
   LAUNCH_CHECK();

@@ -333,6 +333,7 @@ static int g_nt_256 = 1;       // persistent 256-row tiles (gemm_bf16_ntp.hip): 
 static int g_tn_p = 1;         // weight gradients on the persistent 256-row-tile kernel (gemm_bf16_tnp.hip) when the shape allows
 static int g_nt_small_m = 1;   // 64x128 tiles for shapes whose 128x128 tiling quantises badly on 512 workgroup slots
 void climb_attn_set_qb(int v);
+void climb_attn_set_bwd_fused(int v);
 extern "C" int climb_set_option(int key, int value) {
   if (key == 1 && (value == 4 || value == 8)) { g_nt_waves = value; return CLIMB_OK; }
   if (key == 2) { g_nt_small_m = value; return CLIMB_OK; }
@@ -343,6 +344,7 @@ extern "C" int climb_set_option(int key, int value) {
   if (key == 10 && (value == 0 || value == 1)) { g_tn_p = value; return CLIMB_OK; }
   if (key == 11 && value >= 0) { climb_nt2_set_dephase(value); return CLIMB_OK; }
   if (key == 12 && value >= 0 && value <= 2) { climb_attn_set_qb(value); return CLIMB_OK; }
+  if (key == 13 && (value == 0 || value == 1)) { climb_attn_set_bwd_fused(value); return CLIMB_OK; }
   if (key == 9 && value >= 0) { climb_nt256_set_grid(value); return CLIMB_OK; }
   if (key == 6 && (value == 4 || value == 8)) { g_tn_waves = value; return CLIMB_OK; }
   if (key == 3 && value > 0) { g_tn_target = value; return CLIMB_OK; }

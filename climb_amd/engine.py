@@ -25,6 +25,7 @@ _FUSED_ADAPTER = os.environ.get("CLIMB_AMD_FUSED_ADAPTER", "1") != "0"       # m
 # "0" = off (one split GEMM + reduce per weight, the r02 path); default: all layers in one launch, 4 per launch under a data-parallel hook
 # (ranges must become ready in a few chunks for the all-reduce to overlap the rest of the backward)
 _DW_GROUP = os.environ.get("CLIMB_AMD_DW_GROUP")
+_RED_BATCH = os.environ.get("CLIMB_AMD_RED_BATCH", "1") != "0"          # measurement knob: 0 = one reduce launch per LayerNorm backward
 _UNSCALE_MODE = os.environ.get("CLIMB_AMD_FP16_UNSCALE", "end")      # measurement knob: "range" (per finished range), "end" (one pass), "none" (timing only)
 EPI_NONE, EPI_GELU, EPI_RESID, EPI_DGELU, EPI_TANH, EPI_SILU, EPI_DSILU, EPI_RESID2 = 0, 1, 2, 3, 4, 5, 6, 7
 
@@ -714,8 +715,9 @@ class ViltEngine:
         pending, pending_red, group = [], [], []
         if G:
             ws.ensure_deferred(self)
-        lnpart = (lambda k: ws.part_l[k]) if G else (lambda k: ws.part)          # partial sums of LayerNorm backward k (2 per layer)
-        red3 = (lambda part, *names: pending_red.append((part, nlnb, H, names))) if G else (lambda part, *names: self.reduce3(part, nlnb, H, *names))
+        RB = bool(G) and _RED_BATCH
+        lnpart = (lambda k: ws.part_l[k]) if RB else (lambda k: ws.part)          # partial sums of LayerNorm backward k (2 per layer)
+        red3 = (lambda part, *names: pending_red.append((part, nlnb, H, names))) if RB else (lambda part, *names: self.reduce3(part, nlnb, H, *names))
         dxc = (lambda i: ws.dx_c[i]) if G else (lambda i: ws.dres_c)          # 16-bit d(x_i) / d(h1_i) / d(u_i) / d(qkv_i): per layer when deferred
         dhc = (lambda i: ws.dh_c[i]) if G else (lambda i: ws.dres_c)
         du_ = (lambda i: ws.du_l[i]) if G else (lambda i: ws.du)

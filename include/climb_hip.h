@@ -33,7 +33,7 @@ int climb_device_sync(void);
  * 64x128 / 96x192 / 192x192 NT tile variants (0/1); key 3 = workgroup target of the 128x128 TN split; key 6 = waves per workgroup of the TN GEMM (4 or 8);
  * key 7 = persistent 256-row NT tiles (0 never, 1 auto, 2 / 3 force 256 / 192 columns, 4 two-workgroup variant); key 8 = k-loop-only probe of that kernel;
  * key 9 = its grid; key 10 = persistent TN kernel (0/1); key 11 = de-phasing of the two-workgroup variant; key 12 = query blocks per wave of the
- * bf16 attention forward (0 auto, 1, 2) */
+ * bf16 attention forward (0 auto, 1, 2); key 13 = bf16 attention backward as one launch (1, default) or one launch per phase (0) */
 int climb_set_option(int key, int value);
 
 /* ---- embeddings -------------------------------------------------------------------------------------------------- */

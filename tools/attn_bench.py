@@ -36,5 +36,8 @@ t = timeit(lambda: _lib.call("climb_attn_fwd_bf16", qkv, bias, ctx, lse, B, S_pa
 print(f"fwd  {t*1e6:7.1f} us  {f/t/1e12:6.1f} TF")
 t = timeit(lambda: _lib.call("climb_attn_delta", dctx, ctx, 1, delta, B, S_pad, heads, st()))
 print(f"delta {t*1e6:6.1f} us")
-t = timeit(lambda: _lib.call("climb_attn_bwd_bf16", qkv, bias, dctx, ctx, lse, delta, dqkv, B, S_pad, heads, d, st()))
-print(f"bwd  {t*1e6:7.1f} us  {3.5*f/t/1e12:6.1f} TF (7 products)")
+for fused in (1, 0):          # r03: both phases in one launch (default) / one launch per phase
+    _lib.call("climb_set_option", 13, fused)
+    t = timeit(lambda: _lib.call("climb_attn_bwd_bf16", qkv, bias, dctx, ctx, lse, delta, dqkv, B, S_pad, heads, d, st()))
+    print(f"bwd  {t*1e6:7.1f} us  {3.5*f/t/1e12:6.1f} TF (7 products)  {'one launch' if fused else 'two launches'}")
+_lib.call("climb_set_option", 13, 1)
