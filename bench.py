@@ -335,6 +335,14 @@ def real_input_line(dev, args):
                     stamps.append(time.perf_counter())
                 gaps = sorted(b - a_ for a_, b in zip(stamps[skip:-1], stamps[skip + 1:]))
                 out[mode] = gaps[len(gaps) // 2]
+                if mode == "1":                                   # the same step with its (last) prepared batch resident: what the loop costs without any input work
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(10):
+                        trainer.train_step(model, batch, opt)
+                    torch.cuda.synchronize()
+                    out["resident"] = (time.perf_counter() - t0) / 10
+                    out["seq"] = int(model._host.engine().last_ws.S)
             os.environ.pop("CLIMB_AMD_PREFETCH", None)
             if prev_vocab is None:
                 os.environ.pop("CLIMB_AMD_TOKENIZER_VOCAB", None)
@@ -342,6 +350,7 @@ def real_input_line(dev, args):
                 os.environ["CLIMB_AMD_TOKENIZER_VOCAB"] = prev_vocab
             return {"value": round(B / out["1"], 1), "unit": "samples/s", "ms_per_step": round(out["1"] * 1e3, 2),
                     "inline_on_training_thread": {"value": round(B / out["0"], 1), "ms_per_step": round(out["0"] * 1e3, 2)},
+                    "same_step_inputs_resident_ms": round(out["resident"] * 1e3, 2), "tokens_per_sequence": out["seq"],
                     "dataloader_workers": workers, "examples_per_step": B,
                     "note": "VQATrainer loop on 640x480 / 480x640 JPEGs: disk -> dataset/collate workers -> prefetch thread (tokeniser, raw-byte staging, "
                             "H2D, device resize/normalise/pad) -> fused step + AdamW; variable-resolution canvases, so not the fixed-384 step of `value`"}
