@@ -65,6 +65,9 @@ def install_fake_c_abi():
         self._shadow = None
         self._shadow_version = -1
     engine.ViltEngine.allocate = allocate
+    # the grouped weight-gradient / batched-reduction launches build device tables through a host function of the library: no-ops here too
+    engine.ViltEngine._dw_flush = lambda self, ws, pending: pending.clear()
+    engine.ViltEngine._red_flush = lambda self, ws, pending: pending.clear()
     engine._stream = lambda: 0
     torch.cuda.current_stream = lambda *a, **k: types.SimpleNamespace(cuda_stream=0)
 
