@@ -784,6 +784,72 @@ def _rand_batch(B, seed, dev):
     return pixels.to(dev), {k: v.to(dev) for k, v in texts.items()}, target.to(dev)
 
 
+@pytest.mark.parametrize("config", ["ewc", "adapters_nlvr2", "replay_vcr"])
+def test_continual_learning_configs_at_the_benchmarks_64_sequences(config):
+    """BASELINE.json configs[2] / [3] / [4] at the benchmark's size on one GPU (only B = 2 fixtures and batch-4 driver
+    runs exercised them): 64 encoder sequences per step through the throughput (16-bit) mode and the fp32 parity mode (itself pinned to the
+    reference by the B = 2 fixtures of the same code paths) -- the EWC-penalised VQA step, the NLVR2 step under an active Houlsby adapter
+    (32 pairs), and an experience-replay step of VCR (16 x 4 choices, fresh optimizer, eval-mode head so that no dropout mask differs)."""
+    from climb_amd.cl_algorithms import AdapterHandler, EWC
+    dev = _dev()
+    tasks = ["vqa", "nlvr2", "vcr"]
+    out = {}
+    for precision in ("fp32", H16):
+        torch.manual_seed(0)
+        random.seed(0)
+        model, P = make_model(tasks, 42, precision=precision)
+        model.train()
+        if config == "ewc":
+            pixels, texts, target = _rand_batch(64, 501, dev)
+            ewc = EWC(types.SimpleNamespace(ewc_fisher_sample_percentage=0.01, ewc_loss_weight=100.0))
+            fisher, star = _ewc_state(P, 5)
+            ewc.set_task_state("nlvr2", model, fisher, star)
+            loss, (_, logits), ewc_task, ewc_loss = model.fused_forward_backward("vqa", pixels, texts, target, ewc)
+            assert ewc_task == "nlvr2"
+            extra = float(ewc_loss)
+        elif config == "adapters_nlvr2":
+            args = types.SimpleNamespace(adapter_config="houlsby", adapter_reduction_factor=16, ordered_cl_tasks=tasks)
+            handler = AdapterHandler("vanilla", args)
+            handler.add_adapters_to_model(model)
+            handler.activate_adapter_for_training(task_key="nlvr2", model=model)
+            g = torch.Generator().manual_seed(9)
+            with torch.no_grad():
+                for n, p in model.named_parameters():
+                    if ".adapters." in n:
+                        p.copy_((torch.randn(p.shape, generator=g) * (0.05 if n.endswith("weight") else 0.02)).to(p.device))
+            pixels, texts, _ = _rand_batch(64, 502, dev)
+            texts = {k: v[:32] for k, v in texts.items()}
+            labels = torch.randint(0, 2, (32,), generator=torch.Generator().manual_seed(3))
+            loss, (_, logits), _, _ = model.fused_forward_backward("nlvr2", pixels, texts, labels)
+            extra = 0.0
+            assert all((".adapters.nlvr2." in n) or n.startswith("task_layer.") for n in grads_of(model))
+        else:
+            pixels, texts, _ = _rand_batch(64, 503, dev)
+            labels = torch.randint(0, 4, (16,), generator=torch.Generator().manual_seed(4))
+            model.eval()
+            opt = model.create_optimizer({"lr": 1e-4, "weight_decay": 1e-2, "adam_epsilon": 1e-8})        # replay: a fresh AdamW (REF experience_replay.py:61)
+            loss, (_, logits), _, _ = model.fused_forward_backward("vcr", pixels[:16], texts, labels)
+            extra = 0.0
+        G = {n: float(g.double().norm()) for n, g in grads_of(model).items()}
+        if config == "replay_vcr":
+            before = model.get_encoder().vilt.encoder.layer[5].output.dense.weight.detach().clone()
+            opt.step()
+            assert not torch.equal(before, model.get_encoder().vilt.encoder.layer[5].output.dense.weight.detach())
+        out[precision] = (float(loss), logits.detach().float().cpu(), G, extra)
+        assert bool(torch.isfinite(logits).all())
+        del model
+        torch.cuda.empty_cache()
+    l32, lg32, g32, x32 = out["fp32"]
+    l16, lg16, g16, x16 = out[H16]
+    assert abs(l16 - l32) <= 3e-3 * abs(l32) and abs(x16 - x32) <= 1e-4 * max(1.0, abs(x32))       # the EWC term is fp32 in both modes
+    _close(lg16, lg32, BF16_TOL, f"logits {H16} vs fp32 ({config})")
+    assert set(g16) == set(g32)
+    top = max(g32.values())
+    worst = max(abs(g16[n] - v) / v for n, v in g32.items() if v > 1e-3 * top)
+    print(f"{config} at 64 sequences: loss {l32:.4f} / {l16:.4f}, worst gradient-norm difference {worst:.2e}")
+    assert worst <= 6e-2
+
+
 def test_full_size_batch_permutation_and_mode_agreement():
     """BASELINE.json configs[1] size (64 sequences x 185 tokens), where the CPU oracle would take minutes: size-independent
     properties instead.  (1) samples are independent: permuting the batch permutes pooled/logits and leaves the loss and every
