@@ -334,6 +334,8 @@ static int g_tn_p = 1;         // weight gradients on the persistent 256-row-til
 static int g_nt_small_m = 1;   // 64x128 tiles for shapes whose 128x128 tiling quantises badly on 512 workgroup slots
 void climb_attn_set_qb(int v);
 void climb_attn_set_bwd_fused(int v);
+void climb_ntsk_enable(int v);
+void climb_ntsk_set_workspace(void* ptr, long bytes);
 extern "C" int climb_set_option(int key, int value) {
   if (key == 1 && (value == 4 || value == 8)) { g_nt_waves = value; return CLIMB_OK; }
   if (key == 2) { g_nt_small_m = value; return CLIMB_OK; }
@@ -345,6 +347,7 @@ extern "C" int climb_set_option(int key, int value) {
   if (key == 11 && value >= 0) { climb_nt2_set_dephase(value); return CLIMB_OK; }
   if (key == 12 && value >= 0 && value <= 2) { climb_attn_set_qb(value); return CLIMB_OK; }
   if (key == 13 && (value == 0 || value == 1)) { climb_attn_set_bwd_fused(value); return CLIMB_OK; }
+  if (key == 14 && (value == 0 || value == 1)) { climb_ntsk_enable(value); return CLIMB_OK; }
   if (key == 9 && value >= 0) { climb_nt256_set_grid(value); return CLIMB_OK; }
   if (key == 6 && (value == 4 || value == 8)) { g_tn_waves = value; return CLIMB_OK; }
   if (key == 3 && value > 0) { g_tn_target = value; return CLIMB_OK; }
@@ -625,6 +628,15 @@ __global__ __launch_bounds__(512 / NI) void gemm_bf16_tn_kernel(const bf16_t* __
 extern "C" int climb_set_tn_workspace(void* ptr, long bytes) {
   if (bytes < 0 || (((uintptr_t)ptr) & 15)) return CLIMB_EINVAL;
   climb_tnp_set_workspace(ptr, bytes);
+  return CLIMB_OK;
+}
+
+// Registers the scratch of the split-along-K NT kernel (gemm_bf16_ntp.hip: partial accumulator tiles + hand-over flags); NULL / 0
+// unregisters.  climb_nt_workspace_bytes() says how much it wants; without it the N = 768 GEMMs run on 192 of the 256 CUs as before.
+extern "C" int climb_nt_workspace_bytes(void) { return 192 * 96 * 512 * 4 + 4096; }
+extern "C" int climb_set_nt_workspace(void* ptr, long bytes) {
+  if (bytes < 0 || (((uintptr_t)ptr) & 15)) return CLIMB_EINVAL;
+  climb_ntsk_set_workspace(ptr, bytes);
   return CLIMB_OK;
 }
 

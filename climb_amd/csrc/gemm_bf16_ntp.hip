@@ -251,6 +251,187 @@ __global__ __launch_bounds__(512) void gemm_bf16_ntp_kernel(const bf16_t* __rest
 }
 
 static int g_nt256_probe = 0, g_nt256_grid = 256;
+// ---------------------------------------------------------------------------------------------------- split-along-K balancing (r03)
+// The layer's N = 768 GEMMs tile 12288 x 768 into 192 tiles of 256 x 192: a quarter of the 256 CUs idles for the whole launch.  For the
+// long-K ones (down-projection K = 3072, dhn K = 3072, dxn K = 2304: 182 us per layer) this kernel gives every CU 3/4 of a tile's k-loop
+// instead: four workgroups (same XCD) share three tiles,
+//     member 0: tile0 k-tiles [0, 3u)                      -> finishes tile0 (adds member 1's partial)
+//     member 1: tile0 [3u, 4u) first, then tile1 [0, 2u)   -> hands tile0's partial over, finishes tile1 (adds member 2's)
+//     member 2: tile2 [0, u) first, then tile1 [2u, 4u)    -> hands over both, finishes nothing
+//     member 3: tile2 [u, 4u)                              -> finishes tile2 (adds member 2's first partial)          u = K / 256
+// A partial is the raw fp32 accumulator image (96 registers x 512 lanes = 192 KB) written with SYSTEM-scope stores into a slot of the
+// registered scratch (climb_set_tn_workspace) and announced by a flag; the finishing workgroup spins on the flag (bounded: a lost partner
+// costs a wrong tile, never a hung GPU), adds the partial to its accumulators three 16-register blocks at a time and runs the ordinary
+// epilogue.  System scope because nothing guarantees the four workgroups share an L2; the flag is reset by its reader, so a launch always
+// starts from zeros (hipGraph replays included).  Every handed-over part is computed BEFORE the part its workgroup finishes, so only the
+// tile2 hand-over (both sides end at 3u) can make anybody wait.  Requires exactly 192 tiles of 256 x 192, K % 256 == 0, K >= 512, grid 256.
+#define NTSK_SLOT_FLOATS (96 * 512)
+__device__ __forceinline__ void ntsk_store(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ float ntsk_load(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+
+template <typename TO, int EPI>
+__global__ __launch_bounds__(512) void gemm_bf16_ntsk_kernel(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ B, long ldb,
+                                                             TO* __restrict__ C, long ldc, int M, int N, int K, const float* __restrict__ bias,
+                                                             const void* __restrict__ aux, long ldaux, bf16_t* __restrict__ aux_out, long ldauxo,
+                                                             float* ws, int* flags) {
+  constexpr int NI = 3, BN = 192;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wid >> 1, wc = wid & 1, grp = wid >> 2, half = lane >> 5, l31 = lane & 31;
+  const int nbm = M / NTP_BM, nbn = N / BN, gm = nbm / 8;
+  unsigned aoff[4], boff[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const int cs = ((2 * ks + half) ^ swz(l31)) << 4;
+    aoff[ks] = (wr * 64 + l31) * 128 + cs;
+    boff[ks] = (wc * 32 + l31) * 128 + cs;
+  }
+  const int x = blockIdx.x & 7, idx = blockIdx.x >> 3, q = idx >> 2, mem = idx & 3;
+  const int u = K / 256;                                   // a quarter of the tile's k-tiles
+  const int slot0 = (q * 8 + x) * 3;                       // this group's three slots (one per tile)
+  for (int part = 0; part < 2; ++part) {
+    int j, kt0, kt1;
+    bool writer;
+    if (mem == 0)      { if (part) break; j = 0; kt0 = 0; kt1 = 3 * u; writer = false; }
+    else if (mem == 1) { if (!part) { j = 0; kt0 = 3 * u; kt1 = 4 * u; writer = true; } else { j = 1; kt0 = 0; kt1 = 2 * u; writer = false; } }
+    else if (mem == 2) { if (!part) { j = 2; kt0 = 0; kt1 = u; writer = true; } else { j = 1; kt0 = 2 * u; kt1 = 4 * u; writer = true; } }
+    else               { if (part) break; j = 2; kt0 = u; kt1 = 4 * u; writer = false; }
+    int tm, tn;
+    nt_tile_id_gm(gm, x + 8 * (3 * q + j), nbm, nbn, tm, tn);
+    const int m0 = tm * NTP_BM, n0 = tn * BN;
+    const bf16_t* Ak = A + (long)kt0 * GB_BK;              // k-tiles [kt0, kt1) of this tile
+    const bf16_t* Bk = B + (long)kt0 * GB_BK;
+    const int nk = kt1 - kt0;                              // >= 2
+    NtpStage<NI> sg;
+    sg.wid = wid;
+#pragma unroll
+    for (int uu = 0; uu < 2; ++uu)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int slot = (wid * 2 + i) * 64 + lane, r = uu * 128 + (slot >> 3), c = (slot & 7) ^ swz(r);
+        sg.a_off[uu * 2 + i] = (unsigned)(((long)(m0 + r) * lda + c * 8) * 2);
+      }
+#pragma unroll
+    for (int p = 0; p < NI; ++p) {
+      const int slot = wid * 64 + lane, r = slot >> 3, c = (slot & 7) ^ swz(r);
+      sg.b_off[p] = (unsigned)(((long)(n0 + (r >> 5) * (32 * NI) + p * 32 + (r & 31)) * ldb + c * 8) * 2);
+    }
+    f32x16 acc[NI][2];
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.f;
+    {
+      bf16x8 a[2][4];
+      ntp_prologue<NI>(sg, Ak, Bk, smem);
+      wait_vmcnt<ntp_wait(NI, 6, -1, NI - 1)>();
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      if (grp == 1) __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      int T = 0;
+      for (; T + 2 < nk; ++T) ntp_ktile<NI, 0>(acc, a, sg, Ak, Bk, smem, T, aoff, boff);
+      ntp_ktile<NI, 1>(acc, a, sg, Ak, Bk, smem, T, aoff, boff);
+      ntp_ktile<NI, 2>(acc, a, sg, Ak, Bk, smem, T + 1, aoff, boff);
+      if (grp == 0) __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    float* slot = ws + (long)(slot0 + j) * NTSK_SLOT_FLOATS + threadIdx.x;
+    int* flag = flags + slot0 + j;
+    if (writer) {
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) ntsk_store(slot + ((i * 2 + jj) * 16 + r) * 512, acc[i][jj][r]);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this lane's share of the partial is at the coherence point
+      __syncthreads();                                       // ... and everybody's
+      if (threadIdx.x == 0) __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    } else {
+      if (threadIdx.x == 0) {
+        int spins = 0;
+        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 1 && ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(8);
+      }
+      __syncthreads();
+      // acc += partial, three 16-register blocks in flight (the fragment registers of the k-loop are free by now)
+      float t[3][16];
+#pragma unroll
+      for (int b = 0; b < 3; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t[b][r] = ntsk_load(slot + (b * 16 + r) * 512);
+#pragma unroll
+      for (int b = 0; b < 6; ++b) {
+        if (b < 3) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+        else if (b == 3) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+        else if (b == 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[b >> 1][b & 1][r] += t[b % 3][r];
+        if (b + 3 < 6) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) t[b % 3][r] = ntsk_load(slot + ((b + 3) * 16 + r) * 512);
+        }
+      }
+      __syncthreads();                                       // every lane has its share in registers
+      if (threadIdx.x == 0) __hip_atomic_store(flag, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);      // the next launch starts from zeros
+      int el = lane;
+      asm volatile("" : "+v"(el));
+      NtBias<NtpEpi<NI>::NIE> bb[NtpEpi<NI>::PER_ROW];
+      AuxRegs<EPI, NtpEpi<NI>::NIE * 4> ax[NtpEpi<NI>::NSB];
+      ntp_epilogue<0, TO, EPI, NI>(acc, ax, bb, smem + wid * (NtpEpi<NI>::NIE * 4096), el, m0 + wr * 64, n0 + wc * (32 * NI), M, N, C, ldc, bias, aux,
+                                   ldaux, aux_out, ldauxo);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+static float* g_ntsk_ws = nullptr;
+static long g_ntsk_bytes = 0;
+static bool g_ntsk_flags_clean = false;
+static int g_ntsk_on = 1;                                    // climb_set_option 14
+void climb_ntsk_set_workspace(void* ptr, long bytes) { g_ntsk_ws = (float*)ptr; g_ntsk_bytes = ptr ? bytes : 0; g_ntsk_flags_clean = false; }
+void climb_ntsk_enable(int v) { g_ntsk_on = v; }
+#define NTSK_FLAGS 192
+#define NTSK_BYTES ((long)NTSK_FLAGS * NTSK_SLOT_FLOATS * 4 + 4096)
+
+template <typename TO, int EPI>
+static int ntsk_launch_one(hipStream_t st, const bf16_t* A, long lda, const bf16_t* B, long ldb, TO* C, long ldc, int M, int N, int K, const float* bias,
+                           const void* aux, long ldaux, bf16_t* aux_out, long ldauxo) {
+  constexpr int LDS = 2 * (NTP_A_BYTES + 3 * NTP_B_UNIT);
+  static bool configured = false;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_ntsk_kernel<TO, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) return (int)e;
+    configured = true;
+  }
+  int* flags = reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(g_ntsk_ws) + (long)NTSK_FLAGS * NTSK_SLOT_FLOATS * 4);
+  if (!g_ntsk_flags_clean) {                                 // once per registered buffer, in stream order (readers reset their flag afterwards)
+    hipError_t e = hipMemsetAsync(flags, 0, 4096, st);
+    if (e != hipSuccess) return (int)e;
+    g_ntsk_flags_clean = true;
+  }
+  hipLaunchKernelGGL((gemm_bf16_ntsk_kernel<TO, EPI>), dim3(256), dim3(512), LDS, st, A, lda, B, ldb, C, ldc, M, N, K, bias, aux, ldaux, aux_out, ldauxo,
+                     g_ntsk_ws, flags);
+  return CLIMB_OK;
+}
+
+// the split-along-K kernel takes: 48 x 4 tiles of 256 x 192 exactly, K % 256 == 0 and K >= 1536 (below that the hand-over costs more than
+// the idle quarter of the chip), EPI NONE / RESID, a registered scratch of NTSK_BYTES, persistent grid 256
+static int ntsk_try(const bf16_t* A, long lda, const bf16_t* B, long ldb, void* C, long ldc, int c_dtype, int M, int N, int K, const float* bias, int epi,
+                    const void* aux, long ldaux, bf16_t* aux_out, long ldauxo, hipStream_t st) {
+  if (!g_ntsk_on || g_nt256_grid != 256 || g_nt256_probe) return CLIMB_EUNSUPPORTED;
+  if (M != 48 * NTP_BM || N != 4 * 192 || (K % 256) || K < 1536 || g_ntsk_bytes < NTSK_BYTES) return CLIMB_EUNSUPPORTED;
+  if (c_dtype == CLIMB_DT_BF16 && epi == EPI_NONE) return ntsk_launch_one<bf16_t, EPI_NONE>(st, A, lda, B, ldb, (bf16_t*)C, ldc, M, N, K, bias, aux, ldaux, aux_out, ldauxo);
+  if (c_dtype == CLIMB_DT_F32 && epi == EPI_RESID) return ntsk_launch_one<float, EPI_RESID>(st, A, lda, B, ldb, (float*)C, ldc, M, N, K, bias, aux, ldaux, aux_out, ldauxo);
+  return CLIMB_EUNSUPPORTED;
+}
+
+
 void climb_nt256_set_probe(int v) { g_nt256_probe = v; }      // bit 0: k-loop only; v >> 8: supertile height override (measurement)
 void climb_nt256_set_grid(int v) { g_nt256_grid = v; }
 
@@ -278,6 +459,10 @@ int climb_nt256_launch(int bn, const bf16_t* A, long lda, const bf16_t* B, long 
   // for the 192-wide tile, which is also the width the layer's residual GEMMs (N = 768) tile best with
   // (the x GELU' epilogue at 256 columns spills 64 - 72 B/lane as well -- its pre-activation operand next to 128 accumulators -- and goes the same way)
   if (epi == EPI_RESID || epi == EPI_DGELU) bn = 192;
+  if (bn == 192) {
+    const int rc = ntsk_try(A, lda, B, ldb, C, ldc, c_dtype, M, N, K, bias, epi, aux, ldaux, aux_out, ldauxo, st);
+    if (rc != CLIMB_EUNSUPPORTED) return rc;
+  }
   int nwg = ((M + NTP_BM - 1) / NTP_BM) * ((N + bn - 1) / bn);
   if (g_nt256_grid > 0 && nwg > g_nt256_grid) nwg = g_nt256_grid;       // persistent: one workgroup per CU walks the tiles
 #define LNTP(TO, E, NI_) return ntp_launch_one<TO, E, NI_>(nwg, st, A, lda, B, ldb, (TO*)C, ldc, M, N, K, bias, aux, ldaux, aux_out, ldauxo)

@@ -52,6 +52,19 @@ def tn_workspace(device):
     return _TN_WS[key]
 
 
+_NT_WS = {}
+
+
+def nt_workspace(device):
+    """Scratch of the split-along-K NT GEMMs (csrc/gemm_bf16_ntp.hip: partial accumulator tiles handed between workgroups, 38 MB).  Like
+    tn_workspace: a per-device singleton the library keeps a pointer to for the life of the process."""
+    key = str(torch.device(device))
+    if key not in _NT_WS:
+        _NT_WS[key] = torch.empty(_lib.query("climb_nt_workspace_bytes") // 4, dtype=torch.float32, device=device)
+    _lib.call("climb_set_nt_workspace", _NT_WS[key], _NT_WS[key].numel() * 4)
+    return _NT_WS[key]
+
+
 class Workspace:
     """Activation + scratch buffers for one (B, T) shape; allocated once, reused every step."""
 
@@ -206,6 +219,7 @@ class ViltEngine:
         self.grad = torch.zeros(self.layout.total, dtype=torch.float32, device=self.device)
         if self.precision == "bf16":
             tn_workspace(self.device)
+            nt_workspace(self.device)
         self._ws.clear()
         self._shadow = None
         self._shadow_version = -1

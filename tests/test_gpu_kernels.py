@@ -477,6 +477,50 @@ def test_gemm_bf16_nt_256_race_screen_full_size(N, K, force):
         _lib.call("climb_set_option", 5, 1)
 
 
+@pytest.mark.parametrize("K", [1536, 2304, 3072])
+@pytest.mark.parametrize("epi", ["none_16bit", "resid_fp32"])
+def test_gemm_bf16_nt_split_along_k_balancing(K, epi):
+    """r03: the 192-tile NT GEMMs (12288 x 768) on all 256 CUs -- four workgroups share three tiles along K and hand partial accumulator
+    tiles over through the registered scratch (system-scope stores, flags).  Against the one-workgroup-per-tile kernel (itself pinned to
+    float64 and to the two-barrier kernel bit for bit above): equal up to the different summation order of the split; and, repeated under
+    load 25 times, BIT-IDENTICAL to its own first result every time (the hand-over is a fixed-order sum: any difference is a race)."""
+    from climb_amd import _lib
+    from climb_amd.engine import nt_workspace
+    dev = _dev()
+    M, N = 12288, 768
+    g = torch.Generator(device=dev).manual_seed(K)
+    Ad = torch.randn(M, K, device=dev, generator=g).to(_h16())
+    Wd = (torch.randn(N, K, device=dev, generator=g) * 0.05).to(_h16())
+    bias = torch.randn(N, device=dev, generator=g)
+    resid = torch.randn(M, N, device=dev, generator=g) if epi == "resid_fp32" else None
+    cdt, e = (0, 2) if epi == "resid_fp32" else (1, 0)
+    mk = lambda: torch.empty(M, N, device=dev, dtype=torch.float32 if cdt == 0 else _h16())
+
+    def run(out):
+        _lib.call("climb_gemm_bf16_nt", Ad, K, Wd, K, out, N, cdt, M, N, K, bias, e, resid, N, None, 0, None, 0, _st())
+    nt_workspace(dev)
+    try:
+        _lib.call("climb_set_option", 14, 0)
+        ref = mk()
+        run(ref)
+        _lib.call("climb_set_option", 14, 1)
+        first = mk()
+        run(first)
+        torch.cuda.synchronize()
+        assert not torch.equal(first, ref) or K == 0          # (the split kernel really ran: a different summation order shows in the low bits)
+        assert _rel(first.float(), ref.float()) < (2e-6 if cdt == 0 else 1e-2)
+        rows = torch.arange(0, M, 131, device=dev)
+        r64 = Ad[rows].double() @ Wd.double().t() + bias.double() + (resid[rows].double() if resid is not None else 0.0)
+        assert _rel(first[rows].float(), r64) < (1e-5 if cdt == 0 else 1e-2)
+        out = mk()
+        for it in range(25):
+            out.fill_(float("nan"))
+            run(out)
+            assert torch.equal(out, first), f"iteration {it}: {int((out != first).sum())} elements differ from the first run"
+    finally:
+        _lib.call("climb_set_option", 14, 1)
+
+
 @pytest.mark.parametrize("M,N,K", [(64, 128, 128), (384, 768, 768), (1000, 2304, 768), (300, 768, 3072), (130, 48, 768)])
 def test_gemm_bf16_tn_weight_grad(M, N, K):
     from climb_amd import _lib
