@@ -393,7 +393,12 @@ __global__ __launch_bounds__(512) void gemm_bf16_ntsk_kernel(const bf16_t* __res
 static float* g_ntsk_ws = nullptr;
 static long g_ntsk_bytes = 0;
 static bool g_ntsk_flags_clean = false;
-static int g_ntsk_on = 1;                                    // climb_set_option 14
+// MEASURED (r03, M = 12288, same box, us): dhn (K = 3072) 67.1 -> 70.4, dxn (K = 2304) 48.0 -> 55.4, down + residual 79.5 -> 126 (this
+// instantiation spills around the partial add); in the step 10.72 -> 11.4 ms.  The k-loops do get 25 % shorter, but the hand-over costs more:
+// 192 KB of system-scope dword stores + the flag + 96 system-scope loads per lane are ~18 us, and one of the three hand-overs of a group is
+// always a tie (both sides finish at 3u), so it is fully exposed.  OFF by default; kept (with its race-screen test) as the priced answer to
+// "balance the 192-tile GEMMs along K" -- a win needs the partial in LDS before the finishing workgroup's k-loop ends, and 192 KB does not fit.
+static int g_ntsk_on = 0;                                    // climb_set_option 14
 void climb_ntsk_set_workspace(void* ptr, long bytes) { g_ntsk_ws = (float*)ptr; g_ntsk_bytes = ptr ? bytes : 0; g_ntsk_flags_clean = false; }
 void climb_ntsk_enable(int v) { g_ntsk_on = v; }
 #define NTSK_FLAGS 192

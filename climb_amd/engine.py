@@ -219,7 +219,6 @@ class ViltEngine:
         self.grad = torch.zeros(self.layout.total, dtype=torch.float32, device=self.device)
         if self.precision == "bf16":
             tn_workspace(self.device)
-            nt_workspace(self.device)
         self._ws.clear()
         self._shadow = None
         self._shadow_version = -1

@@ -34,7 +34,7 @@ int climb_device_sync(void);
  * key 7 = persistent 256-row NT tiles (0 never, 1 auto, 2 / 3 force 256 / 192 columns, 4 two-workgroup variant); key 8 = k-loop-only probe of that kernel;
  * key 9 = its grid; key 10 = persistent TN kernel (0/1); key 11 = de-phasing of the two-workgroup variant; key 12 = query blocks per wave of the
  * bf16 attention forward (0 auto, 1, 2); key 13 = bf16 attention backward as one launch (1, default) or one launch per phase (0);
- * key 14 = split-along-K balancing of the 192-tile NT GEMMs (1, default, needs climb_set_nt_workspace) */
+ * key 14 = split-along-K balancing of the 192-tile NT GEMMs (0 default: measured slower; 1 needs climb_set_nt_workspace) */
 int climb_set_option(int key, int value);
 
 /* ---- embeddings -------------------------------------------------------------------------------------------------- */
@@ -146,7 +146,7 @@ int climb_gemm_bf16_tn(const void* A, long lda, const void* B, long ldb, float* 
  * >= splits*N*K*4 bytes the partials are written as plain stores and summed by a second launch on the same stream; without one they
  * are accumulated with fp32 atomics.  64 MB covers every ViLT-B shape at 12288 tokens.  Caller-owned, stream-ordered use. */
 int climb_set_tn_workspace(void* ptr, long bytes);
-/* optional scratch for climb_gemm_bf16_nt (r03): with a registered buffer of >= climb_nt_workspace_bytes() the GEMMs that tile into exactly
+/* optional scratch for climb_gemm_bf16_nt (r03; used only under climb_set_option(14, 1)): with a registered buffer of >= climb_nt_workspace_bytes() the GEMMs that tile into exactly
  * 192 tiles of 256 x 192 with K >= 1536 (the layer's down-projection, HF:410-414, and the input gradients dhn / dxn) run on all 256 CUs --
  * four workgroups share three tiles along K and hand partial accumulator tiles over through this buffer; without it 64 CUs idle.
  * Caller-owned, stream-ordered use, one stream at a time. */

@@ -47,6 +47,9 @@ if __name__ == "__main__":
     if os.environ.get("TN_WS", "1") != "0":
         from climb_amd.engine import tn_workspace
         tn_workspace(dev)
+    if os.environ.get("NT_WS", "0") != "0":          # r03: scratch of the split-along-K NT kernel (CLIMB_AMD_OPTIONS=14=1 NT_WS=1)
+        from climb_amd.engine import nt_workspace
+        nt_workspace(dev)
     tot_t = tot_f = 0.0
     for name, N, K, cdt, epi in [("qkv fwd", 2304, 768, 1, 0), ("out fwd +res", 768, 768, 0, 2), ("up fwd gelu", 3072, 768, 1, 1), ("down fwd +res", 768, 3072, 0, 2),
                                  ("du dgelu", 3072, 768, 1, 3), ("dhn", 768, 3072, 1, 0), ("dctx", 768, 768, 1, 0), ("dxn", 768, 2304, 1, 0)]:
