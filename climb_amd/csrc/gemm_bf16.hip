@@ -388,7 +388,10 @@ static int nt_dispatch(const bf16_t* A, long lda, const bf16_t* B, long ldb, TO*
     const bool big = (long)M * N >= 2048L * 768;            // below that the 64 x 128 / 128 x 128 kernels fill the chip better
     // measured (r02, M = 12288): at K = 768 the single-round N = 768 shapes are a tie or better on the 192 x 192 three-stage kernel
     // (dctx 24.6 vs 26.9 us); from K = 2304 on the persistent kernel's k-loop wins (down 88 -> 81, dhn 74 -> 69, dxn 53 -> 51 us)
-    const bool keep192 = use192 && K < 1536;
+    // r03, after the supertile = one XCD's share fix: the persistent kernel wins or ties at K = 768 too (out-projection + residual 31.7 -> 28.2,
+    // dctx 24.6 -> 24.1 us), so the 192 x 192 kernel (and its 52 B/lane spill) is off the step's path; it still serves tile counts in [160, 256]
+    // that are not "big"
+    const bool keep192 = false;
     if (g_nt_256 >= 2 || (big && !keep192)) {
       int rc = climb_nt256_launch(bn, A, lda, B, ldb, C, ldc, sizeof(TO) == 4 ? CLIMB_DT_F32 : CLIMB_DT_BF16, M, N, K, bias, epi, aux, ldaux, aux_out, ldauxo,
                                   aux2, ldaux2, st);
