@@ -350,7 +350,8 @@ def real_input_line(dev, args):
                 os.environ["CLIMB_AMD_TOKENIZER_VOCAB"] = prev_vocab
             return {"value": round(B / out["1"], 1), "unit": "samples/s", "ms_per_step": round(out["1"] * 1e3, 2),
                     "inline_on_training_thread": {"value": round(B / out["0"], 1), "ms_per_step": round(out["0"] * 1e3, 2)},
-                    "same_step_inputs_resident_ms": round(out["resident"] * 1e3, 2), "tokens_per_sequence": out["seq"],
+                    "same_step_inputs_resident_ms": round(out["resident"] * 1e3, 2), "fraction_of_input_resident_rate": round(out["resident"] / out["1"], 3),
+                    "tokens_per_sequence": out["seq"],
                     "dataloader_workers": workers, "examples_per_step": B,
                     "note": "VQATrainer loop on 640x480 / 480x640 JPEGs: disk -> dataset/collate workers -> prefetch thread (tokeniser, raw-byte staging, "
                             "H2D, device resize/normalise/pad) -> fused step + AdamW; variable-resolution canvases, so not the fixed-384 step of `value`"}
