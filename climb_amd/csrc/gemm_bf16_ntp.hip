@@ -36,10 +36,14 @@ struct NtpStage {
   unsigned a_off[4];       // per lane: byte offset (from A) of its 4 DMA sources of the A image, k-tile 0
   unsigned b_off[NI];      // per lane: byte offset (from B) of its DMA source of B unit p
   unsigned wid;            // wave index (uniform)
+  // store-wave mode (SW): waves 0-3 stage the WHOLE images -- their own pieces and, at these byte distances, those of wave wid + 4 (A: 8
+  // pieces = 64 rows further, B: 4 pieces = the other wave column's 32 rows: same swizzle, so the same per-lane offsets serve both)
+  long da, db;
+  bool loader;             // this wave issues DMA and waits on vmcnt (SW: waves 0-3 only)
 };
 
 // issue the staging units of phase P of the body of k-tile T (D1 / D2: units of k-tile T + 1 / T + 2 are still inside the k-loop)
-template <int NI, int P, bool D1, bool D2, int K_ = 0>
+template <int NI, int P, bool D1, bool D2, int K_ = 0, bool SW = false>
 __device__ __forceinline__ void ntp_issue(const NtpStage<NI>& sg, const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
                                           unsigned char* __restrict__ smem, int T) {
   if constexpr (K_ < NTP_MAXI) {
@@ -53,22 +57,29 @@ __device__ __forceinline__ void ntp_issue(const NtpStage<NI>& sg, const bf16_t* 
         const long koff = (long)t * (GB_BK * 2);               // bytes along k: uniform, folds into the scalar base
         if constexpr (unit < 2) {
 #pragma unroll
-          for (int i = 0; i < 2; ++i)
+          for (int i = 0; i < 2; ++i) {
             __builtin_amdgcn_global_load_lds((gbl_void_t*)(reinterpret_cast<const unsigned char*>(A) + koff + sg.a_off[unit * 2 + i]),
                                              (lds_void_t*)(buf + unit * (NTP_A_BYTES / 2) + (sg.wid * 2 + i) * 1024), 16, 0, 0);
+            if constexpr (SW)
+              __builtin_amdgcn_global_load_lds((gbl_void_t*)(reinterpret_cast<const unsigned char*>(A) + koff + sg.da + sg.a_off[unit * 2 + i]),
+                                               (lds_void_t*)(buf + unit * (NTP_A_BYTES / 2) + (sg.wid * 2 + i + 8) * 1024), 16, 0, 0);
+          }
         } else {
           __builtin_amdgcn_global_load_lds((gbl_void_t*)(reinterpret_cast<const unsigned char*>(B) + koff + sg.b_off[unit - 2]),
                                            (lds_void_t*)(buf + NTP_A_BYTES + (unit - 2) * NTP_B_UNIT + sg.wid * 1024), 16, 0, 0);
+          if constexpr (SW)
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)(reinterpret_cast<const unsigned char*>(B) + koff + sg.db + sg.b_off[unit - 2]),
+                                             (lds_void_t*)(buf + NTP_A_BYTES + (unit - 2) * NTP_B_UNIT + (sg.wid + 4) * 1024), 16, 0, 0);
         }
       }
     }
-    ntp_issue<NI, P, D1, D2, K_ + 1>(sg, A, B, smem, T);
+    ntp_issue<NI, P, D1, D2, K_ + 1, SW>(sg, A, B, smem, T);
   }
 }
 
 __device__ __forceinline__ bf16x8 ntp_frag(const unsigned char* __restrict__ p) { return as_bf16x8(*reinterpret_cast<const u32x4*>(p)); }
 
-template <int NI, int P, bool D1, bool D2, int W>
+template <int NI, int P, bool D1, bool D2, int W, bool SW = false>
 __device__ __forceinline__ void ntp_phase(f32x16 (&acc)[NI][2], bf16x8 (&a)[2][4], const NtpStage<NI>& sg, const bf16_t* __restrict__ A,
                                           const bf16_t* __restrict__ B, unsigned char* __restrict__ smem, int T, const unsigned (&aoff)[4],
                                           const unsigned (&boff)[4]) {
@@ -84,8 +95,15 @@ __device__ __forceinline__ void ntp_phase(f32x16 (&acc)[NI][2], bf16x8 (&a)[2][4
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) a[jj][ks] = ntp_frag(buf + jj * 4096 + aoff[ks]);
   }
-  ntp_issue<NI, P, D1, D2>(sg, A, B, smem, T);
-  if constexpr (W >= 0) wait_vmcnt<(W < 0 ? 0 : W)>();
+  if constexpr (SW) {
+    if (sg.loader) {          // wave-uniform: waves 4-7 issue no loads and never look at vmcnt (it counts their epilogue stores only)
+      ntp_issue<NI, P, D1, D2, 0, true>(sg, A, B, smem, T);
+      if constexpr (W >= 0) wait_vmcnt<(W < 0 ? 0 : W)>();
+    }
+  } else {
+    ntp_issue<NI, P, D1, D2>(sg, A, B, smem, T);
+    if constexpr (W >= 0) wait_vmcnt<(W < 0 ? 0 : W)>();
+  }
   __builtin_amdgcn_sched_barrier(0);
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
@@ -101,26 +119,26 @@ __device__ __forceinline__ void ntp_phase(f32x16 (&acc)[NI][2], bf16x8 (&a)[2][4
 }
 
 // one k-tile; MODE 0: main loop (T <= nk - 3), 1: T = nk - 2, 2: T = nk - 1
-template <int NI, int MODE, int P = 0>
+template <int NI, int MODE, int P = 0, bool SW = false>
 __device__ __forceinline__ void ntp_ktile(f32x16 (&acc)[NI][2], bf16x8 (&a)[2][4], const NtpStage<NI>& sg, const bf16_t* __restrict__ A,
                                           const bf16_t* __restrict__ B, unsigned char* __restrict__ smem, int T, const unsigned (&aoff)[4],
                                           const unsigned (&boff)[4]) {
   if constexpr (P < NI) {
-    constexpr int W = ntp_wait(NI, 6, MODE == 0 ? 2 : (MODE == 1 ? 4 : 5), P);
-    ntp_phase<NI, P, MODE <= 1, MODE == 0, W>(acc, a, sg, A, B, smem, T, aoff, boff);
-    ntp_ktile<NI, MODE, P + 1>(acc, a, sg, A, B, smem, T, aoff, boff);
+    constexpr int W = ntp_wait(NI, 6, MODE == 0 ? 2 : (MODE == 1 ? 4 : 5), P, SW ? 2 : 1, SW ? 4 : 2);
+    ntp_phase<NI, P, MODE <= 1, MODE == 0, W, SW>(acc, a, sg, A, B, smem, T, aoff, boff);
+    ntp_ktile<NI, MODE, P + 1, SW>(acc, a, sg, A, B, smem, T, aoff, boff);
   }
 }
-template <int NI, int P = 0>
+template <int NI, int P = 0, bool SW = false>
 __device__ __forceinline__ void ntp_prologue(const NtpStage<NI>& sg, const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
                                              unsigned char* __restrict__ smem) {
   // what the bodies of k-tiles -2 and -1 would have issued, in the same order
   if constexpr (P < NI) {
-    ntp_issue<NI, P, false, true>(sg, A, B, smem, -2);
-    ntp_prologue<NI, P + 1>(sg, A, B, smem);
+    ntp_issue<NI, P, false, true, 0, SW>(sg, A, B, smem, -2);
+    ntp_prologue<NI, P + 1, SW>(sg, A, B, smem);
   } else if constexpr (P < 2 * NI) {
-    ntp_issue<NI, P - NI, true, true>(sg, A, B, smem, -1);
-    ntp_prologue<NI, P + 1>(sg, A, B, smem);
+    ntp_issue<NI, P - NI, true, true, 0, SW>(sg, A, B, smem, -1);
+    ntp_prologue<NI, P + 1, SW>(sg, A, B, smem);
   }
 }
 
@@ -163,7 +181,55 @@ __device__ __forceinline__ void ntp_epilogue(const f32x16 (&acc)[NI][2], AuxRegs
   }
 }
 
-template <typename TO, int EPI, int NI>
+// STORE-WAVE MODE (r03, SW).  On gfx9 a wave's loads and stores share one vmcnt, so a wave that has just stored its tile cannot start the
+// next tile's counted LDS-DMA waits before the stores have drained: the epilogue's HBM burst ADDS to the k-loop.
+// Here the two kinds live in different waves.  Waves 0-3 stage the whole A / B images (their own pieces and those of wave + 4: same per-lane
+// offsets, a uniform distance) and are the only ones that wait on vmcnt; waves 4-7 issue no loads in the k-loop and are the only ones that
+// store: in the epilogue every wave turns a sub-block of its accumulators through its staging region as before, a raw barrier publishes the
+// regions, and wave w + 4 drains its own region and then wave w's (same wave column: the same bias registers serve both).  Waves 4-7 never
+// wait for their stores -- they drain under the next tile's k-loop, and the hardware holds back only the next epilogue's store issue if a
+// previous tile's are still in flight.  EPI NONE / GELU only (no operand LOADS in the epilogue), whole tiles only (M % 256, N % BN).
+template <int S, typename TO, int EPI, int NI>
+__device__ __forceinline__ void ntp_epilogue_sw(const f32x16 (&acc)[NI][2], NtBias<NtpEpi<NI>::NIE> (&bb)[NtpEpi<NI>::PER_ROW], unsigned char* __restrict__ smem,
+                                                int wid, int el, int m0, int n0, int M, int N, TO* __restrict__ C, long ldc, const float* __restrict__ bias,
+                                                bf16_t* __restrict__ aux_out, long ldauxo) {
+  using E = NtpEpi<NI>;
+  if constexpr (S < E::NSB) {
+    constexpr int J = S / E::PER_ROW, H = S % E::PER_ROW;
+    const int wc = wid & 1, storer = wid >> 2;
+    unsigned char* stage = smem + wid * (E::NIE * 4096);
+    if constexpr (S == 0) {
+      if (storer) {
+#pragma unroll
+        for (int h = 0; h < E::PER_ROW; ++h) nt_bias_preload<E::NIE>(bb[h], bias, el, n0 + wc * (32 * NI) + h * E::NIE * 32, N);
+      }
+    }
+    {
+      f32x16 blk[E::NIE];
+#pragma unroll
+      for (int i = 0; i < E::NIE; ++i) blk[i] = acc[H * E::NIE + i][J];
+      nt_epi_stage<E::NIE>(blk, stage, el);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();                            // every wave's sub-block S is staged
+    __builtin_amdgcn_sched_barrier(0);
+    if (storer) {
+      AuxRegs<EPI, E::NIE * 4> none;
+      const int nw = n0 + wc * (32 * NI) + H * E::NIE * 32;
+      nt_epi_drain<TO, EPI, E::NIE, 0>(none, bb[H], stage, el, m0 + (wid >> 1) * 64 + J * 32, nw, M, N, C, ldc, aux_out, ldauxo);
+      __builtin_amdgcn_sched_barrier(0);
+      nt_epi_drain<TO, EPI, E::NIE, 0>(none, bb[H], stage - 4 * (E::NIE * 4096), el, m0 + ((wid - 4) >> 1) * 64 + J * 32, nw, M, N, C, ldc, aux_out, ldauxo);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the drains' LDS reads have returned (their global stores have only been issued)
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();                            // the staging regions may be rewritten
+    __builtin_amdgcn_sched_barrier(0);
+    ntp_epilogue_sw<S + 1, TO, EPI, NI>(acc, bb, smem, wid, el, m0, n0, M, N, C, ldc, bias, aux_out, ldauxo);
+  }
+}
+
+template <typename TO, int EPI, int NI, bool SW = false>
 __global__ __launch_bounds__(512) void gemm_bf16_ntp_kernel(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ B, long ldb,
                                                             TO* __restrict__ C, long ldc, int M, int N, int K, const float* __restrict__ bias,
                                                             const void* __restrict__ aux, long ldaux, bf16_t* __restrict__ aux_out, long ldauxo, int probe) {
@@ -190,6 +256,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_ntp_kernel(const bf16_t* __rest
     // LDS-DMA plan: a 1 KB piece = 8 rows x 8 chunks; wave w issues pieces 2w, 2w + 1 of A0 and of A1 and piece w of every B unit
     NtpStage<NI> sg;
     sg.wid = wid;
+    sg.loader = !SW || grp == 0;
+    sg.da = 64 * lda * 2;
+    sg.db = 32L * NI * ldb * 2;
 #pragma unroll
     for (int u = 0; u < 2; ++u)
 #pragma unroll
@@ -214,16 +283,23 @@ __global__ __launch_bounds__(512) void gemm_bf16_ntp_kernel(const bf16_t* __rest
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     bf16x8 a[2][4];
-    ntp_prologue<NI>(sg, A, B, smem);
-    wait_vmcnt<ntp_wait(NI, 6, -1, NI - 1)>();               // A0, A1, B_0 of k-tile 0: this wave's pieces have landed
+    if constexpr (SW) {
+      if (grp == 0) {
+        ntp_prologue<NI, 0, true>(sg, A, B, smem);
+        wait_vmcnt<ntp_wait(NI, 6, -1, NI - 1, 2, 4)>();
+      }
+    } else {
+      ntp_prologue<NI>(sg, A, B, smem);
+      wait_vmcnt<ntp_wait(NI, 6, -1, NI - 1)>();             // A0, A1, B_0 of k-tile 0: this wave's pieces have landed
+    }
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();                            // ... and everybody else's
     if (grp == 1) __builtin_amdgcn_s_barrier();              // group 1 runs one barrier behind group 0 from here on
     __builtin_amdgcn_sched_barrier(0);
     int T = 0;
-    for (; T + 2 < nk; ++T) ntp_ktile<NI, 0>(acc, a, sg, A, B, smem, T, aoff, boff);
-    ntp_ktile<NI, 1>(acc, a, sg, A, B, smem, T, aoff, boff);
-    ntp_ktile<NI, 2>(acc, a, sg, A, B, smem, T + 1, aoff, boff);
+    for (; T + 2 < nk; ++T) ntp_ktile<NI, 0, 0, SW>(acc, a, sg, A, B, smem, T, aoff, boff);
+    ntp_ktile<NI, 1, 0, SW>(acc, a, sg, A, B, smem, T, aoff, boff);
+    ntp_ktile<NI, 2, 0, SW>(acc, a, sg, A, B, smem, T + 1, aoff, boff);
     if (grp == 0) __builtin_amdgcn_s_barrier();              // re-align the groups: every wave is past its last fragment read
     __builtin_amdgcn_sched_barrier(0);
     if (probe) {          // measurement aid (climb_set_option 8): the k-loop alone, accumulators kept live, nothing stored
@@ -240,9 +316,13 @@ __global__ __launch_bounds__(512) void gemm_bf16_ntp_kernel(const bf16_t* __rest
       int el = lane;
       asm volatile("" : "+v"(el));
       NtBias<NtpEpi<NI>::NIE> bb[NtpEpi<NI>::PER_ROW];
-      AuxRegs<EPI, NtpEpi<NI>::NIE * 4> ax[NtpEpi<NI>::NSB];
-      ntp_epilogue<0, TO, EPI, NI>(acc, ax, bb, smem + wid * (NtpEpi<NI>::NIE * 4096), el, m0 + wr * 64, n0 + wc * (32 * NI), M, N, C, ldc, bias, aux,
-                                   ldaux, aux_out, ldauxo);
+      if constexpr (SW) {
+        ntp_epilogue_sw<0, TO, EPI, NI>(acc, bb, smem, wid, el, m0, n0, M, N, C, ldc, bias, aux_out, ldauxo);
+      } else {
+        AuxRegs<EPI, NtpEpi<NI>::NIE * 4> ax[NtpEpi<NI>::NSB];
+        ntp_epilogue<0, TO, EPI, NI>(acc, ax, bb, smem + wid * (NtpEpi<NI>::NIE * 4096), el, m0 + wr * 64, n0 + wc * (32 * NI), M, N, C, ldc, bias, aux,
+                                     ldaux, aux_out, ldauxo);
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();       // the staging regions are the next tile's k-tile buffers
@@ -440,6 +520,9 @@ static int ntsk_try(const bf16_t* A, long lda, const bf16_t* B, long ldb, void* 
 void climb_nt256_set_probe(int v) { g_nt256_probe = v; }      // bit 0: k-loop only; v >> 8: supertile height override (measurement)
 void climb_nt256_set_grid(int v) { g_nt256_grid = v; }
 
+static int g_ntp_sw = 1;          // climb_set_option 15: store-wave mode for the multi-round GEMMs without epilogue loads
+void climb_ntp_set_sw(int v) { g_ntp_sw = v; }
+
 template <typename TO, int EPI, int NI>
 static int ntp_launch_one(int nwg, hipStream_t st, const bf16_t* A, long lda, const bf16_t* B, long ldb, TO* C, long ldc, int M, int N, int K,
                           const float* bias, const void* aux, long ldaux, bf16_t* aux_out, long ldauxo) {
@@ -449,6 +532,21 @@ static int ntp_launch_one(int nwg, hipStream_t st, const bf16_t* A, long lda, co
     hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_ntp_kernel<TO, EPI, NI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) return (int)e;
     configured = true;
+  }
+  if constexpr (EPI == EPI_NONE || EPI == EPI_GELU) {
+    // store-wave mode where stores of one tile can hide under the next: more tiles than workgroups, whole tiles only
+    const long tiles = (long)((M + NTP_BM - 1) / NTP_BM) * ((N + 64 * NI - 1) / (64 * NI));
+    if (g_ntp_sw && !(g_nt256_probe & 1) && tiles > nwg && (M % NTP_BM) == 0 && (N % (64 * NI)) == 0) {
+      static bool configured_sw = false;
+      if (!configured_sw) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_ntp_kernel<TO, EPI, NI, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) return (int)e;
+        configured_sw = true;
+      }
+      hipLaunchKernelGGL((gemm_bf16_ntp_kernel<TO, EPI, NI, true>), dim3(nwg), dim3(512), LDS, st, A, lda, B, ldb, C, ldc, M, N, K, bias, aux, ldaux, aux_out,
+                         ldauxo, g_nt256_probe);
+      return CLIMB_OK;
+    }
   }
   hipLaunchKernelGGL((gemm_bf16_ntp_kernel<TO, EPI, NI>), dim3(nwg), dim3(512), LDS, st, A, lda, B, ldb, C, ldc, M, N, K, bias, aux, ldaux, aux_out,
                      ldauxo, g_nt256_probe);

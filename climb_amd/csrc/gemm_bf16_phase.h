@@ -34,7 +34,7 @@ constexpr int ntp_sched(int NI, int p, int k) {
   return t[p][k];
 #undef U_
 }
-constexpr int ntp_nglds(int unit, int gb = 1) { return unit < 2 ? 2 : gb; }      // DMA instructions per lane: A halves 2; a B unit 1 (8 waves) or 2 (4 waves)
+constexpr int ntp_nglds(int unit, int gb = 1, int ga = 2) { return unit < 2 ? ga : gb; }      // DMA instructions per lane: A halves 2 (4 when four waves stage a 256-row image); a B unit 1 (8 waves) or 2 (4 waves)
 // is (unit, tile t) read by the phase that FOLLOWS phase p of k-tile T?
 constexpr bool ntp_needed_next(int NI, int T, int p, int unit, int t) {
   if (p + 1 < NI) return t == T && unit == 2 + p + 1;
@@ -42,7 +42,7 @@ constexpr bool ntp_needed_next(int NI, int T, int p, int unit, int t) {
 }
 // vmcnt for the wait in phase p of k-tile T (after that phase's own issues) when the k-loop has nk tiles; -1 = nothing to wait for.
 // T = -1, p = NI - 1 is the prologue's wait.
-constexpr int ntp_wait(int NI, int nk, int T, int p, int gb = 1) {
+constexpr int ntp_wait(int NI, int nk, int T, int p, int gb = 1, int ga = 2) {
   int cum = 0, need_end = -1;
   for (int Tb = -2; Tb <= T; ++Tb)
     for (int pb = 0; pb < NI; ++pb) {
@@ -52,7 +52,7 @@ constexpr int ntp_wait(int NI, int nk, int T, int p, int gb = 1) {
         if (e < 0) continue;
         const int unit = e / 4, t = Tb + e % 4;
         if (t < 0 || t >= nk) continue;
-        cum += ntp_nglds(unit, gb);
+        cum += ntp_nglds(unit, gb, ga);
         if (ntp_needed_next(NI, T, p, unit, t)) need_end = cum;
       }
     }
