@@ -520,7 +520,11 @@ static int ntsk_try(const bf16_t* A, long lda, const bf16_t* B, long ldb, void* 
 void climb_nt256_set_probe(int v) { g_nt256_probe = v; }      // bit 0: k-loop only; v >> 8: supertile height override (measurement)
 void climb_nt256_set_grid(int v) { g_nt256_grid = v; }
 
-static int g_ntp_sw = 1;          // climb_set_option 15: store-wave mode for the multi-round GEMMs without epilogue loads
+// MEASURED (r03, M = 12288, same box): QKV 51.6 -> 57.2 us, up-projection + GELU 82.4 -> 93.3 us, step 10.51 -> 10.71 ms.  The stores do
+// leave the loading waves' vmcnt, but (i) waves 4-7 now drain two regions each while waves 0-3 idle at the barriers (the k-buffers ARE the
+// staging regions: the next tile's DMA cannot start before the drains have read them), and (ii) the k-loop runs slower next to the write
+// stream (the r01 probe said the same of a concurrent fill).  OFF by default; bit-exact under the race screens of tests/test_gpu_kernels.py.
+static int g_ntp_sw = 0;          // climb_set_option 15: store-wave mode for the multi-round GEMMs without epilogue loads
 void climb_ntp_set_sw(int v) { g_ntp_sw = v; }
 
 template <typename TO, int EPI, int NI>

@@ -34,7 +34,8 @@ int climb_device_sync(void);
  * key 7 = persistent 256-row NT tiles (0 never, 1 auto, 2 / 3 force 256 / 192 columns, 4 two-workgroup variant); key 8 = k-loop-only probe of that kernel;
  * key 9 = its grid; key 10 = persistent TN kernel (0/1); key 11 = de-phasing of the two-workgroup variant; key 12 = query blocks per wave of the
  * bf16 attention forward (0 auto, 1, 2); key 13 = bf16 attention backward as one launch (1, default) or one launch per phase (0);
- * key 14 = split-along-K balancing of the 192-tile NT GEMMs (0 default: measured slower; 1 needs climb_set_nt_workspace) */
+ * key 14 = split-along-K balancing of the 192-tile NT GEMMs (0 default: measured slower; 1 needs climb_set_nt_workspace);
+ * key 15 = store-wave mode of the persistent NT kernel (0 default: measured slower) */
 int climb_set_option(int key, int value);
 
 /* ---- embeddings -------------------------------------------------------------------------------------------------- */
