@@ -786,8 +786,8 @@ class ViltEngine:
             if len(group) >= G and not last_group:
                 self._dw_flush(ws, pending)
                 self._red_flush(ws, pending_red)
-                for j in group:
-                    self._ready(*lay.layer_range[j])
+                # the group's layers are adjacent in the flat buffer: ONE range (under data parallelism: one 4-layer collective, not four)
+                self._ready(lay.layer_range[min(group)][0], lay.layer_range[max(group)][1])
                 group = []
         do_emb = embeddings and first_layer == 0
         if do_emb:
@@ -795,8 +795,8 @@ class ViltEngine:
         if G:
             self._dw_flush(ws, pending)
             self._red_flush(ws, pending_red)
-            for j in group:
-                self._ready(*lay.layer_range[j])
+            if group:
+                self._ready(lay.layer_range[min(group)][0], lay.layer_range[max(group)][1])
         if do_emb:
             self._ready(*lay.embed_range)
         self.saved = None          # the activations are consumed: a later no-grad forward may use this workspace again
