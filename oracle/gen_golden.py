@@ -94,8 +94,14 @@ def case_single_image(task, tasks, B, fname, ragged=False, wseed=42, dseed=1):
 VARRES_SIZES = [(384, 512), (288, 384), (384, 384), (352, 640)]      # (H, W) multiples of 32, shortest edge <= 384, longest <= 640
 
 
-def case_varres(fname, tasks=("vqa", "nlvr2"), wseed=42, dseed=9):
+# 16 COCO-like images of BOTH orientations (what every real VQA batch looks like, and what bench.py's real_input leg trains on): the padded
+# canvas is 640 x 640 = 400 patches, no image has more than 240 valid ones -- the reference keeps max_b(h w) rows (HF:131-159)
+MIXED_SIZES = [(384, 512), (512, 384), (384, 384), (352, 640), (640, 352), (384, 576), (576, 384), (320, 384)] * 2
+
+
+def case_varres(fname, tasks=("vqa", "nlvr2"), wseed=42, dseed=9, sizes=None):
     """Row F2: padded variable-resolution batch through the reference's own masked visual_embed (random patch selection)."""
+    VARRES_SIZES = sizes or globals()["VARRES_SIZES"]
     print(f"[{fname}] variable-resolution batch {VARRES_SIZES}")
     tasks = list(tasks)
     B = len(VARRES_SIZES)
@@ -589,6 +595,9 @@ def main():
     torch.set_num_threads(os.cpu_count() or 8)
     if len(sys.argv) > 1 and sys.argv[1] == "varres":
         case_varres("vqa_b4_varres.npz")
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "mixed":
+        case_varres("vqa_b16_mixed.npz", dseed=10, sizes=MIXED_SIZES)
         return
     if len(sys.argv) > 1 and sys.argv[1] == "cl_eval":
         case_cl_eval()
