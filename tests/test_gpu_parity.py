@@ -898,7 +898,7 @@ def test_variable_resolution_batch_vs_reference(golden_dir, precision, tol, fixt
     every canvas patch in raster order and masks the invalid ones; the reference shuffles and pads randomly.  Pooled output,
     logits, loss and all gradients must agree (golden = the reference's own run).  `vqa_b16_mixed` (r03): 16 COCO-like images of BOTH
     orientations -- a 640 x 640 canvas of 400 patches of which no image fills more than 240, so the engine PACKS each sample's valid patches
-    (281-token sequences, S_pad = 288: the shape bench.py's real_input leg trains on), against the reference's own run of that batch."""
+    (261-token sequences, S_pad = 288: the shape bench.py's real_input leg trains on), against the reference's own run of that batch."""
     z = np.load(os.path.join(golden_dir, fixture))
     m = _meta(z)
     sizes = [tuple(int(v) for v in r) for r in z["sizes"]]
@@ -927,7 +927,7 @@ def test_variable_resolution_batch_vs_reference(golden_dir, precision, tol, fixt
                 _close(G[n], oG[n], tol, n)          # incl. the transpose of the bilinear position resize
         else:
             ws = model._host._engine.last_ws
-            assert ws.compact and ws.NS == 240 and ws.S_pad == 288
+            assert ws.compact and ws.NP == 400 and ws.NS == 220 and ws.S_pad == 288          # 11 x 20 patches at most, packed
     else:
         big = z["grad_norms"] > 1e-3 * z["grad_norms"].max()
         assert (np.abs(norms - z["grad_norms"])[big] / z["grad_norms"][big]).max() < 6e-2
