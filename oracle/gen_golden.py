@@ -285,6 +285,42 @@ def case_nlvr2(fname, b=2, tasks=("vqa", "nlvr2"), wseed=42, dseed=3):
                         meta=np.array([f"task=nlvr2;tasks={','.join(tasks)};b={b};wseed={wseed};dseed={dseed}"]))
 
 
+NLVR2_VARRES_SIZES = [(384, 512), (512, 384), (384, 384), (352, 640), (640, 352), (320, 384), (384, 576), (576, 384)]      # image j of example i = row 2 i + j
+
+
+def case_nlvr2_varres(fname, tasks=("vqa", "nlvr2"), wseed=42, dseed=14):
+    """NLVR2 on real-world-shaped inputs: two images per example, every image its own resolution and orientation on one padded canvas, ragged
+    text.  The reference flattens the images through ONE processor call and runs two encoder passes (image 0 of every example with
+    image_token_type_idx 1, then image 1 with 2: REF/modeling/vilt.py:281-304), each with its own max_b(h w) patch count."""
+    sizes = NLVR2_VARRES_SIZES
+    b = len(sizes) // 2
+    print(f"[{fname}] NLVR2, {b} examples x 2 variable-resolution images {sizes}")
+    tasks = list(tasks)
+    P = vo.init_params(tasks, wseed)
+    e1 = vo.synthetic_varres_encodings(sizes, seed=dseed)
+    enc = dict(input_ids=e1["input_ids"][:b], token_type_ids=e1["token_type_ids"][:b], attention_mask=e1["attention_mask"][:b],
+               pixel_values=e1["pixel_values"], pixel_mask=e1["pixel_mask"])
+    labels = torch.from_numpy(np.random.default_rng([dseed, 13]).integers(0, 2, size=(b,), dtype=np.int64))
+    model = ri.build_reference_learner(tasks, P)
+    model.train()
+    trainer = ri.make_trainer("nlvr2")
+    batch = {"raw_texts": [""] * b, "images": [[None, None]] * b, "labels": labels}
+    model.zero_grad()
+    loss, (pooled, logits), _, _ = run_ref_step(model, trainer, enc, batch)
+    G = ref_grads(model)
+    o_loss, (o_pooled, o_logits), _, o_G = vo.train_step(P, "nlvr2", enc, labels)
+    check("pooled", o_pooled, pooled, 2e-5)
+    check("logits", o_logits, logits, 2e-5)
+    check("loss", o_loss, loss, 2e-5)
+    gn, gh = tensor_summary(G)
+    on, _ = tensor_summary({n: o_G[n] for n in G})
+    check("grad norms", on, gn, 1e-4)
+    np.savez_compressed(os.path.join(OUT, fname), pooled=pooled.detach().numpy(), logits=logits.detach().numpy(),
+                        loss=np.float64(loss.item()), labels=labels.numpy(), sizes=np.array(sizes),
+                        grad_names=np.array(list(G.keys())), grad_norms=gn, grad_heads=gh,
+                        meta=np.array([f"task=nlvr2;tasks={','.join(tasks)};b={b};wseed={wseed};dseed={dseed};varres=1"]))
+
+
 def case_vcr(fname, b=2, tasks=("snli-ve", "vcr"), wseed=42, dseed=4):
     """VCR multi-choice, eval mode (the head's Dropout(0.1) is the only stochastic op on the path)."""
     print(f"[{fname}] VCR four-choice forward/backward (eval mode)")
@@ -595,6 +631,9 @@ def main():
     torch.set_num_threads(os.cpu_count() or 8)
     if len(sys.argv) > 1 and sys.argv[1] == "varres":
         case_varres("vqa_b4_varres.npz")
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "nlvr2_varres":
+        case_nlvr2_varres("nlvr2_b4_varres.npz")
         return
     if len(sys.argv) > 1 and sys.argv[1] == "mixed":
         case_varres("vqa_b16_mixed.npz", dseed=10, sizes=MIXED_SIZES)

@@ -141,6 +141,36 @@ def test_nlvr2_two_images(golden_dir):
     _close(heads, z["grad_heads"], TOL, "grad heads")
 
 
+@pytest.mark.parametrize("precision,tol", [("fp32", TOL), (H16, BF16_TOL)])
+def test_nlvr2_two_variable_resolution_images_vs_reference(golden_dir, precision, tol):
+    """NLVR2 as it arrives in practice (r03 fixture from the reference): two images per example, every image its own resolution and
+    orientation on one padded canvas, ragged text.  The reference runs two encoder passes with their own patch counts
+    (REF/modeling/vilt.py:281-304); here all 2b sequences are ONE packed batch with per-row image_token_type_idx."""
+    z = np.load(os.path.join(golden_dir, "nlvr2_b4_varres.npz"))
+    m = _meta(z)
+    b = int(m["b"])
+    sizes = [tuple(int(v) for v in r) for r in z["sizes"]]
+    model, P = make_model(m["tasks"].split(","), int(m["wseed"]), precision=precision)
+    e1 = vo.synthetic_varres_encodings(sizes, seed=int(m["dseed"]))
+    texts = dict(input_ids=e1["input_ids"][:b], token_type_ids=e1["token_type_ids"][:b], attention_mask=e1["attention_mask"][:b])
+    images = dict(pixel_values=e1["pixel_values"], pixel_mask=e1["pixel_mask"])
+    model.train()
+    loss, (pooled, logits), _, _ = model.fused_forward_backward("nlvr2", images, texts, torch.from_numpy(z["labels"]))
+    _close(pooled, z["pooled"], tol, "pooled")
+    _close(logits, z["logits"], tol, "logits")
+    _close(loss, z["loss"], tol, "loss")
+    G = grads_of(model)
+    names = [str(n) for n in z["grad_names"]]
+    norms, heads = _summary(G, names)
+    if precision == "fp32":
+        assert np.array_equal(logits.argmax(-1).cpu().numpy(), z["logits"].argmax(-1))
+        _close(norms, z["grad_norms"], tol, "grad norms")
+        _close(heads, z["grad_heads"], tol, "grad heads")
+    else:
+        big = z["grad_norms"] > 1e-3 * z["grad_norms"].max()
+        assert (np.abs(norms - z["grad_norms"])[big] / z["grad_norms"][big]).max() < 6e-2
+
+
 def test_vcr_four_choices_eval(golden_dir):
     z = np.load(os.path.join(golden_dir, "vcr_b2.npz"))
     m = _meta(z)
