@@ -141,7 +141,7 @@ def test_nlvr2_two_images(golden_dir):
     _close(heads, z["grad_heads"], TOL, "grad heads")
 
 
-@pytest.mark.parametrize("precision,tol", [("fp32", TOL), (H16, BF16_TOL)])
+@pytest.mark.parametrize("precision,tol", [("fp32", TOL), (H16, 3e-2)])
 def test_nlvr2_two_variable_resolution_images_vs_reference(golden_dir, precision, tol):
     """NLVR2 as it arrives in practice (r03 fixture from the reference): two images per example, every image its own resolution and
     orientation on one padded canvas, ragged text.  The reference runs two encoder passes with their own patch counts
