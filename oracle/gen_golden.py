@@ -321,6 +321,71 @@ def case_nlvr2_varres(fname, tasks=("vqa", "nlvr2"), wseed=42, dseed=14):
                         meta=np.array([f"task=nlvr2;tasks={','.join(tasks)};b={b};wseed={wseed};dseed={dseed};varres=1"]))
 
 
+def case_snlive_640(fname="snlive_b4_640.npz", tasks=("snli-ve", "vcr"), B=4, wseed=42, dseed=15):
+    """SNLI-VE as CLiMB feeds it: Flickr30K images are resized to exactly 384 x 640 (REF/data/image_datasets/flickr30kimages_dataset.py:51), so
+    every sequence has the maximum 12 x 20 = 240 patches: 40 + 1 + 240 = 281 tokens, ragged text."""
+    print(f"[{fname}] SNLI-VE, {B} images of 384 x 640 (281-token sequences)")
+    tasks = list(tasks)
+    P = vo.init_params(tasks, wseed)
+    enc = vo.synthetic_varres_encodings([(384, 640)] * B, seed=dseed)
+    target = torch.from_numpy(np.random.default_rng([dseed, 13]).integers(0, 3, size=(B,), dtype=np.int64))
+    model = ri.build_reference_learner(tasks, P)
+    model.train()
+    trainer = ri.make_trainer("snli-ve")
+    batch = {"raw_texts": [""] * B, "images": None, "labels": target}
+    model.zero_grad()
+    loss, (pooled, logits), _, _ = run_ref_step(model, trainer, enc, batch)
+    G = ref_grads(model)
+    o_loss, (o_pooled, o_logits), _, o_G = vo.train_step(P, "snli-ve", enc, target)
+    check("pooled", o_pooled, pooled, 2e-5)
+    check("logits", o_logits, logits, 2e-5)
+    check("loss", o_loss, loss, 2e-5)
+    gn, gh = tensor_summary(G)
+    on, _ = tensor_summary({n: o_G[n] for n in G})
+    check("grad norms", on, gn, 1e-4)
+    np.savez_compressed(os.path.join(OUT, fname), pooled=pooled.detach().numpy(), logits=logits.detach().numpy(), loss=np.float64(loss.item()),
+                        labels=target.numpy(), grad_names=np.array(list(G.keys())), grad_norms=gn, grad_heads=gh,
+                        meta=np.array([f"task=snli-ve;tasks={','.join(tasks)};B={B};wseed={wseed};dseed={dseed};size=384x640"]))
+
+
+VCR_VARRES_SIZES = [(384, 512), (512, 384), (352, 640)]
+
+
+def case_vcr_varres(fname="vcr_b3_varres.npz", tasks=("snli-ve", "vcr"), wseed=42, dseed=16):
+    """VCR on variable-resolution images: four answer choices per question over the SAME image (REF/modeling/vilt.py:331-347), eval mode."""
+    sizes = VCR_VARRES_SIZES
+    b = len(sizes)
+    print(f"[{fname}] VCR, {b} variable-resolution images x 4 choices {sizes}")
+    tasks = list(tasks)
+    P = vo.init_params(tasks, wseed)
+    ei = vo.synthetic_varres_encodings(sizes, seed=dseed)
+    et = vo.synthetic_encodings(4 * b, seed=dseed, ragged_text=True)
+    enc = dict(input_ids=et["input_ids"], token_type_ids=et["token_type_ids"], attention_mask=et["attention_mask"],
+               pixel_values=ei["pixel_values"], pixel_mask=ei["pixel_mask"])
+    labels = torch.from_numpy(np.random.default_rng([dseed, 13]).integers(0, 4, size=(b,), dtype=np.int64))
+    model = ri.build_reference_learner(tasks, P)
+    model.eval()
+    trainer = ri.make_trainer("vcr")
+    batch = {"raw_texts": [[""] * 4] * b, "images": [None] * b, "labels": labels}
+    model.zero_grad()
+    loss, (pooled, logits), _, _ = run_ref_step(model, trainer, enc, batch)
+    G = ref_grads(model)
+    leaves = {n: P[n].clone().requires_grad_(True) for n in P}
+    o_pooled, o_logits = vo.learner_forward(leaves, "vcr", enc, training=False)
+    o_loss = vo.ce_loss(o_logits, labels)
+    o_loss.backward()
+    o_G = {n: leaves[n].grad for n in G}
+    check("pooled", o_pooled, pooled, 2e-5)
+    check("logits", o_logits, logits, 2e-5)
+    check("loss", o_loss, loss, 2e-5)
+    gn, gh = tensor_summary(G)
+    on, _ = tensor_summary(o_G)
+    check("grad norms", on, gn, 1e-4)
+    np.savez_compressed(os.path.join(OUT, fname), pooled=pooled.detach().numpy(), logits=logits.detach().numpy(), loss=np.float64(loss.item()),
+                        labels=labels.numpy(), sizes=np.array(sizes), grad_names=np.array(list(G.keys())), grad_norms=gn, grad_heads=gh,
+                        meta=np.array([f"task=vcr;tasks={','.join(tasks)};b={b};wseed={wseed};dseed={dseed};varres=1;eval=1"]))
+
+
 def case_vcr(fname, b=2, tasks=("snli-ve", "vcr"), wseed=42, dseed=4):
     """VCR multi-choice, eval mode (the head's Dropout(0.1) is the only stochastic op on the path)."""
     print(f"[{fname}] VCR four-choice forward/backward (eval mode)")
@@ -631,6 +696,10 @@ def main():
     torch.set_num_threads(os.cpu_count() or 8)
     if len(sys.argv) > 1 and sys.argv[1] == "varres":
         case_varres("vqa_b4_varres.npz")
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "realshapes":
+        case_snlive_640()
+        case_vcr_varres()
         return
     if len(sys.argv) > 1 and sys.argv[1] == "nlvr2_varres":
         case_nlvr2_varres("nlvr2_b4_varres.npz")

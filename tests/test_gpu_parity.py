@@ -171,6 +171,46 @@ def test_nlvr2_two_variable_resolution_images_vs_reference(golden_dir, precision
         assert (np.abs(norms - z["grad_norms"])[big] / z["grad_norms"][big]).max() < 6e-2
 
 
+@pytest.mark.parametrize("precision,tol", [("fp32", TOL), (H16, 3e-2)])
+@pytest.mark.parametrize("fixture", ["snlive_b4_640.npz", "vcr_b3_varres.npz"])
+def test_tasks_at_their_real_input_shapes_vs_reference(golden_dir, fixture, precision, tol):
+    """r03 fixtures from the reference at the shapes CLiMB's loaders actually produce: SNLI-VE's Flickr30K images are resized to exactly
+    384 x 640 (REF/data/image_datasets/flickr30kimages_dataset.py:51): every sequence has the maximum 240 patches, 281 tokens; VCR's four
+    answer choices run over the SAME variable-resolution image (REF/modeling/vilt.py:331-347; eval mode, the train-mode dropout has its own
+    fixture)."""
+    z = np.load(os.path.join(golden_dir, fixture))
+    m = _meta(z)
+    task = m["task"]
+    model, P = make_model(m["tasks"].split(","), int(m["wseed"]), precision=precision)
+    if task == "snli-ve":
+        B = int(m["B"])
+        enc = vo.synthetic_varres_encodings([(384, 640)] * B, seed=int(m["dseed"]))
+        model.train()
+    else:
+        sizes = [tuple(int(v) for v in r) for r in z["sizes"]]
+        ei = vo.synthetic_varres_encodings(sizes, seed=int(m["dseed"]))
+        et = vo.synthetic_encodings(4 * len(sizes), seed=int(m["dseed"]), ragged_text=True)
+        enc = dict(input_ids=et["input_ids"], token_type_ids=et["token_type_ids"], attention_mask=et["attention_mask"],
+                   pixel_values=ei["pixel_values"], pixel_mask=ei["pixel_mask"])
+        model.eval()
+    texts = dict(input_ids=enc["input_ids"], token_type_ids=enc["token_type_ids"], attention_mask=enc["attention_mask"])
+    images = dict(pixel_values=enc["pixel_values"], pixel_mask=enc["pixel_mask"])
+    loss, (pooled, logits), _, _ = model.fused_forward_backward(task, images, texts, torch.from_numpy(z["labels"]))
+    _close(pooled, z["pooled"], tol, "pooled")
+    _close(logits, z["logits"], tol, "logits")
+    _close(loss, z["loss"], tol, "loss")
+    G = grads_of(model)
+    names = [str(n) for n in z["grad_names"]]
+    norms, heads = _summary(G, names)
+    if precision == "fp32":
+        assert np.array_equal(logits.argmax(-1).cpu().numpy(), z["logits"].argmax(-1))
+        _close(norms, z["grad_norms"], tol, "grad norms")
+        _close(heads, z["grad_heads"], tol, "grad heads")
+    else:
+        big = z["grad_norms"] > 1e-3 * z["grad_norms"].max()
+        assert (np.abs(norms - z["grad_norms"])[big] / z["grad_norms"][big]).max() < 6e-2
+
+
 def test_vcr_four_choices_eval(golden_dir):
     z = np.load(os.path.join(golden_dir, "vcr_b2.npz"))
     m = _meta(z)
