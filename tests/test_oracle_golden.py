@@ -305,3 +305,31 @@ def test_viltbert_train_mode_with_the_references_bert_dropout_masks(golden_dir):
     _close(vo.vqa_loss(logits, vo.synthetic_vqa_targets(B, seed=int(m["dseed"]))), z["loss"], 2e-5, "loss")
     d = json.load(open(os.path.join(golden_dir, "viltbert_train_dropout.json")))
     assert 0.3 < d["mean_feature_rel_rms"] < 0.9 and d["mean_grad_rel_l2"] > 0.3 and len(d["rows"]) >= 8
+
+
+@pytest.mark.parametrize("fixture", ["nlvr2_b4_varres.npz", "snlive_b4_640.npz", "vcr_b3_varres.npz"])
+def test_oracle_at_the_loaders_real_input_shapes(golden_dir, fixture):
+    """r03 fixtures (the reference's own steps on variable-resolution / 384 x 640 inputs for NLVR2, SNLI-VE, VCR): the CPU oracle reproduces
+    pooled, logits and loss (its gradients were checked against the reference's when the fixtures were generated, oracle/gen_golden.py)."""
+    z = np.load(os.path.join(golden_dir, fixture))
+    m = _meta(z)
+    task = m["task"]
+    P = vo.init_params(m["tasks"].split(","), int(m["wseed"]))
+    if task == "snli-ve":
+        enc = vo.synthetic_varres_encodings([(384, 640)] * int(m["B"]), seed=int(m["dseed"]))
+    else:
+        sizes = [tuple(int(v) for v in r) for r in z["sizes"]]
+        ei = vo.synthetic_varres_encodings(sizes, seed=int(m["dseed"]))
+        if task == "nlvr2":
+            b = int(m["b"])
+            enc = dict(input_ids=ei["input_ids"][:b], token_type_ids=ei["token_type_ids"][:b], attention_mask=ei["attention_mask"][:b],
+                       pixel_values=ei["pixel_values"], pixel_mask=ei["pixel_mask"])
+        else:
+            et = vo.synthetic_encodings(4 * len(sizes), seed=int(m["dseed"]), ragged_text=True)
+            enc = dict(input_ids=et["input_ids"], token_type_ids=et["token_type_ids"], attention_mask=et["attention_mask"],
+                       pixel_values=ei["pixel_values"], pixel_mask=ei["pixel_mask"])
+    with torch.no_grad():
+        pooled, logits = vo.learner_forward(P, task, enc, training=False)
+    _close(pooled, z["pooled"], 2e-5, "pooled")
+    _close(logits, z["logits"], 2e-5, "logits")
+    _close(vo.ce_loss(logits, torch.from_numpy(z["labels"])), z["loss"], 2e-5, "loss")
