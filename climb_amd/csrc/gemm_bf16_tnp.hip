@@ -361,6 +361,9 @@ struct TnGroupProblem {      // 72 bytes; include/climb_hip.h documents this lay
 };
 struct TnGroupItem { int prob, tn, tk, kt0, kt1, partial, r0, r1; };      // 32 bytes; reduction tiles [kt0, kt1) of 64 tokens, kt1 - kt0 >= 2
 
+// RAGGED: N, K any multiples of 8 (the adapters' 768 x 48 / 48 x 768 gradients ride in the same launch as 256 x 256 tiles whose surplus
+// columns are computed on clamped addresses and never stored -- the FLOPs of those GEMMs are nothing, their launches and operand reads were).
+template <bool RAGGED>
 __global__ __launch_bounds__(512) void gemm_bf16_tn_grouped_kernel(const TnGroupProblem* __restrict__ probs, const TnGroupItem* __restrict__ items,
                                                                    const int* __restrict__ first) {
   constexpr int NI = 4, BK_ = 256;
@@ -385,7 +388,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_tn_grouped_kernel(const TnGroup
     const int tn = __builtin_amdgcn_readfirstlane(item.tn), tk = __builtin_amdgcn_readfirstlane(item.tk);
     const int kt0 = __builtin_amdgcn_readfirstlane(item.kt0), nk = __builtin_amdgcn_readfirstlane(item.kt1) - kt0;
     const bool partial = __builtin_amdgcn_readfirstlane(item.partial) != 0;
-    const int N = P.N, K = P.K, nbk = K / BK_;
+    const int N = P.N, K = P.K, nbk = (K + BK_ - 1) / BK_;
     const long lda = P.lda, ldb = P.ldb, ldc = P.ldc;
     const int n0 = tn * NTP_BM, k0 = tk * BK_;
     const long a_tile = 64 * lda * 2, b_tile = 64 * ldb * 2;
@@ -398,12 +401,16 @@ __global__ __launch_bounds__(512) void gemm_bf16_tn_grouped_kernel(const TnGroup
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int slot = (wid * 2 + i) * 64 + lane, r = u * 32 + (slot >> 5), c = (slot & 31) ^ tnp_aswz(r);
-        sg.a_off[u * 2 + i] = (unsigned)(((long)r * lda + n0 + c * 8) * 2);
+        int col = n0 + c * 8;
+        if (RAGGED) col = col < N ? col : N - 8;                        // clamped columns are computed but never stored
+        sg.a_off[u * 2 + i] = (unsigned)(((long)r * lda + col) * 2);
       }
 #pragma unroll
     for (int p = 0; p < NI; ++p) {
       const int slot = wid * 64 + lane, r = slot >> 3, c = (slot & 7) ^ tnp_bswz(r);
-      sg.b_off[p] = (unsigned)(((long)r * ldb + k0 + (c >> 2) * (32 * NI) + p * 32 + (c & 3) * 8) * 2);
+      int col = k0 + (c >> 2) * (32 * NI) + p * 32 + (c & 3) * 8;
+      if (RAGGED) col = col < K ? col : K - 8;
+      sg.b_off[p] = (unsigned)(((long)r * ldb + col) * 2);
     }
     f32x16 acc[NI][2];
 #pragma unroll
@@ -429,7 +436,22 @@ __global__ __launch_bounds__(512) void gemm_bf16_tn_grouped_kernel(const TnGroup
     if (grp == 0) __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     float* Cb = P.C + (long)(n0 + wr * 64 + 4 * half) * ldc + k0 + wc * (32 * NI) + l31;
-    if (partial) {
+    if (RAGGED) {          // element guards; tiles this narrow are few and tiny next to their 192-tile reductions
+      const int nb = n0 + wr * 64 + 4 * half, kb = k0 + wc * (32 * NI) + l31;
+#pragma unroll
+      for (int p = 0; p < NI; ++p)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int dn = j * 32 + (r & 3) + 8 * (r >> 2);
+            if (nb + dn < N && kb + p * 32 < K) {
+              float* cp = Cb + (long)dn * ldc + p * 32;
+              if (partial) atomicAdd(cp, acc[p][j][r]);
+              else *cp += acc[p][j][r];
+            }
+          }
+    } else if (partial) {
 #pragma unroll
       for (int p = 0; p < NI; ++p)
 #pragma unroll
@@ -454,7 +476,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_tn_grouped_kernel(const TnGroup
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const float s = bsum[j] + __shfl_xor(bsum[j], 32, 64);
-        if (half == 0) atomicAdd(P.dbias + n0 + wr * 64 + j * 32 + l31, s);
+        if (half == 0 && (!RAGGED || n0 + wr * 64 + j * 32 + l31 < N)) atomicAdd(P.dbias + n0 + wr * 64 + j * 32 + l31, s);
       }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -464,7 +486,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_tn_grouped_kernel(const TnGroup
 }
 
 // Host-side planner (no device work).  M[p] % 128 == 0 (whole 64-token reduction tiles, an even number of them, so that every cut of the
-// stream-K tail leaves >= 2 tiles on both sides), N[p] % 256 == 0, K[p] % 256 == 0.  Workgroup b of `nwg` (a multiple of 8: XCD = b % 8)
+// stream-K tail leaves >= 2 tiles on both sides), N[p] % 8 == 0, K[p] % 8 == 0 (anything that is not a multiple of 256 needs the launch's
+// `ragged` flag).  Workgroup b of `nwg` (a multiple of 8: XCD = b % 8)
 // gets items first[b] .. first[b + 1] - 1.  Returns the number of items written, CLIMB_EINVAL for shapes outside the contract, or
 // CLIMB_EUNSUPPORTED when `cap` items do not suffice (at most tiles + nwg + 1 are ever needed).
 extern "C" int climb_tn_grouped_plan(int nprob, const int* M, const int* N, const int* K, int nwg, int* items_out, int cap, int* first_out) {
@@ -472,14 +495,14 @@ extern "C" int climb_tn_grouped_plan(int nprob, const int* M, const int* N, cons
   struct Tile { int prob, tn, tk, nkt; };
   long ntiles = 0;
   for (int p = 0; p < nprob; ++p) {
-    if (M[p] < 128 || (M[p] % 128) || N[p] <= 0 || (N[p] % 256) || K[p] <= 0 || (K[p] % 256)) return CLIMB_EINVAL;
-    ntiles += (long)(N[p] / 256) * (K[p] / 256);
+    if (M[p] < 128 || (M[p] % 128) || N[p] < 8 || (N[p] % 8) || K[p] < 8 || (K[p] % 8)) return CLIMB_EINVAL;
+    ntiles += (long)((N[p] + 255) / 256) * ((K[p] + 255) / 256);
   }
   if (ntiles + nwg + 1 > cap) return CLIMB_EUNSUPPORTED;
   Tile* tiles = new Tile[ntiles];
   long t = 0;
   for (int p = 0; p < nprob; ++p) {
-    const int nbn = N[p] / 256, nbk = K[p] / 256;
+    const int nbn = (N[p] + 255) / 256, nbk = (K[p] + 255) / 256;
     for (int i = 0; i < nbn * nbk; ++i) {
       // consecutive tiles (= the CUs of one XCD) walk the narrower operand fastest: the XCD's L2 re-reads the smaller panels
       Tile x;
@@ -543,17 +566,23 @@ extern "C" int climb_tn_grouped_plan(int nprob, const int* M, const int* N, cons
 
 // probs: TnGroupProblem[...] in device memory, items / first: the planner's tables copied to device memory (ints).  nwg workgroups
 // (what the plan was made for; 256 on MI355X).
-extern "C" int climb_gemm_bf16_tn_grouped(const void* probs, const void* items, const void* first, int nwg, void* stream) {
+extern "C" int climb_gemm_bf16_tn_grouped(const void* probs, const void* items, const void* first, int nwg, int ragged, void* stream) {
   if (!probs || !items || !first || nwg <= 0) return CLIMB_EINVAL;
   constexpr int LDS = 2 * (NTP_A_BYTES + 4 * NTP_B_UNIT);
   static bool configured = false;
   if (!configured) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_tn_grouped_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_tn_grouped_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute((const void*)gemm_bf16_tn_grouped_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) return (int)e;
     configured = true;
   }
-  hipLaunchKernelGGL(gemm_bf16_tn_grouped_kernel, dim3(nwg), dim3(512), LDS, (hipStream_t)stream, (const TnGroupProblem*)probs, (const TnGroupItem*)items,
-                     (const int*)first);
+  if (ragged)
+    hipLaunchKernelGGL(gemm_bf16_tn_grouped_kernel<true>, dim3(nwg), dim3(512), LDS, (hipStream_t)stream, (const TnGroupProblem*)probs,
+                       (const TnGroupItem*)items, (const int*)first);
+  else
+    hipLaunchKernelGGL(gemm_bf16_tn_grouped_kernel<false>, dim3(nwg), dim3(512), LDS, (hipStream_t)stream, (const TnGroupProblem*)probs,
+                       (const TnGroupItem*)items, (const int*)first);
   LAUNCH_CHECK();
   return CLIMB_OK;
 }

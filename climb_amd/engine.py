@@ -157,6 +157,7 @@ class Workspace:
         self.dh_c = [torch.empty((M, H), dtype=t16, device=dev) for _ in range(L)]
         self.du_l = [torch.empty((M, Fd), dtype=t16, device=dev) for _ in range(L)]
         self.dqkv_l = [torch.empty((M, 3 * H), dtype=t16, device=dev) for _ in range(L)]
+        self.dz_l = [torch.empty((M, self.r), dtype=t16, device=dev) for _ in range(2 * L)] if self.has_adapters else None      # adapters: d(bottleneck) per site
         # ... and of the LayerNorm backwards' {dgamma, dbeta, bias} partial column sums: reduced by ONE launch per group instead of one per LayerNorm
         lnb = _lib.query("climb_layernorm_bwd_rows_per_block")
         self.part_l = [torch.empty((((M + lnb - 1) // lnb) * 3 * H,), dtype=torch.float32, device=dev) for _ in range(2 * L)]
@@ -588,8 +589,14 @@ class ViltEngine:
     # ------------------------------------------------------------------ deferred, grouped weight gradients
     def _dw_group_size(self, ws: Workspace, ad) -> int:
         """Layers per grouped weight-gradient launch for this backward; 0 = the immediate per-GEMM path."""
-        if self.precision != "bf16" or ad is not None or (ws.M % 128) or self.overlap_dw:
+        if self.precision != "bf16" or (ws.M % 128) or self.overlap_dw:
             return 0
+        if ad is not None:
+            # under an active adapter the base is normally frozen (train_adapter); the backward then keeps one d(y) scratch for all layers,
+            # which a DEFERRED gradient of a trainable base weight would read too late: that combination takes the immediate path
+            l0 = f"{ENC}encoder.layer."
+            if any(self.requires_grad[f"{l0}{i}.{n}"] for i in range(self.cfg["layers"]) for n in ("output.dense.weight", "attention.output.dense.weight")):
+                return 0
         if _DW_GROUP is not None:
             return max(0, int(_DW_GROUP))
         return 4 if self.grad_ready_hook is not None else self.cfg["layers"]
@@ -597,7 +604,7 @@ class ViltEngine:
     def _dw_defer(self, pending: list, dY, X, wname, M, N, K, bname=None, ws=None):
         """linear_dw, but recorded for the group's launch when the shape fits its 256 x 256 tiles (else run now)."""
         want_b = bname is not None and self.requires_grad[bname]
-        if not self.requires_grad[wname] or (M % 128) or (N % 256) or (K % 256):
+        if not self.requires_grad[wname] or (M % 128) or (N % 8) or (K % 8):
             return self.linear_dw(dY, X, wname, M, N, K, bname, ws)
         pending.append((dY, X, wname, bname if want_b else None, M, N, K))
 
@@ -616,7 +623,7 @@ class ViltEngine:
                 r["A"], r["B"], r["C"], r["dbias"] = dY.data_ptr(), X.data_ptr(), self.g(w), (self.g(b) if b is not None else 0)
                 r["lda"], r["ldb"], r["ldc"], r["M"], r["N"], r["K"] = N, K, K, M, N, K
             Ms, Ns, Ks = (np.ascontiguousarray(rec[f], dtype=np.int32) for f in ("M", "N", "K"))
-            cap = int(sum((n // 256) * (k // 256) for n, k in zip(Ns, Ks))) + nwg + 1
+            cap = int(sum(((n + 255) // 256) * ((k + 255) // 256) for n, k in zip(Ns, Ks))) + nwg + 1
             items = np.zeros((cap, 8), dtype=np.int32)
             first = np.zeros(nwg + 1, dtype=np.int32)
             n_items = _lib.load().climb_tn_grouped_plan(len(pending), Ms.ctypes.data, Ns.ctypes.data, Ks.ctypes.data, nwg, items.ctypes.data, cap, first.ctypes.data)
@@ -625,11 +632,12 @@ class ViltEngine:
             dev = self.device
             plan = dict(probs=torch.from_numpy(rec.view(np.uint8).copy()).to(dev), items=torch.from_numpy(items[:n_items].copy()).to(dev),
                         first=torch.from_numpy(first).to(dev), nwg=nwg, flops=float(sum(2.0 * M * N * K for _, _, _, _, M, N, K in pending)),
+                        ragged=int(any((N % 256) or (K % 256) for _, _, _, _, M, N, K in pending)),
                         keep=[(dY, X) for dY, X, *_ in pending])
             if len(ws.dw_plans) >= 16:           # requires_grad patterns / group sizes seen on this shape: bounded
                 ws.dw_plans.pop(next(iter(ws.dw_plans)))
             ws.dw_plans[key] = plan
-        self._timed_call("gemm_bf16_tn", plan["flops"], "climb_gemm_bf16_tn_grouped", plan["probs"], plan["items"], plan["first"], plan["nwg"], _stream())
+        self._timed_call("gemm_bf16_tn", plan["flops"], "climb_gemm_bf16_tn_grouped", plan["probs"], plan["items"], plan["first"], plan["nwg"], plan["ragged"], _stream())
         pending.clear()
 
     def _red_flush(self, ws: Workspace, pending: list):
@@ -747,8 +755,9 @@ class ViltEngine:
                 dy = dxc(i + 1)
                 dw(dy, ws.a[i], l + "output.dense.weight", M, H, Fd)
             else:   # x_{i+1} = h1 + y + up(silu(down(y))): d(y) = d(x_{i+1}) + down^T(silu'(z) * up^T d(x_{i+1}))
-                dy = self.adapter_backward(ws, f"{l}output.adapters.{ad}.", ws.so[i], ws.zo[i], ws.yo[i], M, H, r)
-                self.dw_async(dy, ws.a[i], l + "output.dense.weight", M, H, Fd, l + "output.dense.bias", ws)
+                dy = self.adapter_backward(ws, f"{l}output.adapters.{ad}.", ws.so[i], ws.zo[i], ws.yo[i], M, H, r,
+                                           dxc(i + 1), ws.dz_l[2 * i + 1] if G else ws.dz, dw)
+                dw(dy, ws.a[i], l + "output.dense.weight", M, H, Fd, l + "output.dense.bias", ws)
             du = du_(i)
             self.linear_dx(dy, l + "output.dense.weight", du, M, H, Fd, EPI_DGELU, ws.u[i])
             dw(du, ws.hn[i], l + "intermediate.dense.weight", M, Fd, H, l + "intermediate.dense.bias", ws)
@@ -762,8 +771,9 @@ class ViltEngine:
                 dy = dhc(i)
                 dw(dy, ws.ctx[i], l + "attention.output.dense.weight", M, H, H)
             else:
-                dy = self.adapter_backward(ws, f"{l}attention.output.adapters.{ad}.", ws.sa[i], ws.za[i], ws.ya[i], M, H, r)
-                self.dw_async(dy, ws.ctx[i], l + "attention.output.dense.weight", M, H, H, l + "attention.output.dense.bias", ws)
+                dy = self.adapter_backward(ws, f"{l}attention.output.adapters.{ad}.", ws.sa[i], ws.za[i], ws.ya[i], M, H, r,
+                                           dhc(i), ws.dz_l[2 * i] if G else ws.dz, dw)
+                dw(dy, ws.ctx[i], l + "attention.output.dense.weight", M, H, H, l + "attention.output.dense.bias", ws)
             self.linear_dx(dy, l + "attention.output.dense.weight", ws.dctx, M, H, H)
             dqkv = dqkv_(i)
             self.attn_bwd(ws.qkv[i], ws.key_bias, ws.dctx, ws.ctx[i], ws.lse[i], ws.delta, dqkv, B, ws.S_pad)
@@ -811,13 +821,17 @@ class ViltEngine:
         self.linear_fwd(y, a_ + "adapter_down.0.weight", a_ + "adapter_down.0.bias", s_act, M, r, H, EPI_SILU, None, z_pre)
         self.linear_fwd(s_act, a_ + "adapter_up.weight", a_ + "adapter_up.bias", out, M, H, r, EPI_RESID2, resid, None, y, out_f32=True)
 
-    def adapter_backward(self, ws: Workspace, a_: str, s_act, z_pre, y_in, M, H, r):
-        """Backward of out = resid + y + up(silu(down(y))) given d(out) in ws.dres (fp32) / ws.dres_c (operand dtype).
-        Accumulates the adapter's parameter gradients and returns d(y) = d(out) + down^T(silu'(z) * up^T d(out))."""
-        self.dw_async(ws.dres_c, s_act, a_ + "adapter_up.weight", M, H, r, a_ + "adapter_up.bias", ws)
-        self.linear_dx(ws.dres_c, a_ + "adapter_up.weight", ws.dz, M, H, r, EPI_DSILU, z_pre)
-        self.dw_async(ws.dz, y_in, a_ + "adapter_down.0.weight", M, r, H, a_ + "adapter_down.0.bias", ws)
-        self.linear_dx(ws.dz, a_ + "adapter_down.0.weight", ws.dy, M, r, H, EPI_RESID, ws.dres)
+    def adapter_backward(self, ws: Workspace, a_: str, s_act, z_pre, y_in, M, H, r, dout_c=None, dz=None, dw=None):
+        """Backward of out = resid + y + up(silu(down(y))) given d(out) in ws.dres (fp32) / `dout_c` (operand dtype).
+        Accumulates the adapter's parameter gradients (`dw`: now, or recorded for the group's launch -- then `dout_c` and `dz` are per-layer
+        buffers that stay valid until it) and returns d(y) = d(out) + down^T(silu'(z) * up^T d(out))."""
+        dout_c = ws.dres_c if dout_c is None else dout_c
+        dz = ws.dz if dz is None else dz
+        dw = self.dw_async if dw is None else dw
+        dw(dout_c, s_act, a_ + "adapter_up.weight", M, H, r, a_ + "adapter_up.bias", ws)
+        self.linear_dx(dout_c, a_ + "adapter_up.weight", dz, M, H, r, EPI_DSILU, z_pre)
+        dw(dz, y_in, a_ + "adapter_down.0.weight", M, r, H, a_ + "adapter_down.0.bias", ws)
+        self.linear_dx(dz, a_ + "adapter_down.0.weight", ws.dy, M, r, H, EPI_RESID, ws.dres)
         return ws.dy
 
     def embedding_backward(self, ws: Workspace, sv, pending: Optional[list] = None):

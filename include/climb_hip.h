@@ -162,10 +162,11 @@ int climb_nt_workspace_bytes(void);
  *   items : device int32 [n_items][8] = { problem, tile n, tile k, first reduction tile, end reduction tile, partial, 0, 0 }
  *   first : device int32 [nwg + 1]: workgroup b walks items first[b] .. first[b + 1] - 1
  * climb_tn_grouped_plan fills HOST copies of `items` (capacity `cap` records) and `first` from the problems' shapes (host arrays; M % 128,
- * N % 256, K % 256 required) for `nwg` workgroups (a multiple of 8; 256 on MI355X) and returns the number of items (or a negative code);
+ * N % 8, K % 8 required; `ragged` = 1 at the launch when some N or K is not a multiple of 256: surplus tile columns are computed on clamped
+ * addresses and not stored -- the adapters' 768 x 48 / 48 x 768 gradients) for `nwg` workgroups (a multiple of 8; 256 on MI355X) and returns the number of items (or a negative code);
  * the caller uploads them once per shape and keeps them -- the launch itself allocates and copies nothing. */
 int climb_tn_grouped_plan(int nprob, const int* M, const int* N, const int* K, int nwg, int* items_out, int cap, int* first_out);
-int climb_gemm_bf16_tn_grouped(const void* probs, const void* items, const void* first, int nwg, void* stream);
+int climb_gemm_bf16_tn_grouped(const void* probs, const void* items, const void* first, int nwg, int ragged, void* stream);
 /* HF:322-351 in bf16: same contract as the _f32 entry points, qkv/ctx/dctx/dqkv are bf16.  The backward takes the forward's ctx and
  * computes delta itself (its first phase); `delta` [B,heads,S_pad] is scratch it writes */
 int climb_attn_fwd_bf16(const void* qkv, const float* key_bias, void* ctx, float* lse, int B, int S_pad, int heads, int head_dim, void* stream);

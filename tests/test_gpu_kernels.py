@@ -222,15 +222,20 @@ def test_colreduce_batched_matches_single_reductions():
                 assert torch.equal(x, y)
 
 
+@pytest.mark.parametrize("ragged", [0, 1])
 @pytest.mark.parametrize("nwg", [256, 8, 24])
-def test_gemm_bf16_tn_grouped_launch(nwg):
+def test_gemm_bf16_tn_grouped_launch(nwg, ragged):
     """The grouped weight-gradient launch (r03: several dW GEMMs in one persistent kernel, whole tiles reduce over all tokens and
     read-modify-write C, the stream-K tail meets through atomics) against float64 of the same 16-bit operands: problems of different
     token counts and shapes, accumulation into non-zero C, fused bias gradients on some, nwg = 256 (everything is tail), 8 and 24 (whole
     rounds + tail).  Repeated launches must agree (to the atomics' order)."""
     from climb_amd import _lib
     dev = _dev()
+    # C / dbias carry guard rows and columns behind the ragged problems' edges? No: their buffers are exactly [N, K] / [N] -- a write outside
+    # would corrupt the neighbouring allocation and show up in ITS comparison below
     shapes = [(2048, 768, 768, True), (2048, 256, 512, False), (1024, 512, 256, True), (3072, 256, 256, False), (1152, 768, 256, True)]
+    if ragged:          # the adapters' shapes and an odd one: surplus tile columns are computed on clamped addresses and never stored
+        shapes += [(2048, 768, 48, True), (2048, 48, 768, True), (1024, 264, 200, False)]
     g = torch.Generator(device=dev).manual_seed(5 + nwg)
     ops = []
     for M, N, K, bias in shapes:
@@ -246,13 +251,13 @@ def test_gemm_bf16_tn_grouped_launch(nwg):
             r["A"], r["B"], r["C"], r["dbias"] = dY.data_ptr(), X.data_ptr(), C.data_ptr(), (db.data_ptr() if db is not None else 0)
             r["lda"], r["ldb"], r["ldc"], r["M"], r["N"], r["K"] = N, K, K, M, N, K
         Ms, Ns, Ks = (np.ascontiguousarray(rec[f], dtype=np.int32) for f in ("M", "N", "K"))
-        cap = int(sum((n // 256) * (k // 256) for n, k in zip(Ns, Ks))) + nwg + 1
+        cap = int(sum(((n + 255) // 256) * ((k + 255) // 256) for n, k in zip(Ns, Ks))) + nwg + 1
         items, first = np.zeros((cap, 8), dtype=np.int32), np.zeros(nwg + 1, dtype=np.int32)
         n = _lib.load().climb_tn_grouped_plan(len(shapes), Ms.ctypes.data, Ns.ctypes.data, Ks.ctypes.data, nwg, items.ctypes.data, cap, first.ctypes.data)
         assert n > 0
         d_rec = torch.from_numpy(rec.view(np.uint8).copy()).to(dev)
         d_items, d_first = torch.from_numpy(items[:n].copy()).to(dev), torch.from_numpy(first).to(dev)
-        _lib.call("climb_gemm_bf16_tn_grouped", d_rec, d_items, d_first, nwg, _st())
+        _lib.call("climb_gemm_bf16_tn_grouped", d_rec, d_items, d_first, nwg, ragged, _st())
         torch.cuda.synchronize()
         return Cs, dbs, items[:n]
     Cs, dbs, items = run()

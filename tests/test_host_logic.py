@@ -253,6 +253,8 @@ def test_grouped_weight_gradient_plan_covers_every_reduction_tile_once(layers, n
     total = sum(s[0] // 64 * (s[1] // 256) * (s[2] // 256) for s in shapes)
     assert load.sum() == total and load.max() <= total / nwg + 192 + 2          # balanced to within one tile's reduction
     assert lib.climb_tn_grouped_plan(1, M.ctypes.data, N.ctypes.data, K.ctypes.data, 100, items.ctypes.data, cap, first.ctypes.data) == -1      # nwg % 8
+    odd = np.array([12288, 12288, 2048], dtype=np.int32), np.array([768, 48, 264], dtype=np.int32), np.array([48, 768, 200], dtype=np.int32)
+    assert lib.climb_tn_grouped_plan(3, odd[0].ctypes.data, odd[1].ctypes.data, odd[2].ctypes.data, nwg, items.ctypes.data, cap, first.ctypes.data) > 0    # ragged N, K: multiples of 8
     bad = np.array([12288 + 64], dtype=np.int32)
     assert lib.climb_tn_grouped_plan(1, bad.ctypes.data, N.ctypes.data, K.ctypes.data, 256, items.ctypes.data, cap, first.ctypes.data) == -1   # M % 128
     assert lib.climb_tn_grouped_plan(len(shapes), M.ctypes.data, N.ctypes.data, K.ctypes.data, nwg, items.ctypes.data, 8, first.ctypes.data) == -2

@@ -91,6 +91,6 @@ if __name__ == "__main__":
         items, first = np.zeros((cap, 8), dtype=np.int32), np.zeros(nwg + 1, dtype=np.int32)
         n = _lib.load().climb_tn_grouped_plan(len(flat), Ms.ctypes.data, Ns.ctypes.data, Ks.ctypes.data, nwg, items.ctypes.data, cap, first.ctypes.data)
         d = [torch.from_numpy(rec.view(np.uint8).copy()).to(dev), torch.from_numpy(items[:n].copy()).to(dev), torch.from_numpy(first).to(dev)]
-        t = timeit(lambda: _lib.call("climb_gemm_bf16_tn_grouped", d[0], d[1], d[2], nwg, st()), iters=10)
+        t = timeit(lambda: _lib.call("climb_gemm_bf16_tn_grouped", d[0], d[1], d[2], nwg, 0, st()), iters=10)
         f = sum(2.0 * M * N * K for N, K in shapes) * layers
         print(f"TN grouped, {layers:2d} layers per launch ({n} items, {int((items[:n, 5] == 1).sum())} partial): {t*1e6/layers:8.1f} us/layer  {f/t/1e12:7.1f} TF")

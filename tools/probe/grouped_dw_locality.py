@@ -39,7 +39,7 @@ for N, K, count in ((3072, 768, 12), (768, 3072, 12), (2304, 768, 16), (768, 768
     items, first = np.zeros((cap, 8), dtype=np.int32), np.zeros(257, dtype=np.int32)
     n = _lib.load().climb_tn_grouped_plan(count, Ms.ctypes.data, Ns.ctypes.data, Ks.ctypes.data, 256, items.ctypes.data, cap, first.ctypes.data)
     d = [torch.from_numpy(rec.view(np.uint8).copy()).to(dev), torch.from_numpy(items[:n].copy()).to(dev), torch.from_numpy(first).to(dev)]
-    t = timeit(lambda: _lib.call("climb_gemm_bf16_tn_grouped", d[0], d[1], d[2], 256, st()))
+    t = timeit(lambda: _lib.call("climb_gemm_bf16_tn_grouped", d[0], d[1], d[2], 256, 0, st()))
     f = 2.0 * M * N * K * count
     operand_mb = count * (N + K) * M * 2 / 1e6
     print(f"{count:3d} x dW[{N:4d} x {K:4d}]: {tiles:4d} tiles ({tiles / 256:.2f} rounds), {t * 1e3:7.3f} ms  {f / t / 1e12:7.1f} TF   operands {operand_mb:7.0f} MB "
