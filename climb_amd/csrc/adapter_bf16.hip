@@ -23,11 +23,17 @@ __device__ __forceinline__ bf16x8 ad_frag(ad_u32x4 v) {
   return c.b;
 }
 
+// BWD (r03): the input-gradient half of the adapter's backward has the same shape,
+//     t  = dout Wu           [M, r]   (Wu [H, r]: the kernel reads its TRANSPOSED shadow [r, H] where the forward reads Wd)
+//     dz = t * silu'(z)      [M, r]   (z saved by the forward; dz is kept for the down-projection's weight gradient)
+//     dy = dres + dz Wd      [M, H]   (Wd [r, H]: transposed shadow [H, r]; dres = the fp32 residual gradient; dy in the 16-bit operand type)
+// so it is the same kernel with another middle and another epilogue: one launch instead of the two skinny GEMMs (2 x 15.5 us).
 // dynamic LDS: y tile [32][H] (row stride H * 2 + 16 bytes) -- later reused as zred[4][32][64] floats -- then sbuf[32][64] 16-bit
-__global__ __launch_bounds__(256) void adapter_fwd_kernel(const bf16_t* __restrict__ y, long ldy, const float* __restrict__ resid, long ldr,
-                                                          const bf16_t* __restrict__ wd, const float* __restrict__ bd, const bf16_t* __restrict__ wu,
-                                                          const float* __restrict__ bu, bf16_t* __restrict__ z, bf16_t* __restrict__ s, long ldz,
-                                                          float* __restrict__ out, long ldo, int M, int H, int r) {
+template <bool BWD>
+__global__ __launch_bounds__(256) void adapter_kernel(const bf16_t* __restrict__ y, long ldy, const float* __restrict__ resid, long ldr,
+                                                      const bf16_t* __restrict__ wd, const float* __restrict__ bd, const bf16_t* __restrict__ wu,
+                                                      const float* __restrict__ bu, bf16_t* __restrict__ z, bf16_t* __restrict__ s, long ldz,
+                                                      void* __restrict__ out_, long ldo, int M, int H, int r) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, half = lane >> 5, l31 = lane & 31;
   const int m0 = blockIdx.x * AD_ROWS;
@@ -74,11 +80,18 @@ __global__ __launch_bounds__(256) void adapter_fwd_kernel(const bf16_t* __restri
     const int m = e >> 6, n = e & 63;
     float v = 0.f, sv = 0.f;
     if (n < r) {
-      v = zred[(0 * AD_ROWS + m) * 64 + n] + zred[(1 * AD_ROWS + m) * 64 + n] + zred[(2 * AD_ROWS + m) * 64 + n] + zred[(3 * AD_ROWS + m) * 64 + n] + bd[n];
-      sv = silu_f(v);                                              // of the fp32 value, like the GEMM's EPI_SILU epilogue
-      if (m0 + m < M && blockIdx.y == 0) {
-        z[(long)(m0 + m) * ldz + n] = f32_to_bf16(v);
-        s[(long)(m0 + m) * ldz + n] = f32_to_bf16(sv);
+      v = zred[(0 * AD_ROWS + m) * 64 + n] + zred[(1 * AD_ROWS + m) * 64 + n] + zred[(2 * AD_ROWS + m) * 64 + n] + zred[(3 * AD_ROWS + m) * 64 + n];
+      if (!BWD) {
+        v += bd[n];
+        sv = silu_f(v);                                            // of the fp32 value, like the GEMM's EPI_SILU epilogue
+        if (m0 + m < M && blockIdx.y == 0) {
+          z[(long)(m0 + m) * ldz + n] = f32_to_bf16(v);
+          s[(long)(m0 + m) * ldz + n] = f32_to_bf16(sv);
+        }
+      } else {                                                     // z: the forward's pre-activation (input); s: where dz goes (output)
+        const int gm = m0 + m < M ? m0 + m : M - 1;
+        sv = v * dsilu_f(bf16_to_f32(z[(long)gm * ldz + n]));       // like the GEMM's EPI_DSILU epilogue
+        if (m0 + m < M && blockIdx.y == 0) s[(long)(m0 + m) * ldz + n] = f32_to_bf16(sv);
       }
     }
     sbuf[m * 64 + n] = f32_to_bf16(sv);
@@ -101,27 +114,31 @@ __global__ __launch_bounds__(256) void adapter_fwd_kernel(const bf16_t* __restri
 #pragma unroll
     for (int ks = 0; ks < AD_MAXR / 16; ++ks)
       if (ks < ksteps) o = CLIMB_MFMA_H16(sf[ks], ad_frag(*reinterpret_cast<const ad_u32x4*>(wu + (long)n * r + 16 * ks + 8 * half)), o, 0, 0, 0);
-    const float b = bu[n];
+    const float b = BWD ? 0.f : bu[n];
     float rv[16], yv[16];
 #pragma unroll
     for (int q = 0; q < 16; ++q) {                                 // all loads of the block before its first store
       const int m = m0 + (q & 3) + 8 * (q >> 2) + 4 * half;
       const int gm = m < M ? m : M - 1;
       rv[q] = resid[(long)gm * ldr + n];
-      yv[q] = bf16_to_f32(y[(long)gm * ldy + n]);
+      yv[q] = BWD ? 0.f : bf16_to_f32(y[(long)gm * ldy + n]);
     }
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
       const int m = m0 + (q & 3) + 8 * (q >> 2) + 4 * half;
-      if (m < M) out[(long)m * ldo + n] = o[q] + b + rv[q] + yv[q];
+      if (m < M) {
+        if (BWD) reinterpret_cast<bf16_t*>(out_)[(long)m * ldo + n] = f32_to_bf16(o[q] + rv[q]);
+        else reinterpret_cast<float*>(out_)[(long)m * ldo + n] = o[q] + b + rv[q] + yv[q];
+      }
     }
   }
 }
 
 // y [M, H] 16-bit (the sub-layer's output incl. its bias), resid [M, H] fp32, wd [r, H] / wu [H, r] 16-bit weight shadows, bd [r] / bu [H] fp32;
 // z, s [M, r] 16-bit (saved for the backward), out [M, H] fp32 (may not alias y; may alias nothing else it reads except resid element-wise).
-extern "C" int climb_adapter_fwd_bf16(const void* y, long ldy, const float* resid, long ldr, const void* wd, const float* bd, const void* wu,
-                                      const float* bu, void* z, void* s, long ldz, float* out, long ldo, int M, int H, int r, void* stream) {
+template <bool BWD>
+static int adapter_launch(const void* y, long ldy, const float* resid, long ldr, const void* wd, const float* bd, const void* wu, const float* bu, void* z,
+                          void* s, long ldz, void* out, long ldo, int M, int H, int r, void* stream) {
   if (M <= 0 || H <= 0 || (H % 128) || r <= 0 || (r % 16) || r > AD_MAXR || (ldy % 8)) return CLIMB_EUNSUPPORTED;
   const int ystride = H * 2 + 16;
   size_t big = (size_t)AD_ROWS * ystride;
@@ -129,13 +146,28 @@ extern "C" int climb_adapter_fwd_bf16(const void* y, long ldy, const float* resi
   const size_t lds = big + (size_t)AD_ROWS * 64 * 2;
   static size_t lds_set = 0;
   if (lds > lds_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)adapter_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute((const void*)adapter_kernel<BWD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     lds_set = lds;
   }
   const int slices = 1;      // column slices per row block (2 measured 42 us against 32: the repeated y tile costs more than the extra workgroups bring)
-  hipLaunchKernelGGL(adapter_fwd_kernel, dim3((M + AD_ROWS - 1) / AD_ROWS, slices), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)y, ldy, resid, ldr,
+  hipLaunchKernelGGL(adapter_kernel<BWD>, dim3((M + AD_ROWS - 1) / AD_ROWS, slices), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)y, ldy, resid, ldr,
                      (const bf16_t*)wd, bd, (const bf16_t*)wu, bu, (bf16_t*)z, (bf16_t*)s, ldz, out, ldo, M, H, r);
   LAUNCH_CHECK();
   return CLIMB_OK;
+}
+
+// y [M, H] 16-bit (the sub-layer's output incl. its bias), resid [M, H] fp32, wd [r, H] / wu [H, r] 16-bit weight shadows, bd [r] / bu [H] fp32;
+// z, s [M, r] 16-bit (saved for the backward), out [M, H] fp32 (may not alias y; may alias nothing else it reads except resid element-wise).
+extern "C" int climb_adapter_fwd_bf16(const void* y, long ldy, const float* resid, long ldr, const void* wd, const float* bd, const void* wu,
+                                      const float* bu, void* z, void* s, long ldz, float* out, long ldo, int M, int H, int r, void* stream) {
+  return adapter_launch<false>(y, ldy, resid, ldr, wd, bd, wu, bu, z, s, ldz, out, ldo, M, H, r, stream);
+}
+
+// The input-gradient half of the adapter's backward in one launch: dz = (dout Wu) * silu'(z), dy = dres + dz Wd.
+// dout [M, H] 16-bit; dres [M, H] fp32 (the residual gradient d(out)); wu_t [r, H] = Wu^T and wd_t [H, r] = Wd^T (the transposed 16-bit
+// shadows); z [M, r] the forward's saved pre-activation; dz [M, r] and dy [M, H] 16-bit outputs (dy may not alias dout).
+extern "C" int climb_adapter_bwd_bf16(const void* dout, long ldd, const float* dres, long ldr, const void* wu_t, const void* wd_t, const void* z, void* dz,
+                                      long ldz, void* dy, long ldo, int M, int H, int r, void* stream) {
+  return adapter_launch<true>(dout, ldd, dres, ldr, wu_t, nullptr, wd_t, nullptr, const_cast<void*>(z), dz, ldz, dy, ldo, M, H, r, stream);
 }

@@ -642,10 +642,13 @@ class ViltEngine:
 
     def _red_flush(self, ws: Workspace, pending: list):
         """the {dgamma, dbeta, bias} reductions recorded by a group's LayerNorm backwards, as one launch"""
+        rg = self.requires_grad
+        live = [p for p in pending if any(n is not None and rg[n] for n in p[3])]      # a frozen base (adapters, frozen layers): nothing to reduce
+        pending.clear()
+        pending.extend(live)
         if not pending:
             return
         import numpy as np
-        rg = self.requires_grad
         key = tuple((part.data_ptr(), nblk, ncols, tuple(n if (n is not None and rg[n]) else None for n in names)) for part, nblk, ncols, names in pending)
         plan = ws.red_plans.get(key)
         if plan is None:
@@ -829,9 +832,13 @@ class ViltEngine:
         dz = ws.dz if dz is None else dz
         dw = self.dw_async if dw is None else dw
         dw(dout_c, s_act, a_ + "adapter_up.weight", M, H, r, a_ + "adapter_up.bias", ws)
-        self.linear_dx(dout_c, a_ + "adapter_up.weight", dz, M, H, r, EPI_DSILU, z_pre)
+        if self.precision != "fp32" and H % 128 == 0 and r % 16 == 0 and r <= 64 and _FUSED_ADAPTER:
+            _lib.call("climb_adapter_bwd_bf16", dout_c, H, ws.dres, H, self.spt(a_ + "adapter_up.weight"), self.spt(a_ + "adapter_down.0.weight"),
+                      z_pre, dz, r, ws.dy, H, M, H, r, _stream())
+        else:
+            self.linear_dx(dout_c, a_ + "adapter_up.weight", dz, M, H, r, EPI_DSILU, z_pre)
+            self.linear_dx(dz, a_ + "adapter_down.0.weight", ws.dy, M, r, H, EPI_RESID, ws.dres)
         dw(dz, y_in, a_ + "adapter_down.0.weight", M, r, H, a_ + "adapter_down.0.bias", ws)
-        self.linear_dx(dz, a_ + "adapter_down.0.weight", ws.dy, M, r, H, EPI_RESID, ws.dres)
         return ws.dy
 
     def embedding_backward(self, ws: Workspace, sv, pending: Optional[list] = None):

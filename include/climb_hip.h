@@ -140,6 +140,10 @@ int climb_gemm_bf16_nt(const void* A, long lda, const void* B, long ldb, void* C
  * y [M,H] 16-bit, resid / out [M,H] fp32, wd [r,H] / wu [H,r] 16-bit, bd [r] / bu [H] fp32, z / s [M,r] 16-bit (saved for the backward).
  * H % 128 == 0, r % 16 == 0, r <= 64; CLIMB_EUNSUPPORTED otherwise (the caller keeps the two-GEMM path). */
 int climb_adapter_fwd_bf16(const void* y, long ldy, const float* resid, long ldr, const void* wd, const float* bd, const void* wu, const float* bu, void* z, void* s, long ldz, float* out, long ldo, int M, int H, int r, void* stream);
+/* the input-gradient half of the same adapter's backward, one launch: dz = (dout Wu) * silu'(z), dy = dres + dz Wd.  dout [M,H] 16-bit, dres [M,H]
+ * fp32 (the residual gradient), wu_t [r,H] / wd_t [H,r] = the TRANSPOSED 16-bit weight shadows, z [M,r] the forward's saved pre-activation;
+ * outputs dz [M,r] (kept for the down-projection's weight gradient) and dy [M,H], 16-bit */
+int climb_adapter_bwd_bf16(const void* dout, long ldd, const float* dres, long ldr, const void* wu_t, const void* wd_t, const void* z, void* dz, long ldz, void* dy, long ldo, int M, int H, int r, void* stream);
 /* weight gradient: C[N,K] (fp32) += A[M,N]^T B[M,K]; reduction over tokens via LDS transpose reads, split over M with fp32 atomics;
  * dbias (optional, fp32 [N]) += column sums of A = the bias gradient of the same layer (one extra MFMA against an all-ones operand) */
 int climb_gemm_bf16_tn(const void* A, long lda, const void* B, long ldb, float* C, long ldc, int M, int N, int K, float* dbias, void* stream);

@@ -667,6 +667,32 @@ def test_adapter_forward_fused(M, r):
         assert _rel(out, out2.double().cpu()) < 1e-3 and _rel(s.float(), s2.float().double().cpu()) < 6e-3
 
 
+@pytest.mark.parametrize("M,r", [(12288, 48), (100, 48), (64, 16), (517, 64)])
+def test_adapter_backward_fused(M, r):
+    """r03: the input-gradient half of the adapter backward in one launch, dz = (dout Wu) * silu'(z), dy = dres + dz Wd, against float64 of the
+    same 16-bit-rounded operands (the kernel reads the TRANSPOSED weight shadows)."""
+    from climb_amd import _lib
+    dev = _dev()
+    H = 768
+    g = torch.Generator().manual_seed(3 * M + r)
+    dout = _bf(torch.randn(M, H, generator=g))
+    dres = torch.randn(M, H, generator=g)
+    wd, wu = _bf(torch.randn(r, H, generator=g) * 0.05), _bf(torch.randn(H, r, generator=g) * 0.05)
+    zin = _bf(torch.randn(M, r, generator=g))
+    dz = torch.full((M, r), float("nan"), device=dev, dtype=_h16())
+    dy = torch.full((M, H), float("nan"), device=dev, dtype=_h16())
+    _lib.call("climb_adapter_bwd_bf16", dout.to(dev), H, dres.to(dev), H, wu.t().contiguous().to(dev), wd.t().contiguous().to(dev), zin.to(dev), dz, r,
+              dy, H, M, H, r, _st())
+    t = dout.double() @ wu.double()
+    zd = zin.double()
+    sg = torch.sigmoid(zd)
+    dzr = t * (sg * (1.0 + zd * (1.0 - sg)))
+    dz16 = dzr.to(_h16()).double()
+    dyr = dres.double() + dz16 @ wd.double()
+    assert _rel(dz.float(), dzr) < 6e-3
+    assert _rel(dy.float(), dyr) < 6e-3          # 16-bit output
+
+
 def test_weight_shadow_cast_and_batched_transpose():
     from climb_amd import _lib
     dev = _dev()
