@@ -599,7 +599,15 @@ class ViltEngine:
                 return 0
         if _DW_GROUP is not None:
             return max(0, int(_DW_GROUP))
-        return 4 if self.grad_ready_hook is not None else self.cfg["layers"]
+        return self._ready_group() if self.grad_ready_hook is not None else self.cfg["layers"]
+
+    def _ready_group(self) -> int:
+        """Layers per reported gradient range.  Under a data-parallel hook this must NOT depend on the local batch (ranks with different shard
+        sizes take different weight-gradient paths -- e.g. a last batch of 2 + 1 examples -- but have to issue the same collectives): always
+        groups of 4 layers (or CLIMB_AMD_DW_GROUP) from the top down, whichever path computed them."""
+        if self.grad_ready_hook is None:
+            return 1
+        return int(_DW_GROUP) if (_DW_GROUP is not None and int(_DW_GROUP) > 0) else 4
 
     def _dw_defer(self, pending: list, dY, X, wname, M, N, K, bname=None, ws=None):
         """linear_dw, but recorded for the group's launch when the shape fits its 256 x 256 tiles (else run now)."""
@@ -737,6 +745,7 @@ class ViltEngine:
         last = f"{ENC}encoder.layer.{cfg['layers'] - 1}."
         G = self._dw_group_size(ws, ad)          # > 0: weight gradients are recorded per layer and launched per group of G layers
         pending, pending_red, group = [], [], []
+        rgroup = self._ready_group()
         if G:
             ws.ensure_deferred(self)
         RB = bool(G) and _RED_BATCH
@@ -791,8 +800,11 @@ class ViltEngine:
                 red3(lnpart(2 * i), l + "layernorm_before.weight", l + "layernorm_before.bias",
                      f"{ENC}encoder.layer.{i - 1}.output.dense.bias" if (i > first_layer and ad is None) else None)
             self.join_side()
-            if not G:
-                self._ready(*lay.layer_range[i])
+            if not G:          # immediate weight gradients: the layer is final now, reported in the same groups the deferred path uses
+                group.append(i)
+                if len(group) >= rgroup or i == first_layer:
+                    self._ready(lay.layer_range[min(group)][0], lay.layer_range[max(group)][1])
+                    group = []
                 continue
             group.append(i)
             last_group = i == first_layer

@@ -1103,7 +1103,7 @@ def test_hipgraph_replay_matches_eager():
 
 
 # ------------------------------------------------------------------------------------------------ data parallel, end to end
-def _dp_worker(rank, world, port, q, precision):
+def _dp_worker(rank, world, port, q, precision, gbatch=4):
     import os as _os
     _os.environ["MASTER_ADDR"], _os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     import torch.distributed as dist
@@ -1113,28 +1113,32 @@ def _dp_worker(rank, world, port, q, precision):
         torch.manual_seed(1000 + rank)                                     # replicas start DIFFERENT: the broadcast must fix that
         model, _ = make_model(["vqa"], 42 + rank, precision=precision)
         ddp = GradientAllReducer(model)          # payload: fp32 in the fp32 mode, bf16 staging buffer in the bf16 mode
-        enc = vo.synthetic_encodings(4, seed=21)
-        tgt = vo.synthetic_vqa_targets(4, seed=21)
-        sl = slice(2 * rank, 2 * rank + 2)                                 # this rank's shard of the global batch of 4
+        from climb_amd.data.sharding import shard_of
+        enc = vo.synthetic_encodings(gbatch, seed=21)
+        tgt = vo.synthetic_vqa_targets(gbatch, seed=21)
+        # this rank's strided share of the global batch and the weight its d(loss) carries (4: halves, weight 1; 3: shares of 2 and 1 examples,
+        # weights 4/3 and 2/3 -- the ranks then run DIFFERENT weight-gradient paths (384 and 192 token rows) and must still issue the same collectives)
+        sl, weight = shard_of(list(range(gbatch)), rank, world)
         images, texts = enc_to_inputs({k: v[sl] for k, v in enc.items()})
         opt = model.create_optimizer({"lr": 1e-3, "weight_decay": 1e-2, "adam_epsilon": 1e-8})
         model.train()
         losses, grads = [], None
         for it in range(2):
-            loss, _, _, _ = model.fused_forward_backward("vqa", images, texts, tgt[sl])
+            loss, _, _, _ = model.fused_forward_backward("vqa", images, texts, tgt[sl], grad_weight=weight)
             if it == 0 and rank == 0:          # the averaged gradients the optimizer is about to consume (numpy: pickled by value)
                 grads = {n: p.grad.detach().cpu().numpy() for n, p in model.named_parameters() if p.grad is not None}
             opt.step()
             opt.zero_grad()
             losses.append(float(loss))
         ok = ddp.replicas_in_sync()
-        q.put((rank, ok, losses, grads, ddp.bytes_reduced))
+        q.put((rank, ok, losses, grads, ddp.bytes_reduced, weight / world))          # weight / world = examples of the shard / examples of the batch
     finally:
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("gbatch", [4, 3])
 @pytest.mark.parametrize("precision,tol", [("fp32", 1e-4), (H16, 4e-2)])      # bf16: payload rounding 2^-9 + bf16 GEMM order noise
-def test_data_parallel_two_ranks_equals_single_process_on_the_global_batch(precision, tol):
+def test_data_parallel_two_ranks_equals_single_process_on_the_global_batch(precision, tol, gbatch):
     """Two processes (gloo collectives on device tensors, both on the test box's single GPU) train on halves of a batch of 4 through the
     real engine hooks: weights broadcast from rank 0, per-range gradient all-reduce during the backward, finish() before AdamW.
     The averaged gradients equal (fp32 summation order aside) those of ONE process on the whole batch -- the loss is a batch mean,
@@ -1147,7 +1151,7 @@ def test_data_parallel_two_ranks_equals_single_process_on_the_global_batch(preci
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q, precision)) for r in range(2)]
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q, precision, gbatch)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=600) for _ in procs]
@@ -1159,8 +1163,8 @@ def test_data_parallel_two_ranks_equals_single_process_on_the_global_batch(preci
     assert res[0][4] > 0 and res[0][4] == res[1][4]
     # single process, global batch: its gradient is what the ranks' averaged gradient must be
     model, _ = make_model(["vqa"], 42, precision=precision)
-    enc = vo.synthetic_encodings(4, seed=21)
-    tgt = vo.synthetic_vqa_targets(4, seed=21)
+    enc = vo.synthetic_encodings(gbatch, seed=21)
+    tgt = vo.synthetic_vqa_targets(gbatch, seed=21)
     images, texts = enc_to_inputs(enc)
     model.train()
     loss, _, _, _ = model.fused_forward_backward("vqa", images, texts, tgt)
@@ -1173,7 +1177,8 @@ def test_data_parallel_two_ranks_equals_single_process_on_the_global_batch(preci
             continue             # mathematically zero (softmax shift invariance): only rounding noise on both sides
         worst = max(worst, _close(torch.from_numpy(dp[n]), g.cpu(), tol, f"averaged gradient {n}"))
     print(f"data parallel[{precision}] (2 ranks) vs single process on the global batch: worst gradient error {worst:.2e}")
-    assert abs(0.5 * (res[0][2][0] + res[1][2][0]) - float(loss)) < tol * abs(float(loss))      # mean of the shard losses = global loss
+    # the shard losses, weighted by their share of the global batch, are the global loss (r[5] = examples of the shard / examples of the batch)
+    assert abs(sum(r[5] * r[2][0] for r in res) - float(loss)) < tol * abs(float(loss))
 
 
 @pytest.mark.parametrize("B", [1, 7, 33, 48])
