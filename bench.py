@@ -20,6 +20,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 FLOP_PER_SAMPLE = 100.14e9          # forward 33.38 + backward 66.76 GFLOP at S=185, no padding counted
+# of which the opt-in CLIMB_AMD_CLS_ONLY_LAST=1 step does not execute (ViltEngine.cls_only_last: out-projection + MLP of the last layer on 1 of S rows, fwd + bwd):
+FLOP_NOT_RUN_CLS_ONLY = 3 * 184 * 2 * (768 * 768 + 2 * 768 * 3072)          # 5.86 GFLOP; the whole-step rate below counts EXECUTED flops
 PEAK = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3}   # dense MFMA peak TFLOP/s for the operand dtype (MI355X_MICROARCH.md)
 
 
@@ -151,6 +153,22 @@ def main():
         ddp.overlap = first
         dp_ab = {("overlap" if not first else "deferred") + "_ms_per_step": round(float(other.item()) / args.steps * 1e3, 3)}
     final_loss = float(loss.item())
+    # the same K steps with the opt-in dead-row elimination of the last encoder layer (ViltEngine.cls_only_last, DESIGN.md section 5: the
+    # rows of x_L that nothing reads are not computed; same loss and gradients) -- reported NEXT TO the headline, which executes every row
+    cls_only = None
+    if world == 1 and ddp is None and not eng.cls_only_last:
+        eng.cls_only_last = True
+        for _ in range(3):
+            step()
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        dt_cls = time.perf_counter() - t1
+        eng.cls_only_last = False
+        cls_only = {"ms_per_step": round(dt_cls / args.steps * 1e3, 3), "value": round(B * args.steps / dt_cls, 2), "unit": "samples/s",
+                    "flops_not_executed_frac": round(FLOP_NOT_RUN_CLS_ONLY / FLOP_PER_SAMPLE, 4)}
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -176,20 +194,24 @@ def main():
                 traffic = tj[dominant]["hbm_bytes_per_launch"]
         except Exception:
             traffic = None
+        flop_run = FLOP_PER_SAMPLE - (FLOP_NOT_RUN_CLS_ONLY if eng.cls_only_last else 0)
         roof = {"bound": "mfma", "kernel": dominant, "achieved": round(achieved, 2), "peak": PEAK[args.precision], "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK[args.precision], 4), "traffic": traffic,
                 "launches_per_step": len(events) // max(1, n_prof_steps), "event_sampled_steps": n_prof_steps, "avg_launch_us": round(1e3 * sum(k_ms) / max(1, len(k_ms)), 2),
                 "kernel_time_frac_of_step": round(k_time / n_prof_steps / (dt / args.steps), 4),
-                "whole_step_tflops": round(FLOP_PER_SAMPLE * B * args.steps / dt / 1e12, 2),
-                "whole_step_frac": round(FLOP_PER_SAMPLE * B * args.steps / dt / 1e12 / PEAK[args.precision], 4)}
+                "whole_step_tflops": round(flop_run * B * args.steps / dt / 1e12, 2),
+                "whole_step_frac": round(flop_run * B * args.steps / dt / 1e12 / PEAK[args.precision], 4)}
         out = {"metric": "image-text pairs/sec on ViLT VQAv2 fine-tune step", "value": round(value, 2), "unit": "samples/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "median_ms_per_step": round(step_ms[len(step_ms) // 2], 3),
                "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": args.precision, "data": "synthetic", "hip_graph": use_graph,
                "config": {"workload": "BASELINE.json configs[1]: ViLT sequential-FT VQAv2 step (fwd+BCE+bwd+AdamW), 384x384 image + 40 tokens, "
                                       "12-layer ViLT-B/32 random-init + VQA head", "batch_per_gpu": B, "global_batch": B * world, "seq_len": ws.S,
-                          "seq_len_padded": ws.S_pad, "parallelism": f"dp{world}", "final_loss": round(final_loss, 3)},
+                          "seq_len_padded": ws.S_pad, "parallelism": f"dp{world}", "final_loss": round(final_loss, 3),
+                          "last_layer": "[CLS] rows only after its attention (CLIMB_AMD_CLS_ONLY_LAST=1)" if eng.cls_only_last else "every row"},
                "roofline": roof}
+        if cls_only is not None:
+            out["cls_only_last_layer"] = cls_only
         if ddp is not None:
             out["replicas_in_sync"] = in_sync
             out["dp_overlap"] = bool(ddp.overlap)

@@ -108,6 +108,11 @@ class Workspace:
         self.lse = [buf((B, nh, self.S_pad)) for _ in range(L)]
         self.clsn, self.fmean, self.frstd = buf((B, H)), buf((B,)), buf((B,))
         self.pooled = buf((B, H))
+        # the last layer on its [CLS] rows only (ViltEngine.cls_only_last): compact [B, .] twins of h1 / hn / u / a / x_L and of the backward's
+        # d(x_L) / d(u) / d(hn) / d(h1) operands
+        self.h1c, self.xLc, self.mean2c, self.rstd2c = buf((B, H)), buf((B, H)), buf((B,)), buf((B,))
+        self.hnc, self.uc, self.ac = buf((B, H), adt), buf((B, Fd), adt), buf((B, Fd), adt)
+        self.dyc, self.duc, self.dhnc, self.dhcc = buf((B, H), adt), buf((B, Fd), adt), buf((B, H), adt), buf((B, H), adt)
         # backward scratch (shared by all layers)
         self.dres = buf((M, H))
         self.dres_c = self.dres if eng.precision == "fp32" else buf((M, H), adt)
@@ -209,6 +214,12 @@ class ViltEngine:
         self.overlap_dw = os.environ.get("CLIMB_AMD_OVERLAP_DW", "0") != "0"   # measured slower on MI355X (r01): off
         self._side = None
         self._side_pending = None
+        # OPT-IN (CLIMB_AMD_CLS_ONLY_LAST=1): rows of the LAST encoder layer that nothing reads are not computed (DESIGN.md section 5 "CLS rows
+        # only").  The only consumer of x_L is the pooler, which reads token 0 of every sequence (REF/modeling/vilt.py:123-124 returns
+        # `pooler_output` alone), so after the last layer's attention only the B [CLS] rows go through the out-projection / MLP / final
+        # LayerNorm, forward and backward.  Same loss, same gradients (tests/test_gpu_parity.py compares the two steps); off by default so that
+        # the default step executes every FLOP of the reference's (bench.py times both).
+        self.cls_only_last = os.environ.get("CLIMB_AMD_CLS_ONLY_LAST", "0") != "0"
 
     # ------------------------------------------------------------------ buffers
     def allocate(self):
@@ -315,6 +326,36 @@ class ViltEngine:
             self._gemm_f32(dY, 1, N, X, 1, K, self.g(wname), K, N, K, M, beta=1.0)
         else:
             self._bf16_dw(dY, X, wname, M, N, K, self.g(bname) if want_b else None)
+
+    # the same three products on a row-STRIDED subset (the last layer's [CLS] rows: row b of an operand is row b * S_pad of a saved [M, .] one)
+    def _lin_fwd_ld(self, X, ldx, wname, bname, Y, ldy, M, N, K, epi=EPI_NONE, aux=None, ldaux=0, aux_out=None, ldauxo=0, out_f32=False):
+        bias = self.p(bname) if bname else None
+        if self.precision == "fp32":
+            self._gemm_f32(X, ldx, 1, self.p(wname), K, 1, Y, ldy, M, N, K, bias, epi, aux, ldaux, aux_out, ldauxo)
+        else:
+            self._timed_call("gemm_bf16_nt_rows", 2.0 * M * N * K, "climb_gemm_bf16_nt", X, ldx, self.sp(wname), K, Y, ldy, F32 if out_f32 else BF16, M, N, K,
+                             bias, epi, aux, ldaux, aux_out, ldauxo, None, 0, _stream())
+
+    def _lin_dx_ld(self, dY, lddy, wname, dX, lddx, M, N, K, epi=EPI_NONE, aux=None, ldaux=0):
+        if self.precision == "fp32":
+            self._gemm_f32(dY, lddy, 1, self.p(wname), 1, K, dX, lddx, M, K, N, None, epi, aux, ldaux)
+        else:
+            self._timed_call("gemm_bf16_nt_rows", 2.0 * M * N * K, "climb_gemm_bf16_nt", dY, lddy, self.spt(wname), N, dX, lddx, BF16, M, K, N, None, epi, aux,
+                             ldaux, None, 0, None, 0, _stream())
+
+    def _lin_dw_ld(self, dY, lddy, X, ldx, wname, M, N, K, bname=None, ws=None):
+        want_b = bname is not None and self.requires_grad[bname]
+        if want_b and (self.precision == "fp32" or not self.requires_grad[wname]):
+            csr = _lib.query("climb_colsum_rows_per_block")
+            _lib.call("climb_colsum", dY, lddy, self.adt, None, 0, ws.part, M, N, _stream())
+            _lib.call("climb_colreduce", ws.part, N, (M + csr - 1) // csr, self.g(bname), N, 1.0, _stream())
+        if not self.requires_grad[wname]:
+            return
+        if self.precision == "fp32":
+            self._gemm_f32(dY, 1, lddy, X, 1, ldx, self.g(wname), K, N, K, M, beta=1.0)
+        else:
+            self._timed_call("gemm_bf16_tn", 2.0 * M * N * K, "climb_gemm_bf16_tn", dY, lddy, X, ldx, self.g(wname), K, M, N, K,
+                             self.g(bname) if want_b else None, _stream())
 
     def reduce3(self, part, nblk, ncols, n0, n1, n2):
         """{dgamma, dbeta, colsum} partials -> three parameter gradients, one launch (names may be None / frozen)."""
@@ -514,6 +555,7 @@ class ViltEngine:
         M = ws.M
         ad = self.active_adapter
         r = self.layout.adapters[ad] if ad is not None else 0
+        prune = self.cls_only_last and ad is None
         for i in range(cfg["layers"]):
             l = f"{ENC}encoder.layer.{i}."
             x = ws.x[i]
@@ -522,6 +564,17 @@ class ViltEngine:
             # fused QKV projection: q/k/v weights are adjacent in the flat buffer (HF:325-327 as one [2304,768] GEMM)
             self.linear_fwd(ws.xn[i], l + "attention.attention.query.weight", l + "attention.attention.query.bias", ws.qkv[i], M, 3 * H, H)
             self.attn_fwd(ws.qkv[i], ws.key_bias, ws.ctx[i], ws.lse[i], B, ws.S_pad)
+            if prune and i == cfg["layers"] - 1:
+                # last layer: only the [CLS] row of every sequence is read downstream (row b * S_pad of the [M, .] operands)
+                SH = ws.S_pad * H
+                self._lin_fwd_ld(ws.ctx[i], SH, l + "attention.output.dense.weight", l + "attention.output.dense.bias", ws.h1c, H, B, H, H,
+                                 EPI_RESID, x, SH, out_f32=True)
+                _lib.call("climb_layernorm_fwd", ws.h1c, H, self.p(l + "layernorm_after.weight"), self.p(l + "layernorm_after.bias"), cfg["ln_eps"],
+                          ws.hnc, H, adt, ws.mean2c, ws.rstd2c, B, H, st)
+                self._lin_fwd_ld(ws.hnc, H, l + "intermediate.dense.weight", l + "intermediate.dense.bias", ws.ac, Fd, B, Fd, H, EPI_GELU,
+                                 None, 0, ws.uc, Fd)
+                self._lin_fwd_ld(ws.ac, Fd, l + "output.dense.weight", l + "output.dense.bias", ws.xLc, H, B, H, Fd, EPI_RESID, ws.h1c, H, out_f32=True)
+                continue
             if ad is None:
                 self.linear_fwd_resid(ws.ctx[i], l + "attention.output.dense.weight", l + "attention.output.dense.bias", ws.h1[i], M, H, H, x)
             else:   # h1 = x + y + up(silu(down(y))),  y = Wo ctx + bo
@@ -537,10 +590,10 @@ class ViltEngine:
                 a_ = f"{l}output.adapters.{ad}."
                 self.linear_fwd(ws.a[i], l + "output.dense.weight", l + "output.dense.bias", ws.yo[i], M, H, Fd)
                 self.adapter_fwd(a_, ws.yo[i], ws.h1[i], ws.zo[i], ws.so[i], ws.x[i + 1], M, H, r)
-        xL = ws.x[cfg["layers"]]
+        xL, ldxL = (ws.xLc, H) if prune else (ws.x[cfg["layers"]], ws.S_pad * H)
         # final LayerNorm only on the row the pooler consumes (token 0 = text [CLS]); `last_hidden_state` is never
         # used by CLiMB (REF/modeling/vilt.py:123-124), so the other S-1 rows are dead work we skip
-        _lib.call("climb_layernorm_fwd", xL, ws.S_pad * H, self.p(ENC + "layernorm.weight"), self.p(ENC + "layernorm.bias"), cfg["ln_eps"],
+        _lib.call("climb_layernorm_fwd", xL, ldxL, self.p(ENC + "layernorm.weight"), self.p(ENC + "layernorm.bias"), cfg["ln_eps"],
                   ws.clsn, H, F32, ws.fmean, ws.frstd, B, H, st)
         if self.precision == "bf16":      # skinny GEMM (M = batch): split-K over all CUs, then the activation (61 -> ~20 us at bs = 64)
             self._gemm_f32(ws.clsn, H, 1, self.p(ENC + "pooler.dense.weight"), H, 1, ws.pooled, H, B, H, H, self.p(ENC + "pooler.dense.bias"))
@@ -553,7 +606,7 @@ class ViltEngine:
             self._generation = getattr(self, "_generation", 0) + 1
             # ViLT-BERT: `inputs_embeds` is BertParams' reusable output buffer, which the next BERT forward of this shape overwrites -- the
             # embedding backward reads it, so the saved copy is its own tensor (7.9 MB at bs = 64)
-            self.saved = dict(ws=ws, input_ids=input_ids, token_type_ids=token_type_ids, adapter=ad, var=var, generation=self._generation,
+            self.saved = dict(ws=ws, input_ids=input_ids, token_type_ids=token_type_ids, adapter=ad, var=var, generation=self._generation, cls_only=prune,
                               inputs_embeds=inputs_embeds.clone() if inputs_embeds is not None else None)
             self.last_ws = ws
         return ws.pooled
@@ -735,14 +788,18 @@ class ViltEngine:
         self._gemm_f32(ws.dpre, H, 1, self.p(pw), 1, H, ws.dclsn, H, B, H, H)
         # final LayerNorm (row 0 of every sequence); all other rows of d(x_L) are zero
         ws.dres.zero_()
-        xL = ws.x[cfg["layers"]]
-        _lib.call("climb_layernorm_bwd", ws.dclsn, H, F32, xL, ws.S_pad * H, ws.fmean, ws.frstd, self.p(ENC + "layernorm.weight"), None, 0,
-                  ws.dres, ws.S_pad * H, None, 0, ws.part, B, H, st)
-        self.reduce3(ws.part, (B + lnb - 1) // lnb, H, ENC + "layernorm.weight", ENC + "layernorm.bias", None)
+        prune = bool(sv.get("cls_only"))
+        SH = ws.S_pad * H
+        xL, ldxL = (ws.xLc, H) if prune else (ws.x[cfg["layers"]], SH)
+        _lib.call("climb_layernorm_bwd", ws.dclsn, H, F32, xL, ldxL, ws.fmean, ws.frstd, self.p(ENC + "layernorm.weight"), None, 0,
+                  ws.dres, SH, None, 0, ws.part, B, H, st)
+        last = f"{ENC}encoder.layer.{cfg['layers'] - 1}."
+        prune = prune and first_layer < cfg["layers"]
+        # (pruned last layer: the column sums of d(x_L) the kernel leaves next to dgamma / dbeta ARE the gradient of the last layer's output bias)
+        self.reduce3(ws.part, (B + lnb - 1) // lnb, H, ENC + "layernorm.weight", ENC + "layernorm.bias", last + "output.dense.bias" if prune else None)
         self._ready(*lay.top_range)
         # d(x_L): cast for the GEMMs (bf16 mode) + column sums for the last layer's output bias
         csr = _lib.query("climb_colsum_rows_per_block")
-        last = f"{ENC}encoder.layer.{cfg['layers'] - 1}."
         G = self._dw_group_size(ws, ad)          # > 0: weight gradients are recorded per layer and launched per group of G layers
         pending, pending_red, group = [], [], []
         rgroup = self._ready_group()
@@ -757,36 +814,43 @@ class ViltEngine:
         dqkv_ = (lambda i: ws.dqkv_l[i]) if G else (lambda i: ws.dqkv)
         dw = (lambda *a, **k: self._dw_defer(pending, *a, **k)) if G else self.dw_async
         nL = cfg["layers"]
-        _lib.call("climb_colsum", ws.dres, H, F32, None if self.precision == "fp32" else dxc(nL), H, ws.part, M, H, st)
-        if first_layer < cfg["layers"] and ad is None:
-            self.bias_grad_from_part(ws.part.data_ptr(), H, (M + csr - 1) // csr, last + "output.dense.bias", H)
+        if prune:       # d(x_L) is non-zero on the [CLS] rows alone: their 16-bit copy is a compact [B, H] operand
+            if self.precision != "fp32":
+                ws.dyc.copy_(ws.dres.view(B, ws.S_pad, H)[:, 0])
+        else:
+            _lib.call("climb_colsum", ws.dres, H, F32, None if self.precision == "fp32" else dxc(nL), H, ws.part, M, H, st)
+            if first_layer < cfg["layers"] and ad is None:
+                self.bias_grad_from_part(ws.part.data_ptr(), H, (M + csr - 1) // csr, last + "output.dense.bias", H)
         for i in range(cfg["layers"] - 1, first_layer - 1, -1):
             l = f"{ENC}encoder.layer.{i}."
-            # MLP: x_{i+1} = h1 + W2 gelu(u) + b2,  u = W1 hn + b1
-            if ad is None:
-                dy = dxc(i + 1)
-                dw(dy, ws.a[i], l + "output.dense.weight", M, H, Fd)
-            else:   # x_{i+1} = h1 + y + up(silu(down(y))): d(y) = d(x_{i+1}) + down^T(silu'(z) * up^T d(x_{i+1}))
-                dy = self.adapter_backward(ws, f"{l}output.adapters.{ad}.", ws.so[i], ws.zo[i], ws.yo[i], M, H, r,
-                                           dxc(i + 1), ws.dz_l[2 * i + 1] if G else ws.dz, dw)
-                dw(dy, ws.a[i], l + "output.dense.weight", M, H, Fd, l + "output.dense.bias", ws)
-            du = du_(i)
-            self.linear_dx(dy, l + "output.dense.weight", du, M, H, Fd, EPI_DGELU, ws.u[i])
-            dw(du, ws.hn[i], l + "intermediate.dense.weight", M, Fd, H, l + "intermediate.dense.bias", ws)
-            self.linear_dx(du, l + "intermediate.dense.weight", ws.dhn, M, Fd, H)
-            self.join_side()          # LN backward overwrites d(residual) that dW2 is reading
-            _lib.call("climb_layernorm_bwd", ws.dhn, H, adt, ws.h1[i], H, ws.mean2[i], ws.rstd2[i], self.p(l + "layernorm_after.weight"),
-                      ws.dres, H, ws.dres, H, None if self.precision == "fp32" else dhc(i), H, lnpart(2 * i + 1), M, H, st)
-            red3(lnpart(2 * i + 1), l + "layernorm_after.weight", l + "layernorm_after.bias", l + "attention.output.dense.bias" if ad is None else None)
-            # attention: h1 = x + Wo ctx + bo
-            if ad is None:
-                dy = dhc(i)
-                dw(dy, ws.ctx[i], l + "attention.output.dense.weight", M, H, H)
+            if prune and i == nL - 1:
+                self._last_layer_backward_cls(ws, l, i)     # MLP, LayerNorm and out-projection on the B [CLS] rows; leaves d(ctx) in ws.dctx
             else:
-                dy = self.adapter_backward(ws, f"{l}attention.output.adapters.{ad}.", ws.sa[i], ws.za[i], ws.ya[i], M, H, r,
-                                           dhc(i), ws.dz_l[2 * i] if G else ws.dz, dw)
-                dw(dy, ws.ctx[i], l + "attention.output.dense.weight", M, H, H, l + "attention.output.dense.bias", ws)
-            self.linear_dx(dy, l + "attention.output.dense.weight", ws.dctx, M, H, H)
+                # MLP: x_{i+1} = h1 + W2 gelu(u) + b2,  u = W1 hn + b1
+                if ad is None:
+                    dy = dxc(i + 1)
+                    dw(dy, ws.a[i], l + "output.dense.weight", M, H, Fd)
+                else:   # x_{i+1} = h1 + y + up(silu(down(y))): d(y) = d(x_{i+1}) + down^T(silu'(z) * up^T d(x_{i+1}))
+                    dy = self.adapter_backward(ws, f"{l}output.adapters.{ad}.", ws.so[i], ws.zo[i], ws.yo[i], M, H, r,
+                                               dxc(i + 1), ws.dz_l[2 * i + 1] if G else ws.dz, dw)
+                    dw(dy, ws.a[i], l + "output.dense.weight", M, H, Fd, l + "output.dense.bias", ws)
+                du = du_(i)
+                self.linear_dx(dy, l + "output.dense.weight", du, M, H, Fd, EPI_DGELU, ws.u[i])
+                dw(du, ws.hn[i], l + "intermediate.dense.weight", M, Fd, H, l + "intermediate.dense.bias", ws)
+                self.linear_dx(du, l + "intermediate.dense.weight", ws.dhn, M, Fd, H)
+                self.join_side()          # LN backward overwrites d(residual) that dW2 is reading
+                _lib.call("climb_layernorm_bwd", ws.dhn, H, adt, ws.h1[i], H, ws.mean2[i], ws.rstd2[i], self.p(l + "layernorm_after.weight"),
+                          ws.dres, H, ws.dres, H, None if self.precision == "fp32" else dhc(i), H, lnpart(2 * i + 1), M, H, st)
+                red3(lnpart(2 * i + 1), l + "layernorm_after.weight", l + "layernorm_after.bias", l + "attention.output.dense.bias" if ad is None else None)
+                # attention: h1 = x + Wo ctx + bo
+                if ad is None:
+                    dy = dhc(i)
+                    dw(dy, ws.ctx[i], l + "attention.output.dense.weight", M, H, H)
+                else:
+                    dy = self.adapter_backward(ws, f"{l}attention.output.adapters.{ad}.", ws.sa[i], ws.za[i], ws.ya[i], M, H, r,
+                                               dhc(i), ws.dz_l[2 * i] if G else ws.dz, dw)
+                    dw(dy, ws.ctx[i], l + "attention.output.dense.weight", M, H, H, l + "attention.output.dense.bias", ws)
+                self.linear_dx(dy, l + "attention.output.dense.weight", ws.dctx, M, H, H)
             dqkv = dqkv_(i)
             self.attn_bwd(ws.qkv[i], ws.key_bias, ws.dctx, ws.ctx[i], ws.lse[i], ws.delta, dqkv, B, ws.S_pad)
             # q/k/v weights and biases are adjacent: one [2304,768] weight-gradient GEMM + one [2304] bias reduction
@@ -825,6 +889,33 @@ class ViltEngine:
         if do_emb:
             self._ready(*lay.embed_range)
         self.saved = None          # the activations are consumed: a later no-grad forward may use this workspace again
+
+    def _last_layer_backward_cls(self, ws: Workspace, l: str, i: int):
+        """Backward of the last layer's MLP, `layernorm_after` and attention out-projection on the B [CLS] rows (`cls_only_last`): d(x_L) is
+        zero everywhere else, so every product below is the dense one with its all-zero rows left out.  In: d(x_L) in the [CLS] rows of
+        ws.dres (fp32, row stride S_pad * H) and ws.dyc (16-bit modes).  Out: d(h1) in the same rows of ws.dres, d(ctx) in ws.dctx (zero
+        off the [CLS] rows), the six parameter gradients accumulated."""
+        cfg = self.cfg
+        B, H, Fd = ws.B, cfg["hidden"], cfg["ffn"]
+        SH, SF = ws.S_pad * H, ws.S_pad * Fd
+        st = _stream()
+        f32 = self.precision == "fp32"
+        lnb = _lib.query("climb_layernorm_bwd_rows_per_block")
+        dy, lddy = (ws.dres, SH) if f32 else (ws.dyc, H)
+        # x_L = h1 + W2 gelu(u) + b2,  u = W1 hn + b1
+        self._lin_dw_ld(dy, lddy, ws.ac, Fd, l + "output.dense.weight", B, H, Fd)
+        self._lin_dx_ld(dy, lddy, l + "output.dense.weight", ws.duc, Fd, B, H, Fd, EPI_DGELU, ws.uc, Fd)
+        self._lin_dw_ld(ws.duc, Fd, ws.hnc, H, l + "intermediate.dense.weight", B, Fd, H, l + "intermediate.dense.bias", ws)
+        self._lin_dx_ld(ws.duc, Fd, l + "intermediate.dense.weight", ws.dhnc, H, B, Fd, H)
+        # hn = LN(h1): d(h1) = d(x_L) + LN'(d(hn)), in place in the [CLS] rows of the residual-gradient stream
+        _lib.call("climb_layernorm_bwd", ws.dhnc, H, self.adt, ws.h1c, H, ws.mean2c, ws.rstd2c, self.p(l + "layernorm_after.weight"),
+                  ws.dres, SH, ws.dres, SH, None if f32 else ws.dhcc, H, ws.part, B, H, st)
+        self.reduce3(ws.part, (B + lnb - 1) // lnb, H, l + "layernorm_after.weight", l + "layernorm_after.bias", l + "attention.output.dense.bias")
+        # h1 = x + Wo ctx + bo
+        dh, lddh = (ws.dres, SH) if f32 else (ws.dhcc, H)
+        self._lin_dw_ld(dh, lddh, ws.ctx[i], SH, l + "attention.output.dense.weight", B, H, H)
+        ws.dctx.zero_()
+        self._lin_dx_ld(dh, lddh, l + "attention.output.dense.weight", ws.dctx, SH, B, H, H)
 
     def adapter_fwd(self, a_: str, y, resid, z_pre, s_act, out, M, H, r):
         """out = resid + y + up(silu(down(y))), saving z = down(y) and s = silu(z) for the backward.  16-bit mode: one launch

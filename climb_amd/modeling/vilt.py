@@ -634,7 +634,7 @@ class ViltContinualLearner(ContinualLearner):
             return self.fused_forward_backward(task_key, images, texts, target, ewc, dropout_keep)
         img = images if isinstance(images, dict) else {"pixel_values": images}
         flags = tuple(sorted(n for n, p in host._params.items() if not p.requires_grad))
-        key = (task_key, self.training, eng.active_adapter, hash(flags), tuple(target.shape), target.dtype,
+        key = (task_key, self.training, eng.active_adapter, eng.cls_only_last, hash(flags), tuple(target.shape), target.dtype,
                tuple((k, tuple(v.shape)) for k, v in sorted(texts.items())), tuple((k, tuple(v.shape)) for k, v in sorted(img.items())))
         graphs = self.__dict__.setdefault("_graphs", {})
         cs = graphs.get(key)

@@ -960,6 +960,40 @@ def test_full_size_batch_permutation_and_mode_agreement():
     assert rel < 3e-2, rel
 
 
+# ------------------------------------------------------------------------------------------------ last layer on its [CLS] rows only
+@pytest.mark.parametrize("precision,tol", [("fp32", 2e-5), (H16, 2e-2)])
+@pytest.mark.parametrize("B,frozen", [(64, 0), (3, 0), (5, 11)])
+def test_last_layer_on_cls_rows_only_equals_every_row(precision, tol, B, frozen):
+    """`ViltEngine.cls_only_last` (opt-in, CLIMB_AMD_CLS_ONLY_LAST=1): after the last layer's attention only the B [CLS] rows go through the out-projection, the MLP
+    and the final LayerNorm, forward and backward -- no other row of x_L has a reader (REF/modeling/vilt.py:123-124 returns pooler_output
+    alone).  The step must be the one that computes every row like the reference does: same pooled / logits / loss and the same gradient of
+    EVERY parameter (fp32: summation order only; 16-bit: the B-row GEMMs run on another kernel, so operand roundings land differently).
+    `frozen` = layers frozen from the bottom (11: the pruned layer is the only one with gradients)."""
+    dev = _dev()
+    pixels, texts, target = _rand_batch(B, 17 + B, dev)
+    model, _ = make_model(["vqa"], 42, precision=precision)
+    if frozen:
+        model.get_encoder().freeze_bottom_k_layers(frozen)
+    model.train()
+    eng = model._host.engine()
+    assert not eng.cls_only_last, "the default step computes every row"
+    out = {}
+    for mode in (True, False):
+        eng.cls_only_last = mode
+        model._host.drop_grads()
+        loss, (pooled, logits), _, _ = model.fused_forward_backward("vqa", pixels, texts, target)
+        out[mode] = (float(loss), pooled.clone(), logits.clone(), {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None})
+    eng.cls_only_last = False
+    (l1, p1, g1, G1), (l0, p0, g0, G0) = out[True], out[False]
+    assert abs(l1 - l0) <= tol * abs(l0), (l1, l0)
+    _close(p1, p0, tol, "pooled")
+    _close(g1, g0, tol, "logits")
+    assert set(G1) == set(G0) and len(G0) > 4
+    # (the key bias shifts every score of a row alike, softmax cancels it: its gradient is rounding noise around zero in both runs)
+    worst = max((_close(G1[n], G0[n], tol * (5 if precision != "fp32" else 1), f"grad {n}"), n) for n in G0 if not n.endswith("attention.key.bias"))
+    print(f"{precision} B={B} frozen={frozen}: {len(G0)} gradients, worst relative difference {worst[0]:.2e} ({worst[1]})")
+
+
 # ------------------------------------------------------------------------------------------------ variable resolution (row F2)
 @pytest.mark.parametrize("fixture", ["vqa_b4_varres.npz", "vqa_b16_mixed.npz"])
 @pytest.mark.parametrize("precision,tol", [("fp32", TOL), (H16, BF16_TOL)])

@@ -5,6 +5,7 @@ residual sums, the pre-GELU and GELU outputs.  GPU box:  python tools/bf16_error
 import os
 import sys
 
+os.environ["CLIMB_AMD_CLS_ONLY_LAST"] = "0"      # this table reads EVERY row of every saved intermediate (the default; pinned here)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
