@@ -133,6 +133,9 @@ def main():
     out = os.path.join(ROOT, "tests", "golden", "driver_calls.json")
     json.dump(golden, open(out, "w"), indent=1)
     print("wrote", out, os.path.getsize(out), "bytes")
+    os.chdir(ROOT)
+    import shutil
+    shutil.rmtree(work, ignore_errors=True)      # 13 GB of checkpoints the scenarios wrote; nothing reads them after the recording
 
 
 if __name__ == "__main__":
