@@ -126,8 +126,9 @@ class Workspace:
         self.dclsn, self.dpre = buf((B, H)), buf((B, H))
         lnb = _lib.query("climb_layernorm_bwd_rows_per_block")
         csr = _lib.query("climb_colsum_rows_per_block")
+        etb = _lib.query("climb_embed_text_bwd_rows_per_block")
         npart = max(((M + lnb - 1) // lnb) * 3 * H, ((M + csr - 1) // csr) * max(Fd, 3 * H),
-                    (self.NP + 1) * 3 * H, ((B * T + 31) // 32) * 3 * H)
+                    (self.NP + 1) * 3 * H, ((B * T + etb - 1) // etb) * 3 * H)
         self.part = buf((npart,))
         self.dpre = buf((B * T, H))
         self.part2 = buf((T * 2 * H,))
@@ -795,8 +796,10 @@ class ViltEngine:
                   ws.dres, SH, None, 0, ws.part, B, H, st)
         last = f"{ENC}encoder.layer.{cfg['layers'] - 1}."
         prune = prune and first_layer < cfg["layers"]
-        # (pruned last layer: the column sums of d(x_L) the kernel leaves next to dgamma / dbeta ARE the gradient of the last layer's output bias)
-        self.reduce3(ws.part, (B + lnb - 1) // lnb, H, ENC + "layernorm.weight", ENC + "layernorm.bias", last + "output.dense.bias" if prune else None)
+        # d(x_L) is non-zero on the B [CLS] rows only, so the column sums the kernel leaves next to dgamma / dbeta ARE the gradient of the last
+        # layer's output bias (no pass over the M - B zero rows)
+        last_bias = last + "output.dense.bias" if (first_layer < cfg["layers"] and ad is None) else None
+        self.reduce3(ws.part, (B + lnb - 1) // lnb, H, ENC + "layernorm.weight", ENC + "layernorm.bias", last_bias)
         self._ready(*lay.top_range)
         # d(x_L): cast for the GEMMs (bf16 mode) + column sums for the last layer's output bias
         csr = _lib.query("climb_colsum_rows_per_block")
@@ -817,10 +820,9 @@ class ViltEngine:
         if prune:       # d(x_L) is non-zero on the [CLS] rows alone: their 16-bit copy is a compact [B, H] operand
             if self.precision != "fp32":
                 ws.dyc.copy_(ws.dres.view(B, ws.S_pad, H)[:, 0])
-        else:
-            _lib.call("climb_colsum", ws.dres, H, F32, None if self.precision == "fp32" else dxc(nL), H, ws.part, M, H, st)
-            if first_layer < cfg["layers"] and ad is None:
-                self.bias_grad_from_part(ws.part.data_ptr(), H, (M + csr - 1) // csr, last + "output.dense.bias", H)
+        elif self.precision != "fp32":      # the GEMMs' 16-bit copy of d(x_L): zeros, and the B rows that are not
+            dxc(nL).zero_()
+            dxc(nL).view(B, ws.S_pad, H)[:, 0].copy_(ws.dres.view(B, ws.S_pad, H)[:, 0])
         for i in range(cfg["layers"] - 1, first_layer - 1, -1):
             l = f"{ENC}encoder.layer.{i}."
             if prune and i == nL - 1:
@@ -971,7 +973,8 @@ class ViltEngine:
                   self.g(te + "word_embeddings.weight") if (rg[te + "word_embeddings.weight"] and ie is None) else None,
                   self.g(te + "position_embeddings.weight") if rg[te + "position_embeddings.weight"] else None,
                   ws.dpre, ws.part, ws.part2, 0 if ie is None else int(ie.shape[1]), st)
-        nb = (B * T + 31) // 32
+        etb = _lib.query("climb_embed_text_bwd_rows_per_block")
+        nb = (B * T + etb - 1) // etb
         # [dgamma | dbeta | dmodality row 0 (text rows)] in one launch; the modality table starts with row 0
         self.reduce3(ws.part, nb, H, te + "LayerNorm.weight", te + "LayerNorm.bias", e + "token_type_embeddings.weight")
         if rg[te + "token_type_embeddings.weight"]:

@@ -44,8 +44,9 @@ int climb_set_option(int key, int value);
  * ids == NULL: `word` is an inputs_embeds matrix [B, emb_ld, H] (emb_ld >= T rows per sequence) used in place of the table lookup
  * (HF TextEmbeddings with inputs_embeds; REF/modeling/viltbert.py:142-147 feeds BERT's last hidden state this way). */
 int climb_embed_text_fwd(const long* ids, const long* tts, const float* word, const float* type, const float* pos, const float* gamma, const float* beta, const float* mod0, float eps, float* x, int B, int T, int S_pad, int H, float* mean, float* rstd, int emb_ld, void* stream);
-/* backward of the above: scatter-adds into dword (atomics), dpos += sum over the batch; part[ceil(B*T/32)][3][H] = {dgamma, dbeta,
+/* backward of the above: scatter-adds into dword (atomics), dpos += sum over the batch; part[ceil(B*T/R)][3][H], R = climb_embed_text_bwd_rows_per_block(), = {dgamma, dbeta,
  * dmodality0} partials; part2[T][2][H] = token-type partials (reduce over T with stride 2H); dpre [B*T,H] scratch */
+int climb_embed_text_bwd_rows_per_block(void);
 int climb_embed_text_bwd(const long* ids, const long* tts, const float* word, const float* type, const float* pos, const float* gamma, const float* mean, const float* rstd, const float* dres, int B, int T, int S_pad, int H, float* dword, float* dpos, float* dpre, float* part, float* part2, int emb_ld, void* stream);
 /* HF:292-300 Conv2d(3,768,k=32,s=32) as a GEMM: out[(b*NP + py*gw + px), c*P*P + ky*P + kx] = pixels[b,c,py*P+ky,px*P+kx] */
 int climb_im2col(const float* pixels, void* out, int out_dtype, int B, int C, int H, int W, int P, void* stream);
