@@ -104,6 +104,27 @@ def main():
 
     for _ in range(args.warmup):
         loss = step()
+    # Data parallel: whether the collectives should run UNDER the backward is a property of the fabric and of what shares the CUs with the
+    # persistent GEMMs, so it is settled here, before the timed region: three untimed steps each way, the slowest rank's
+    # time decides, every rank takes the same decision (CLIMB_AMD_DP_OVERLAP pins it instead).  The timed K steps then run one setting.
+    dp_tuned = None
+    if ddp is not None and (world > 1 or os.environ.get("CLIMB_AMD_FORCE_DDP") == "1") and os.environ.get("CLIMB_AMD_DP_OVERLAP") is None:
+        trial = {}
+        for setting in (True, False):
+            ddp.overlap = setting
+            step()
+            dist.barrier()
+            torch.cuda.synchronize()
+            t_ = time.perf_counter()
+            for _ in range(3):
+                step()
+            dist.barrier()
+            torch.cuda.synchronize()
+            tt = torch.tensor([time.perf_counter() - t_], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            trial[setting] = float(tt.item()) / 3
+        ddp.overlap = trial[True] <= trial[False]
+        dp_tuned = {"overlap_ms": round(trial[True] * 1e3, 3), "deferred_ms": round(trial[False] * 1e3, 3), "chosen": "overlap" if ddp.overlap else "deferred"}
     eng = model._host.engine()
     dominant = "gemm_bf16_nt" if args.precision in ("bf16", "fp16") else "gemm_f32"
     prof = {"kernel": dominant, "events": []}
@@ -215,6 +236,8 @@ def main():
         if ddp is not None:
             out["replicas_in_sync"] = in_sync
             out["dp_overlap"] = bool(ddp.overlap)
+            if dp_tuned:
+                out["dp_overlap_warmup_trial"] = dp_tuned
             out["dp_payload"] = ddp.compress
             out["allreduce_MB_per_step"] = round(ddp.bytes_reduced / 1e6 / (args.steps + args.warmup + (args.steps + 2 if dp_ab else 0)), 1)
             if dp_ab:
