@@ -77,14 +77,17 @@ extern "C" int climb_layernorm_fwd(const float* x, long ldx, const float* gamma,
 //   dxo = dres_in + rstd * (g - mean_c(g) - xhat * mean_c(g * xhat)),  g = dy * gamma, xhat = (x - mean) * rstd
 // Writes dxo (fp32, may alias dres_in), an optional cast of it (next GEMM operand), and per-block partial column
 // sums  part[blk][0]=dgamma, [1]=dbeta, [2]=colsum(dxo)  (reduced deterministically by climb_colreduce).
-#define LNB_ROWS 16  // rows per block (4 waves x 4 rows)
+// rows per block = LNB_WAVES waves x 4 rows.  r03: 8 waves (512 threads) instead of 4 -- the same waves per CU, half the partial-sum rows:
+// 3.5 MB less written per launch and half of what the 24 launches of a step leave for the batched column reduction to read (170 -> 85 MB)
+#define LNB_WAVES 8
+#define LNB_ROWS (4 * LNB_WAVES)
 template <typename TI, typename TO, int NV>
-__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TI* __restrict__ dy, long lddy, const float* __restrict__ x, long ldx,
+__global__ __launch_bounds__(64 * LNB_WAVES) void layernorm_bwd_kernel(const TI* __restrict__ dy, long lddy, const float* __restrict__ x, long ldx,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             const float* __restrict__ gamma, const float* dres_in, long ldr,
                                                             float* dxo, long ldo, TO* __restrict__ dcast, long ldc,
                                                             float* __restrict__ part, int M, int C) {
-  __shared__ __attribute__((aligned(16))) float red[4][NV * 256];
+  __shared__ __attribute__((aligned(16))) float red[LNB_WAVES][NV * 256];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   float4 ag[NV], ab[NV], as[NV];
 #pragma unroll
@@ -95,8 +98,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TI* __restrict
     int c = (i * 64 + lane) * 4;
     gm[i] = (c < C) ? ld4(gamma + c) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
-  for (int rr = 0; rr < LNB_ROWS / 4; ++rr) {
-    const int row = blockIdx.x * LNB_ROWS + rr * 4 + wid;
+  for (int rr = 0; rr < 4; ++rr) {
+    const int row = blockIdx.x * LNB_ROWS + rr * LNB_WAVES + wid;
     if (row >= M) break;
     const float mu = mean[row], rs = rstd[row];
     float4 xh[NV], g[NV], d[NV], rin[NV];
@@ -147,8 +150,12 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TI* __restrict
       *reinterpret_cast<float4*>(&red[wid][c]) = (k == 0 ? ag[i] : (k == 1 ? ab[i] : as[i]));
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < C; c += 256)
-      part[((long)blockIdx.x * 3 + k) * C + c] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+    for (int c = threadIdx.x; c < C; c += 64 * LNB_WAVES) {
+      float t = red[0][c];
+#pragma unroll
+      for (int w = 1; w < LNB_WAVES; ++w) t += red[w][c];
+      part[((long)blockIdx.x * 3 + k) * C + c] = t;
+    }
   }
 }
 
@@ -157,7 +164,7 @@ static int layernorm_bwd_launch(const TI* dy, long lddy, const float* x, long ld
                                 const float* dres_in, long ldr, float* dxo, long ldo, TO* dcast, long ldc, float* part, int M, int C,
                                 hipStream_t st) {
   if (C % 4 || M <= 0) return CLIMB_EINVAL;
-  dim3 grid((M + LNB_ROWS - 1) / LNB_ROWS), blk(256);
+  dim3 grid((M + LNB_ROWS - 1) / LNB_ROWS), blk(64 * LNB_WAVES);
   if (C <= 768)
     hipLaunchKernelGGL((layernorm_bwd_kernel<TI, TO, 3>), grid, blk, 0, st, dy, lddy, x, ldx, mean, rstd, gamma, dres_in, ldr, dxo, ldo, dcast, ldc, part, M, C);
   else if (C <= 1536)

@@ -42,6 +42,18 @@ def _meta(z):
 H16 = os.environ.get("CLIMB_AMD_H16", "bf16")
 
 
+_PARAMS = {}
+
+
+def _seeded_params(tasks, wseed):
+    """vo.init_params, generated once per (tasks, seed) in this process and handed out as fresh clones (the oracle's optimizer updates its
+    copy in place): 3 s of numpy generators per call otherwise, in ~80 tests."""
+    key = (tuple(tasks), wseed)
+    if key not in _PARAMS:
+        _PARAMS[key] = vo.init_params(list(tasks), wseed)
+    return type(_PARAMS[key])((k, v.clone()) for k, v in _PARAMS[key].items())
+
+
 def make_model(tasks, wseed=42, precision="fp32"):
     from climb_amd.modeling import create_continual_learner_map
     from climb_amd.configs.task_configs import task_configs
@@ -49,7 +61,7 @@ def make_model(tasks, wseed=42, precision="fp32"):
     dev = _dev()
     model = create_continual_learner_map["vilt"](model_name_or_path="random-init:0", ordered_cl_tasks=list(tasks),
                                                  model_config=model_configs["vilt"], task_configs=task_configs, device=dev, precision=precision)
-    P = vo.init_params(list(tasks), wseed)
+    P = _seeded_params(tasks, wseed)
     missing, unexpected = model.load_state_dict({k: v for k, v in P.items()}, strict=True)
     model.to(dev)
     return model, P
