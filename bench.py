@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--real-input-only", action="store_true", help="only the `real_input` leg (the trainer loop on JPEG files), printed as JSON")
     ap.add_argument("--child-check", action="store_true", help=argparse.SUPPRESS)       # fp16_operand_line()'s child: run the reference checker leg only
     ap.add_argument("--graph", action="store_true", help="replay the step as a captured hipGraph (measured equal to eager launches at bs=64: the GPU, not the host, is the bottleneck)")
+    ap.add_argument("--no-cls-only-leg", action="store_true", help="skip the extra K steps with CLIMB_AMD_CLS_ONLY_LAST=1 (profiling runs: the trace then holds the default step only)")
     ap.add_argument("--cpu-steps", type=int, default=10, help="timed B=2 CPU steps (BASELINE.md section 4: 10)")
     args = ap.parse_args()
 
@@ -177,7 +178,7 @@ def main():
     # the same K steps with the opt-in dead-row elimination of the last encoder layer (ViltEngine.cls_only_last, DESIGN.md section 5: the
     # rows of x_L that nothing reads are not computed; same loss and gradients) -- reported NEXT TO the headline, which executes every row
     cls_only = None
-    if world == 1 and ddp is None and not eng.cls_only_last:
+    if world == 1 and ddp is None and not eng.cls_only_last and not args.no_cls_only_leg:
         eng.cls_only_last = True
         for _ in range(3):
             step()

@@ -6,11 +6,11 @@ cd /tmp && export TMPDIR=/tmp
 R=/root/repo
 O=$R/gpurun_out/prof_$TAG
 mkdir -p $O
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o r -- python $R/bench.py --no-cpu-baseline --steps 8 --warmup 3 > $O/stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o r -- python $R/bench.py --no-cpu-baseline --no-cls-only-leg --steps 8 --warmup 3 > $O/stats.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_$c -o r -- python $R/bench.py --no-cpu-baseline --steps 2 --warmup 1 > $O/pmc_$c.log 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_$c -o r -- python $R/bench.py --no-cpu-baseline --no-cls-only-leg --steps 2 --warmup 1 > $O/pmc_$c.log 2>&1
 done
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES --kernel-trace --output-format csv -d $O/pmc_mfma -o r -- python $R/bench.py --no-cpu-baseline --steps 2 --warmup 1 > $O/pmc_mfma.log 2>&1
-rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d $O/pmc_lds -o r -- python $R/bench.py --no-cpu-baseline --steps 2 --warmup 1 > $O/pmc_lds.log 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES --kernel-trace --output-format csv -d $O/pmc_mfma -o r -- python $R/bench.py --no-cpu-baseline --no-cls-only-leg --steps 2 --warmup 1 > $O/pmc_mfma.log 2>&1
+rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d $O/pmc_lds -o r -- python $R/bench.py --no-cpu-baseline --no-cls-only-leg --steps 2 --warmup 1 > $O/pmc_lds.log 2>&1
 python $R/bench.py --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_nocpu.json
 ls -la $O
