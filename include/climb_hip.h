@@ -29,6 +29,9 @@ const char* climb_arch(void);
 const char* climb_h16(void);
 const char* climb_error_string(int code);
 int climb_device_sync(void);
+/* diagnostic for bench.py's roofline (no counterpart in the reference): blocks x 4 waves each run `iters` rounds of 16 independent 32x32x16 MFMAs on
+ * register operands read once from src (blocks*256*64 16-bit values); out: blocks*256 floats.  2 * 32*32*16 * 16 * iters * 4 * blocks flops. */
+int climb_mfma_sustained_probe(const void* src, float* out, int blocks, int iters, void* stream);
 /* tuning switches for A/B measurements: key 1 = waves per workgroup of the 128x128 bf16 NT GEMM (4 or 8); key 2 / 4 / 5 = allow the
  * 64x128 / 96x192 / 192x192 NT tile variants (0/1); key 3 = workgroup target of the 128x128 TN split; key 6 = waves per workgroup of the TN GEMM (4 or 8);
  * key 7 = persistent 256-row NT tiles (0 never, 1 auto, 2 / 3 force 256 / 192 columns, 4 two-workgroup variant); key 8 = k-loop-only probe of that kernel;
