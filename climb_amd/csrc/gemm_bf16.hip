@@ -336,6 +336,7 @@ void climb_attn_set_qb(int v);
 void climb_attn_set_bwd_fused(int v);
 void climb_ntsk_enable(int v);
 void climb_ntp_set_sw(int v);
+void climb_ntp_set_dephase(int v);
 void climb_ntsk_set_workspace(void* ptr, long bytes);
 extern "C" int climb_set_option(int key, int value) {
   if (key == 1 && (value == 4 || value == 8)) { g_nt_waves = value; return CLIMB_OK; }
@@ -350,6 +351,7 @@ extern "C" int climb_set_option(int key, int value) {
   if (key == 13 && (value == 0 || value == 1)) { climb_attn_set_bwd_fused(value); return CLIMB_OK; }
   if (key == 14 && (value == 0 || value == 1)) { climb_ntsk_enable(value); return CLIMB_OK; }
   if (key == 15 && (value == 0 || value == 1)) { climb_ntp_set_sw(value); return CLIMB_OK; }
+  if (key == 16 && value >= 0 && value < 4000) { climb_ntp_set_dephase(value); return CLIMB_OK; }
   if (key == 9 && value >= 0) { climb_nt256_set_grid(value); return CLIMB_OK; }
   if (key == 6 && (value == 4 || value == 8)) { g_tn_waves = value; return CLIMB_OK; }
   if (key == 3 && value > 0) { g_tn_target = value; return CLIMB_OK; }

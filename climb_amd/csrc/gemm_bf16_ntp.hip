@@ -238,7 +238,18 @@ __global__ __launch_bounds__(512) void gemm_bf16_ntp_kernel(const bf16_t* __rest
   const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wr = wid >> 1, wc = wid & 1, grp = wid >> 2, half = lane >> 5, l31 = lane & 31;
   const int nbm = (M + NTP_BM - 1) / NTP_BM, nbn = (N + BN - 1) / BN;
-  const int gm = (probe >> 8) ? (probe >> 8) : ((nbm % 8 == 0) ? nbm / 8 : 8);       // M-tiles per supertile (see nt_tile_id_gm); bits 8.. of `probe`: A/B override
+  const int gm = ((probe >> 8) & 255) ? ((probe >> 8) & 255) : ((nbm % 8 == 0) ? nbm / 8 : 8);       // M-tiles per supertile (see nt_tile_id_gm); bits 8..15 of `probe`: A/B override
+  // De-phasing (bits 16.. of `probe`, climb_set_option 16; multi-round launches only): every workgroup starts together and every tile costs
+  // the same, so the whole chip computes, then the whole chip stores -- an HBM burst with idle matrix pipes, then idle HBM under busy pipes.
+  // Workgroup group g = (id / 8) % groups (id % 8 = the XCD: every XCD gets every group) holds back g x dph x 64 clocks ONCE, so that one
+  // group's epilogue falls under the others' k-loops for the rest of the launch.
+  if constexpr (!SW) {
+    const int dph = (probe >> 16) & 1023, ng = 2 << ((probe >> 26) & 3), g = (blockIdx.x >> 3) & (ng - 1);
+    if (dph > 0 && g > 0) {
+      const long t0 = __builtin_readcyclecounter();
+      while (__builtin_readcyclecounter() - t0 < (long)g * dph * 64) __builtin_amdgcn_s_sleep(8);
+    }
+  }
   probe &= 1;
   // fragment read offsets: row (wr*64 | wc*32) + l31 (+ 32 for the second m-block), k-chunk 2 ks + half, swizzled
   unsigned aoff[4], boff[4];
@@ -526,6 +537,8 @@ void climb_nt256_set_grid(int v) { g_nt256_grid = v; }
 // stream (the r01 probe said the same of a concurrent fill).  OFF by default; bit-exact under the race screens of tests/test_gpu_kernels.py.
 static int g_ntp_sw = 0;          // climb_set_option 15: store-wave mode for the multi-round GEMMs without epilogue loads
 void climb_ntp_set_sw(int v) { g_ntp_sw = v; }
+static int g_ntp_dephase = 0;     // climb_set_option 16: v % 1000 = hold-back unit (x 64 clocks) of the de-phased workgroup groups, v / 1000 = k: 2 << k groups
+void climb_ntp_set_dephase(int v) { g_ntp_dephase = v; }
 
 template <typename TO, int EPI, int NI>
 static int ntp_launch_one(int nwg, hipStream_t st, const bf16_t* A, long lda, const bf16_t* B, long ldb, TO* C, long ldc, int M, int N, int K,
@@ -552,8 +565,11 @@ static int ntp_launch_one(int nwg, hipStream_t st, const bf16_t* A, long lda, co
       return CLIMB_OK;
     }
   }
+  int probe = g_nt256_probe & 0xffff;
+  if (g_ntp_dephase > 0 && (long)((M + NTP_BM - 1) / NTP_BM) * ((N + 64 * NI - 1) / (64 * NI)) > nwg)
+    probe |= ((g_ntp_dephase % 1000) & 1023) << 16 | ((g_ntp_dephase / 1000) & 3) << 26;
   hipLaunchKernelGGL((gemm_bf16_ntp_kernel<TO, EPI, NI>), dim3(nwg), dim3(512), LDS, st, A, lda, B, ldb, C, ldc, M, N, K, bias, aux, ldaux, aux_out,
-                     ldauxo, g_nt256_probe);
+                     ldauxo, probe);
   return CLIMB_OK;
 }
 

@@ -38,7 +38,8 @@ int climb_mfma_sustained_probe(const void* src, float* out, int blocks, int iter
  * key 9 = its grid; key 10 = persistent TN kernel (0/1); key 11 = de-phasing of the two-workgroup variant; key 12 = query blocks per wave of the
  * bf16 attention forward (0 auto, 1, 2); key 13 = bf16 attention backward as one launch (1, default) or one launch per phase (0);
  * key 14 = split-along-K balancing of the 192-tile NT GEMMs (0 default: measured slower; 1 needs climb_set_nt_workspace);
- * key 15 = store-wave mode of the persistent NT kernel (0 default: measured slower) */
+ * key 15 = store-wave mode of the persistent NT kernel (0 default: measured slower);
+ * key 16 = de-phased start of the persistent NT kernel's workgroups in multi-round launches: value % 1000 = hold-back unit (x 64 clocks), value / 1000 = k: 2 << k groups (0 = off) */
 int climb_set_option(int key, int value);
 
 /* ---- embeddings -------------------------------------------------------------------------------------------------- */
