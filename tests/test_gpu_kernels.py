@@ -526,6 +526,33 @@ def test_gemm_bf16_nt_split_along_k_balancing(K, epi):
         _lib.call("climb_set_option", 14, 0)          # the library's default: measured slower than one workgroup per tile (see gemm_bf16_ntp.hip)
 
 
+@pytest.mark.parametrize("value", [100, 1050, 3012])
+def test_gemm_bf16_nt_dephased_start_is_the_same_arithmetic(value):
+    """r03 (option 16, OFF by default: measured no gain): workgroup groups of a multi-round persistent NT launch hold back
+    once before their first tile.  Only time moves: the up-projection + GELU (576 tiles on 256 workgroups, both outputs) stays bit-identical."""
+    from climb_amd import _lib
+    dev = _dev()
+    M, N, K = 12288, 3072, 768
+    g = torch.Generator(device=dev).manual_seed(value)
+    Ad = torch.randn(M, K, device=dev, generator=g).to(_h16())
+    Wd = (torch.randn(N, K, device=dev, generator=g) * 0.05).to(_h16())
+    bias = torch.randn(N, device=dev, generator=g)
+
+    def run():
+        out, pre = torch.empty(M, N, device=dev, dtype=_h16()), torch.empty(M, N, device=dev, dtype=_h16())
+        _lib.call("climb_gemm_bf16_nt", Ad, K, Wd, K, out, N, 1, M, N, K, bias, 1, None, 0, pre, N, None, 0, _st())
+        torch.cuda.synchronize()
+        return out, pre
+    try:
+        ref = run()
+        _lib.call("climb_set_option", 16, value)
+        for _ in range(3):
+            got = run()
+            assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
+    finally:
+        _lib.call("climb_set_option", 16, 0)
+
+
 @pytest.mark.parametrize("M,N,K", [(64, 128, 128), (384, 768, 768), (1000, 2304, 768), (300, 768, 3072), (130, 48, 768)])
 def test_gemm_bf16_tn_weight_grad(M, N, K):
     from climb_amd import _lib
