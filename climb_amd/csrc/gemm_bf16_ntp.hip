@@ -264,6 +264,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_ntp_kernel(const bf16_t* __rest
     int tm, tn;
     nt_tile_id_gm(gm, id, nbm, nbn, tm, tn);
     const int m0 = tm * NTP_BM, n0 = tn * BN;
+    // the lane id, recomputed per tile from the exec mask (two instructions) instead of kept in a register across the k-loop: with 256 VGPRs
+    // allocated the residual instantiation used to SPILL it before the tile loop and reload it (scratch load + vmcnt(0)) in every epilogue
+    int ln = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    asm volatile("" : "+v"(ln));
     // LDS-DMA plan: a 1 KB piece = 8 rows x 8 chunks; wave w issues pieces 2w, 2w + 1 of A0 and of A1 and piece w of every B unit
     NtpStage<NI> sg;
     sg.wid = wid;
@@ -274,14 +278,14 @@ __global__ __launch_bounds__(512) void gemm_bf16_ntp_kernel(const bf16_t* __rest
     for (int u = 0; u < 2; ++u)
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        const int slot = (wid * 2 + i) * 64 + lane, r = u * 128 + (slot >> 3), c = (slot & 7) ^ swz(r);
+        const int slot = (wid * 2 + i) * 64 + ln, r = u * 128 + (slot >> 3), c = (slot & 7) ^ swz(r);
         int arow = m0 + r;
         arow = arow < M ? arow : M - 1;                     // clamped rows are computed but never stored
         sg.a_off[u * 2 + i] = (unsigned)(((long)arow * lda + c * 8) * 2);
       }
 #pragma unroll
     for (int p = 0; p < NI; ++p) {
-      const int slot = wid * 64 + lane, r = slot >> 3, c = (slot & 7) ^ swz(r);       // r = 0..63: wave column r >> 5, row r & 31 of n-block p
+      const int slot = wid * 64 + ln, r = slot >> 3, c = (slot & 7) ^ swz(r);       // r = 0..63: wave column r >> 5, row r & 31 of n-block p
       int brow = n0 + (r >> 5) * (32 * NI) + p * 32 + (r & 31);
       brow = brow < N ? brow : N - 1;
       sg.b_off[p] = (unsigned)(((long)brow * ldb + c * 8) * 2);
@@ -324,7 +328,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_ntp_kernel(const bf16_t* __rest
       // epilogue: the k-tile buffers are free; each wave turns its block through a private staging region inside them.
       // `el` is the lane id behind an opaque move, so that none of the epilogue's address arithmetic is hoisted out of the tile
       // loop and kept in registers across the k-loop (measured: 27 spilled registers and a vmcnt(0) in the k-loop otherwise).
-      int el = lane;
+      int el = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
       asm volatile("" : "+v"(el));
       NtBias<NtpEpi<NI>::NIE> bb[NtpEpi<NI>::PER_ROW];
       if constexpr (SW) {

@@ -12,11 +12,11 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # kernels whose spills are a measured trade (see their comments): attention backward phase 1 (168-VGPR cap keeps 3 workgroups per CU),
 # the 192x192 GEMM with the fp32 residual / adapter dual-residual operand prefetched (a few dwords, outside the k-loop),
 # the fp32 128x128 GEMM's adapter-epilogue instantiation (adapters in the fp32 parity mode only)
-# the persistent 256 x 192 GEMM with the fp32 residual epilogue (2 dwords, stored before the tile loop and reloaded in the epilogue: checked in
-# the ISA, never inside the k-loop) and the two-workgroup variant of it that only option 7 = 4 selects;
+# the two-workgroup variant of the persistent GEMM that only option 7 = 4 selects (the persistent 256 x 192 GEMM with the fp32 residual
+# epilogue itself no longer spills: r03, the lane id is recomputed per tile instead of kept across the k-loop);
 # bench.py's pipe-only diagnostic (16 accumulator tiles = all 256 AGPRs + 256 VGPRs at one wave per SIMD: one dword outside its MFMA loop)
 KNOWN = ("gemm_bf16_ntsk_kernelIfLi2E", "attn_bwd_bf16_kernelILi1E", "attn_bwd_bf16_fused_kernel", "gemm_bf16_nt192_kernelIfLi2E", "gemm_bf16_nt192_kernelItLi2E", "gemm_bf16_nt192_kernelIfLi7E",
-         "gemm_bf16_nt192_kernelItLi7E", "gemm_f32_kernelILi128ELi128ELb1E", "gemm_bf16_ntp_kernelIfLi2ELi3E", "gemm_bf16_ntp_kernelItLi2ELi3E",
+         "gemm_bf16_nt192_kernelItLi7E", "gemm_f32_kernelILi128ELi128ELb1E",
          "gemm_bf16_nt2_kernelIfLi2E", "gemm_bf16_nt2_kernelItLi2E", "mfma_sustained_kernel")
 
 
