@@ -51,6 +51,8 @@ def main():
     if args.gpus > 1 and world == 1:
         raise SystemExit("for --gpus N>1 launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
                          "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+    if rank != 0:
+        os.dup2(2, 1)       # only rank 0 owns stdout: whatever another rank's libraries print (RCCL's banner sits in a C stdio buffer until exit) goes to stderr
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -274,7 +276,13 @@ def main():
             if args.precision == "bf16":
                 out["real_input"] = real_input_line(dev, args)
             out["cpu_baseline"] = cpu_baseline(args.cpu_steps)
+        # the JSON line must be the LAST line on stdout: RCCL prints its version banner through C stdio, which is block-buffered on a pipe and would
+        # otherwise come out at process exit, after this line (seen with the forced single-rank RCCL run).  Flush it now, print, then hand fd 1 to stderr.
+        import ctypes
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)
         print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
