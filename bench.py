@@ -113,8 +113,12 @@ def main():
     dp_tuned = None
     if ddp is not None and (world > 1 or os.environ.get("CLIMB_AMD_FORCE_DDP") == "1") and os.environ.get("CLIMB_AMD_DP_OVERLAP") is None:
         trial = {}
-        for setting in (True, False):
-            ddp.overlap = setting
+        # overlap, overlap with 32 / 64 CUs left to RCCL (the persistent GEMM grids shrink while collectives are in flight: parallel.py), deferred
+        settings = {"overlap": (True, 0), "overlap_reserve32": (True, 32), "overlap_reserve64": (True, 64), "deferred": (False, 0)}
+        if os.environ.get("CLIMB_AMD_DP_RESERVE_CUS") is not None:       # pinned reserve: only overlap against deferred, as before
+            settings = {"overlap": (True, ddp.reserve_cus), "deferred": (False, 0)}
+        for setting, (ov, rs) in settings.items():
+            ddp.overlap, ddp.reserve_cus = ov, rs
             step()
             dist.barrier()
             torch.cuda.synchronize()
@@ -126,8 +130,9 @@ def main():
             tt = torch.tensor([time.perf_counter() - t_], dtype=torch.float64, device=dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             trial[setting] = float(tt.item()) / 3
-        ddp.overlap = trial[True] <= trial[False]
-        dp_tuned = {"overlap_ms": round(trial[True] * 1e3, 3), "deferred_ms": round(trial[False] * 1e3, 3), "chosen": "overlap" if ddp.overlap else "deferred"}
+        best = min(trial, key=trial.get)          # every rank holds the same (all-reduced) times: the same decision everywhere
+        ddp.overlap, ddp.reserve_cus = settings[best]
+        dp_tuned = dict({k + "_ms": round(v * 1e3, 3) for k, v in trial.items()}, chosen=best)
     eng = model._host.engine()
     dominant = "gemm_bf16_nt" if args.precision in ("bf16", "fp16") else "gemm_f32"
     prof = {"kernel": dominant, "events": []}
@@ -163,8 +168,8 @@ def main():
     # deferred), so that one multi-GPU run answers whether overlap pays on this fabric
     dp_ab = None
     if ddp is not None and world > 1:
-        first = ddp.overlap
-        ddp.overlap = not first
+        first, first_rs = ddp.overlap, ddp.reserve_cus
+        ddp.overlap, ddp.reserve_cus = not first, 0
         for _ in range(2):
             step()
         fence()
@@ -174,7 +179,7 @@ def main():
         fence()
         other = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
         dist.all_reduce(other, op=dist.ReduceOp.MAX)
-        ddp.overlap = first
+        ddp.overlap, ddp.reserve_cus = first, first_rs
         dp_ab = {("overlap" if not first else "deferred") + "_ms_per_step": round(float(other.item()) / args.steps * 1e3, 3)}
     final_loss = float(loss.item())
     # the same K steps with the opt-in dead-row elimination of the last encoder layer (ViltEngine.cls_only_last, DESIGN.md section 5: the
@@ -261,6 +266,7 @@ def main():
         if ddp is not None:
             out["replicas_in_sync"] = in_sync
             out["dp_overlap"] = bool(ddp.overlap)
+            out["dp_reserved_cus"] = int(ddp.reserve_cus) if ddp.overlap else 0
             if dp_tuned:
                 out["dp_overlap_warmup_trial"] = dp_tuned
             out["dp_payload"] = ddp.compress

@@ -206,6 +206,7 @@ class ViltEngine:
         self._head_ws: Dict[tuple, dict] = {}
         self.requires_grad: Dict[str, bool] = {n: True for n in layout.shapes}
         self.grad_ready_hook: Optional[Callable[[int, int], None]] = None   # (lo, hi) flat range whose grads are final
+        self._cu_reserve = 0             # CUs the persistent GEMMs leave free (set_cu_reserve: collectives running under the backward)
         self.touched: List[tuple] = []                  # flat ranges that received gradients in the last backward
         self.saved = None
         self._unused = set()                            # trainable tensors the last forward did not use (their .grad stays None, like torch's)
@@ -663,6 +664,17 @@ class ViltEngine:
             return 1
         return int(_DW_GROUP) if (_DW_GROUP is not None and int(_DW_GROUP) > 0) else 4
 
+    def set_cu_reserve(self, n: int):
+        """Leave `n` CUs to somebody else (RCCL's collectives under the backward: parallel.GradientAllReducer.reserve_cus): the persistent GEMMs --
+        one workgroup per CU, walking the tiles -- are launched on the remaining ones until this is called again with 0."""
+        n = max(0, int(n))
+        if n == self._cu_reserve:
+            return
+        self._cu_reserve = n
+        if self.precision == "bf16":
+            ncu = torch.cuda.get_device_properties(self.device).multi_processor_count
+            _lib.call("climb_set_option", 9, max(8, (ncu - n) // 8 * 8))        # persistent NT grid (a library-wide setting)
+
     def _dw_defer(self, pending: list, dY, X, wname, M, N, K, bname=None, ws=None):
         """linear_dw, but recorded for the group's launch when the shape fits its 256 x 256 tiles (else run now)."""
         want_b = bname is not None and self.requires_grad[bname]
@@ -674,10 +686,10 @@ class ViltEngine:
         if not pending:
             return
         import numpy as np
-        key = tuple((w, b, dY.data_ptr(), X.data_ptr()) for dY, X, w, b, M, N, K in pending)
+        key = (self._cu_reserve,) + tuple((w, b, dY.data_ptr(), X.data_ptr()) for dY, X, w, b, M, N, K in pending)
         plan = ws.dw_plans.get(key)
         if plan is None:
-            nwg = max(8, torch.cuda.get_device_properties(self.device).multi_processor_count // 8 * 8)
+            nwg = max(8, (torch.cuda.get_device_properties(self.device).multi_processor_count - self._cu_reserve) // 8 * 8)
             rec = np.zeros(len(pending), dtype=[("A", "<u8"), ("B", "<u8"), ("C", "<u8"), ("dbias", "<u8"), ("lda", "<i8"), ("ldb", "<i8"), ("ldc", "<i8"),
                                                 ("M", "<i4"), ("N", "<i4"), ("K", "<i4"), ("reserved", "<i4")])
             assert rec.dtype.itemsize == 72

@@ -83,6 +83,14 @@ class GradientAllReducer:
         self.min_bucket = min_bucket_elems
         self.eng = None
         self.overlap = (os.environ.get("CLIMB_AMD_DP_OVERLAP", "1") != "0") if overlap is None else bool(overlap)
+        # CUs left to RCCL while collectives run UNDER the backward (overlap mode only).  The persistent GEMMs launch one 8-wave / 256-VGPR workgroup
+        # per CU, which cannot share a CU with an RCCL workgroup: with k CUs held by a collective, k of the 256 workgroups of a multi-round launch
+        # only start when the others have finished ALL their tiles (the launch takes twice as long).  With a reserve the engine sizes those grids
+        # to the CUs that are free (tiles spread evenly) from the first collective of a step until finish().  0 = off; bench.py --gpus N tries it
+        # in its warm-up next to plain overlap and deferred collectives and keeps the fastest.
+        self.reserve_cus = int(os.environ.get("CLIMB_AMD_DP_RESERVE_CUS", "0"))
+        self._reserved = False
+        self._in_finish = False
         self._works: List[Tuple[object, List[Tuple[int, int]], Optional[torch.Tensor]]] = []
         self._small: List[Tuple[int, int]] = []
         self._deferred: List[Tuple[int, int]] = []
@@ -142,7 +150,15 @@ class GradientAllReducer:
             self.enabled = prev
 
     # ------------------------------------------------------------------ collectives
+    def _reserve(self, on: bool):
+        if on == self._reserved or self.eng is None or not hasattr(self.eng, "set_cu_reserve"):
+            return
+        self.eng.set_cu_reserve(self.reserve_cus if on else 0)
+        self._reserved = on
+
     def _reduce(self, payload: torch.Tensor, ranges, packed):
+        if self.reserve_cus > 0 and not self._in_finish:      # a collective is about to run next to the rest of the backward
+            self._reserve(True)
         op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
         work = dist.all_reduce(payload, op=op, group=self.pg, async_op=True)
         self._works.append((work, ranges, packed))
@@ -227,10 +243,14 @@ class GradientAllReducer:
         """Block the compute stream on every outstanding collective (no host sync on RCCL) and put the averaged gradients back."""
         if not self.enabled:
             return
-        for lo, hi in self._deferred:
-            self._dispatch(lo, hi)
-        self._deferred.clear()
-        self._flush_small()
+        self._in_finish = True
+        try:
+            for lo, hi in self._deferred:
+                self._dispatch(lo, hi)
+            self._deferred.clear()
+            self._flush_small()
+        finally:
+            self._in_finish = False
         scale = 1.0 if (self._avg or self.world == 1) else 1.0 / self.world
         if self.takes_scaled:            # the half payload was cast from gradients that still carried the loss scale
             scale /= float(getattr(self.eng, "loss_scale", 1.0))
@@ -253,6 +273,7 @@ class GradientAllReducer:
                 else:
                     _scale(self.eng.grad[lo:hi], scale)
         self._works.clear()
+        self._reserve(False)            # nothing of RCCL's is on the chip any more: the persistent grids take every CU again
         self._packs_used = 0            # every collective was waited for: the pack buffers are free (also on paths that never call begin())
 
     def replicas_in_sync(self) -> bool:

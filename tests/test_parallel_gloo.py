@@ -104,6 +104,56 @@ def test_bucketed_allreduce_world2(compress):
         assert nbytes == (4 if compress == "none" else 2) * nelem, "every reported gradient element is reduced exactly once"
 
 
+def _reserve_worker(rank, world, port, q, overlap):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from climb_amd.parallel import GradientAllReducer
+        layout = FlatLayout(["vqa"], TASK_ARITH)
+        eng = _FakeEngine(layout, rank)
+        calls = []
+        eng.set_cu_reserve = calls.append
+        red = GradientAllReducer(None, compress="none", overlap=overlap)
+        red.reserve_cus = 32
+        red.attach(eng)
+        seen_during = []
+        for _ in range(2):          # two steps: the reserve is taken and given back every step
+            red.begin()
+            for lo, hi in eng.backward_order("vqa"):
+                eng.grad_ready_hook(lo, hi)
+                seen_during.append(list(calls))
+            red.finish()
+        q.put((rank, calls, seen_during[0], red.bytes_reduced))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("overlap", [True, False])
+def test_cu_reserve_is_held_only_while_collectives_run_under_the_backward(overlap):
+    """GradientAllReducer.reserve_cus (bench.py tries it in its warm-up): from the first collective launched UNDER the backward until finish() the
+    engine is told to leave CUs to RCCL (persistent GEMM grids shrink); with deferred collectives nothing runs next to the backward and the engine is
+    never asked.  The averaged gradients are the same either way (checked by the tests above: the reserve only sizes launches)."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_reserve_worker, args=(r, world, port, q, overlap)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, calls, first_hook_calls, nbytes in res:
+        assert nbytes > 0
+        if overlap:
+            assert calls == [32, 0, 32, 0], calls          # taken at the first collective of each step, given back by finish()
+            assert first_hook_calls in ([], [32])          # (the head's range may be too small for a collective of its own)
+        else:
+            assert calls == [], calls
+
+
 def test_payload_type_follows_the_librarys_16_bit_type():
     """On the IEEE-half build of the library the 16-bit cast kernels produce half, whose range holds the gradients only while they carry the
     loss scale: the reducer's 16-bit payload is "fp16" there (scaled ranges, scale divided out in finish()) and an explicit bf16 one is
