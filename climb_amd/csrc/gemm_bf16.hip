@@ -352,7 +352,8 @@ extern "C" int climb_set_option(int key, int value) {
   if (key == 14 && (value == 0 || value == 1)) { climb_ntsk_enable(value); return CLIMB_OK; }
   if (key == 15 && (value == 0 || value == 1)) { climb_ntp_set_sw(value); return CLIMB_OK; }
   if (key == 16 && value >= 0 && value < 4000) { climb_ntp_set_dephase(value); return CLIMB_OK; }
-  if (key == 9 && value >= 0) { climb_nt256_set_grid(value); return CLIMB_OK; }
+  if (key == 9 && value >= 0) { climb_nt256_set_grid(value); climb_nt4_set_grid(value); return CLIMB_OK; }
+  if (key == 17 && value >= 0 && value <= 2) { climb_nt4_set(value); return CLIMB_OK; }
   if (key == 6 && (value == 4 || value == 8)) { g_tn_waves = value; return CLIMB_OK; }
   if (key == 3 && value > 0) { g_tn_target = value; return CLIMB_OK; }
   return CLIMB_EINVAL;
@@ -378,6 +379,11 @@ static int nt_dispatch(const bf16_t* A, long lda, const bf16_t* B, long ldb, TO*
   const bool use192 = glds && g_nt_192 == 1 && (N % N192_T) == 0 && K >= 2 * GB_BK && nwg192 >= 160 && nwg192 <= 256;
   // persistent 256 x {256, 192} tiles (gemm_bf16_ntp.hip): the tile width whose last round of 256 workgroups wastes less
   const bool epi256 = epi == EPI_NONE || epi == EPI_GELU || epi == EPI_RESID || epi == EPI_DGELU;
+  if (glds && epi256 && g_nt_256 == 1) {      // (forcing one of the 8-wave tile shapes through option 7 also keeps this kernel out)
+    int rc = climb_nt4_launch(A, lda, B, ldb, C, ldc, sizeof(TO) == 4 ? CLIMB_DT_F32 : CLIMB_DT_BF16, M, N, K, bias, epi, aux, ldaux, aux_out, ldauxo, st);
+    if (rc == CLIMB_OK) { LAUNCH_CHECK(); return CLIMB_OK; }
+    if (rc != CLIMB_EUNSUPPORTED) return rc;
+  }
   if (glds && epi256 && K >= 2 * GB_BK && g_nt_256 != 0) {
     const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256), t192 = (long)((M + 255) / 256) * ((N + 191) / 192);
     const long c256 = (t256 + 255) / 256 * 256, c192 = (t192 + 255) / 256 * 192;       // rounds x tile width

@@ -227,3 +227,9 @@ void climb_tnp_set_workspace(void* ptr, long bytes);
 int climb_nt2_launch(const bf16_t* A, long lda, const bf16_t* B, long ldb, void* C, long ldc, int c_dtype, int M, int N, int K, const float* bias, int epi,
                      const void* aux, long ldaux, bf16_t* aux_out, long ldauxo, hipStream_t st);
 void climb_nt2_set_dephase(int units_of_64_clocks);
+// gemm_bf16_nt4.hip (r04): 192 x 192 tiles, four waves (one per SIMD), two accumulator sets -- the epilogue of a tile runs inside the k-loop of the
+// next one.  CLIMB_EUNSUPPORTED for the shapes / epilogues it does not take.
+int climb_nt4_launch(const bf16_t* A, long lda, const bf16_t* B, long ldb, void* C, long ldc, int c_dtype, int M, int N, int K, const float* bias, int epi,
+                     const void* aux, long ldaux, bf16_t* aux_out, long ldauxo, hipStream_t st);
+void climb_nt4_set(int v);        // climb_set_option 17
+void climb_nt4_set_grid(int v);   // follows climb_set_option 9

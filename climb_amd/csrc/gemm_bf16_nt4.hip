@@ -1,0 +1,467 @@
+// bf16 NT GEMM, 192 x 192 x 64 tiles, ONE persistent workgroup of FOUR waves per CU (one wave per SIMD, up to 512 registers), TWO accumulator
+// sets: the epilogue of tile i runs INSIDE the k-loop of tile i + 1 (r04).
+//
+// Why it exists ("what the r01 - r03 evidence says the next NT kernel is").  In the 8-wave kernels of gemm_bf16_ntp.hip
+// half of a K = 768 tile's time is outside the k-loop: the accumulators ARE the epilogue's input, so the k-loop of the next tile cannot start
+// before the tile has been turned through LDS and stored, and a wave's global stores share vmcnt with its LDS-DMA loads, so the next tile's
+// first counted wait also waits for the whole store burst -- 256 CUs storing in lock step, then 256 CUs computing with HBM idle.  Here
+//   * a workgroup's k-tiles form ONE stream across its tiles: the LDS-DMA of the next tile's first k-tiles is issued during the last k-tiles
+//     of the current one (three 48 KB stages, two whole k-tiles always in flight), so there is no pipeline drain / refill between tiles;
+//   * the last k-step of a tile leaves its result in the second accumulator set; while the next tile accumulates, the finished tile is
+//     drained one 32 x 32 block per k-tile: turned through a 4 KB per-wave LDS region (row-major: a lane gets 4 consecutive columns of one row,
+//     8 lanes a 128-byte line), bias / residual / GELU / x GELU' applied, stored -- 4 to 8 store instructions per k-tile and wave instead of a
+//     burst, each counted vmcnt wait only ever meets stores issued at least a k-tile earlier;
+//   * epilogue operands (fp32 residual, 16-bit pre-activation) are fetched one block ahead by loads the compiler does not see (asm), issued at
+//     the START of a window, i.e. older than the window's 12 DMA instructions: the window's one wait, vmcnt(12), covers them.
+// 192 x 192 because M = 192 B for the benchmark's padded sequences: 12288 x {768, 2304, 3072} is exactly {1, 3, 4} rounds of 256 tiles (the
+// 256-row tiles leave a quarter of the chip idle on the five N = 768 GEMMs of a layer), and 3 stages + the turn regions are exactly 160 KB.
+//
+// Structure.  Waves 2 (M) x 2 (N); wave (wr, wc) owns rows wr*96 .. +96, columns wc*96 .. +96 = [3 m-blocks][3 n-blocks] of
+// v_mfma_f32_32x32x16_bf16 (144 accumulator registers per set), operands swapped as in the other NT kernels (a lane owns one output row x 4
+// consecutive columns per register group).  Stage s = { A image [192 rows][64 k] | B image [192][64] }, 128-byte rows, 16-byte chunks XOR-
+// swizzled by swz(row), filled by LDS-DMA (MUBUF form: per-lane offsets that never change + a scalar offset) with the swizzle on the SOURCE
+// address.  A "window" = k-step 3 of k-tile T and k-steps 0 - 2 of k-tile T + 1 = 36 MFMA slots; every slot = one MFMA + its fillers, pinned
+// by sched_barrier(0): fragment reads of the NEXT k-step (6 per 9 MFMAs, from the stage of k-tile T + 1), the 12 DMA pieces of k-tile T + 3
+// (into the stage k-tile T just left), and the epilogue pieces of one block of the previous tile.  A window ends with
+// { lgkmcnt(0); vmcnt(12); s_barrier }: every wave has read k-tile T + 1's stage for the last time, every wave's share of k-tile T + 2 has landed.
+// The accumulation order over k is that of the 128 x 128 two-barrier kernel: fp32 results are bit-identical to it (race screens in
+// tests/test_gpu_kernels.py).
+//
+// Takes: M % 192 == 0, N % 192 == 0, (M / 192) % 8 == 0, K % 64 == 0, K >= 640, epilogues NONE / GELU / RESID / DGELU.
+#include "gemm_bf16_nt.h"
+
+#define NT4_T 192
+#define NT4_OP (NT4_T * 128)             // one operand image of a k-tile: 24 KB
+#define NT4_STAGE (2 * NT4_OP)           // 48 KB
+#define NT4_TURN (3 * NT4_STAGE)         // 144 KB: the four per-wave turn regions follow
+#define NT4_LDS (NT4_TURN + 4 * 4096)    // 160 KB
+
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+struct Nt4Lane {            // per-lane constants
+  unsigned fo[4];                // fragment read offset of k-step ks inside an operand image, row l31 (the wave's row base and the stage are scalars)
+  unsigned vo[4];                // DMA source offsets: A even / odd piece, B even / odd piece
+  unsigned wr0;                  // turn region, LDS byte ADDRESS of this lane's float4 of register group 0 (asm ds_write); group g: ^ (g << 5)
+  unsigned rd;                   // turn region, byte offset (inside the wave's region) of this lane's row-major float4; + p * 1024
+  unsigned vc, vx, vo2, vb;      // row-major lane offsets (bytes) into C / aux / aux_out / bias
+};
+struct Nt4Walk {            // tile walk of one stream (wave-uniform): tile = (xcd * gm + tml, tn)
+  int tml, tn, gm, step, xcd;
+  __device__ __forceinline__ void advance() { tml += step; while (tml >= gm) { tml -= gm; ++tn; } }
+  __device__ __forceinline__ int m0() const { return (xcd * gm + tml) * NT4_T; }
+  __device__ __forceinline__ int n0() const { return tn * NT4_T; }
+};
+struct Nt4Uni {             // wave-uniform state
+  __amdgpu_buffer_rsrc_t ra, rb, rc, rx, ro, rbias;
+  unsigned pa[6], pb[6];         // byte offset of this wave's DMA piece j inside the tile's A / B rows
+  unsigned lda2, ldb2;           // bytes per operand row
+  unsigned ldc_b, ldx_b, ldo_b;  // bytes per row of C / aux / aux_out
+  unsigned wid;
+  // DMA stream
+  Nt4Walk dw;
+  int dkt, dleft, nk;
+  unsigned curA, curB;           // byte offset of the stream's k-tile: tile rows + k
+  unsigned dma_off, rd_off;      // stage offsets: DMA destination / fragment reads of this window
+  unsigned rda, rdb;             // rd_off + this wave's row base inside the A / B image
+  // finished ("previous") tile: epilogue addressing
+  unsigned cbase, xbase, obase, bbase;
+};
+
+__device__ __forceinline__ bf16x8 ntp_frag_(const unsigned char* p) { return as_bf16x8(*reinterpret_cast<const u32x4*>(p)); }
+
+template <int EPI> struct Nt4Aux { };
+template <> struct Nt4Aux<EPI_RESID> { f32x4 v[4]; };
+template <> struct Nt4Aux<EPI_DGELU> { u32x2 v[4]; };
+
+// ---------------------------------------------------------------------------------------------------- loads the compiler does not count
+// (a register load hipcc can see is waited for with vmcnt(0) as soon as stores are pending: DESIGN.md section 5, "a load behind a store")
+__device__ __forceinline__ void nt4_ld128(f32x4& d, const __amdgpu_buffer_rsrc_t& r, unsigned voff, unsigned soff) {
+  asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(d) : "v"(voff), "s"(r), "s"(soff) : "memory");
+}
+__device__ __forceinline__ void nt4_ld64(u32x2& d, const __amdgpu_buffer_rsrc_t& r, unsigned voff, unsigned soff) {
+  asm volatile("s_nop 4\n\tbuffer_load_dwordx2 %0, %1, %2, %3 offen" : "=v"(d) : "v"(voff), "s"(r), "s"(soff) : "memory");
+}
+template <int EPI> __device__ __forceinline__ void nt4_aux_load(Nt4Aux<EPI>&, int, const Nt4Uni&, const Nt4Lane&, unsigned) {}
+template <> __device__ __forceinline__ void nt4_aux_load<EPI_RESID>(Nt4Aux<EPI_RESID>& a, int p, const Nt4Uni& u, const Nt4Lane& l, unsigned soff) {
+  nt4_ld128(a.v[p], u.rx, l.vx, soff);
+}
+template <> __device__ __forceinline__ void nt4_aux_load<EPI_DGELU>(Nt4Aux<EPI_DGELU>& a, int p, const Nt4Uni& u, const Nt4Lane& l, unsigned soff) {
+  nt4_ld64(a.v[p], u.rx, l.vx, soff);
+}
+// pins the registers of asm loads behind a wait (the compiler must not touch them between load and wait)
+template <int EPI> __device__ __forceinline__ void nt4_pin(Nt4Aux<EPI>&) {}
+template <> __device__ __forceinline__ void nt4_pin<EPI_RESID>(Nt4Aux<EPI_RESID>& a) { asm volatile("" : "+v"(a.v[0]), "+v"(a.v[1]), "+v"(a.v[2]), "+v"(a.v[3])::"memory"); }
+template <> __device__ __forceinline__ void nt4_pin<EPI_DGELU>(Nt4Aux<EPI_DGELU>& a) { asm volatile("" : "+v"(a.v[0]), "+v"(a.v[1]), "+v"(a.v[2]), "+v"(a.v[3])::"memory"); }
+
+// ---------------------------------------------------------------------------------------------------- DMA
+constexpr int nt4_dma_piece(int q) {      // slot -> piece (0..5: A, 6..11: B) or -1
+  const int s[12] = {4, 7, 10, 13, 16, 19, 22, 25, 28, 31, 33, 35};
+  for (int i = 0; i < 12; ++i)
+    if (s[i] == q) return i;
+  return -1;
+}
+template <int J>
+__device__ __forceinline__ void nt4_dma(const Nt4Uni& u, const Nt4Lane& l, unsigned char* smem) {
+  if constexpr (J < 6)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(u.ra, (lds_void_t*)(smem + u.dma_off + (u.wid * 6 + J) * 1024), 16, l.vo[J & 1], u.curA + u.pa[J], 0, 0);
+  else
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(u.rb, (lds_void_t*)(smem + u.dma_off + NT4_OP + (u.wid * 6 + (J - 6)) * 1024), 16, l.vo[2 + (J & 1)],
+                                             u.curB + u.pb[J - 6], 0, 0);
+}
+// next k-tile of the DMA stream; past the workgroup's last k-tile it stays there (the same bytes again, into a stage nobody reads any more)
+__device__ __forceinline__ void nt4_dma_advance(Nt4Uni& u) {
+  ++u.dkt;
+  if (u.dkt == u.nk) {
+    if (u.dleft > 1) { --u.dleft; u.dkt = 0; u.dw.advance(); }
+    else u.dkt = u.nk - 1;
+  }
+  u.curA = (unsigned)u.dw.m0() * u.lda2 + (unsigned)u.dkt * 128u;
+  u.curB = (unsigned)u.dw.n0() * u.ldb2 + (unsigned)u.dkt * 128u;
+}
+
+// ---------------------------------------------------------------------------------------------------- epilogue pieces of one 32 x 32 block
+template <typename TO> __device__ __forceinline__ void nt4_store(const f32x4& v, const __amdgpu_buffer_rsrc_t& r, unsigned voff, unsigned soff);
+template <> __device__ __forceinline__ void nt4_store<float>(const f32x4& v, const __amdgpu_buffer_rsrc_t& r, unsigned voff, unsigned soff) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, 0);
+}
+template <> __device__ __forceinline__ void nt4_store<bf16_t>(const f32x4& v, const __amdgpu_buffer_rsrc_t& r, unsigned voff, unsigned soff) {
+  u32x2 h = {pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)};
+  __builtin_amdgcn_raw_buffer_store_b64(h, r, voff, soff, 0);
+}
+template <int G>
+__device__ __forceinline__ void nt4_stage_write(const f32x16& acc, const Nt4Lane& l) {
+  f32x4 v = {acc[4 * G], acc[4 * G + 1], acc[4 * G + 2], acc[4 * G + 3]};
+  asm volatile("ds_write_b128 %0, %1" ::"v"(l.wr0 ^ (unsigned)(G << 5)), "v"(v) : "memory");
+}
+// one row-major float4 (readback p of block (bi, bj) of the finished tile): bias, epilogue, store(s).  SUB: -1 = everything at once; the GELU
+// kinds spread their arithmetic over MFMA slots: 0 = bias (+ the pre-activation store), 1..4 = element SUB - 1, the last one also stores
+template <typename TO, int EPI, int SUB>
+__device__ __forceinline__ void nt4_unit(f32x4& v, const f32x4& bias, const Nt4Aux<EPI>& ax, int p, int bi, int bj, const Nt4Uni& u, const Nt4Lane& l) {
+  const unsigned rowoff = (unsigned)(bi * 32 + 8 * p);
+  const unsigned csoff = u.cbase + rowoff * u.ldc_b + (unsigned)(bj * 32 * (int)sizeof(TO));
+  if constexpr (EPI == EPI_NONE) {
+    v += bias;
+    nt4_store<TO>(v, u.rc, l.vc, csoff);
+  } else if constexpr (EPI == EPI_RESID) {
+    v += bias;
+    v += ax.v[p];
+    nt4_store<TO>(v, u.rc, l.vc, csoff);
+  } else if constexpr (EPI == EPI_GELU) {
+    if constexpr (SUB <= 0) {
+      v += bias;
+      nt4_store<bf16_t>(v, u.ro, l.vo2, u.obase + rowoff * u.ldo_b + (unsigned)(bj * 64));
+    }
+    if constexpr (SUB < 0) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = gelu_fast(v[k]);
+    }
+    if constexpr (SUB >= 1) v[SUB - 1] = gelu_fast(v[SUB - 1]);
+    if constexpr (SUB < 0 || SUB == 4) nt4_store<TO>(v, u.rc, l.vc, csoff);
+  } else if constexpr (EPI == EPI_DGELU) {
+    if constexpr (SUB <= 0) v += bias;
+    if constexpr (SUB < 0) {
+      const u32x2 w = ax.v[p];
+      v[0] *= dgelu_fast(h16lo_to_f32(w[0])); v[1] *= dgelu_fast(h16hi_to_f32(w[0]));
+      v[2] *= dgelu_fast(h16lo_to_f32(w[1])); v[3] *= dgelu_fast(h16hi_to_f32(w[1]));
+    }
+    if constexpr (SUB >= 1) {
+      const unsigned w = ax.v[p][(SUB - 1) >> 1];
+      v[SUB - 1] *= dgelu_fast(((SUB - 1) & 1) ? h16hi_to_f32(w) : h16lo_to_f32(w));
+    }
+    if constexpr (SUB < 0 || SUB == 4) nt4_store<TO>(v, u.rc, l.vc, csoff);
+  }
+}
+// operand loads of block B of the finished tile, piece p
+template <int EPI>
+__device__ __forceinline__ void nt4_aux_issue(Nt4Aux<EPI>& ax, int p, int bi, int bj, const Nt4Uni& u, const Nt4Lane& l) {
+  if constexpr (EPI == EPI_RESID) nt4_aux_load<EPI>(ax, p, u, l, u.xbase + (unsigned)(bi * 32 + 8 * p) * u.ldx_b + (unsigned)(bj * 128));
+  if constexpr (EPI == EPI_DGELU) nt4_aux_load<EPI>(ax, p, u, l, u.xbase + (unsigned)(bi * 32 + 8 * p) * u.ldx_b + (unsigned)(bj * 64));
+}
+__device__ __forceinline__ void nt4_bias_issue(f32x4 (&bias)[3], int j, const Nt4Uni& u, const Nt4Lane& l) { nt4_ld128(bias[j], u.rbias, l.vb, u.bbase + (unsigned)(j * 128)); }
+// coordinates of the tile that has just been finished -> epilogue bases
+template <typename TO, int EPI>
+__device__ __forceinline__ void nt4_set_prev(Nt4Uni& u, int m0, int n0) {
+  const unsigned wr = u.wid >> 1, wc = u.wid & 1;
+  const unsigned mrow = (unsigned)m0 + wr * 96u, ncol = (unsigned)n0 + wc * 96u;
+  u.cbase = mrow * u.ldc_b + ncol * (unsigned)sizeof(TO);
+  u.xbase = mrow * u.ldx_b + ncol * (EPI == EPI_RESID ? 4u : 2u);
+  u.obase = mrow * u.ldo_b + ncol * 2u;
+  u.bbase = ncol * 4u;
+}
+
+// ---------------------------------------------------------------------------------------------------- one MFMA slot
+// CFG: SW   switch window (k-step 3 finishes a tile INTO accP, k-step 0 starts the next one from zero)
+//      EB   block of the finished tile drained in this window (-1: none);  AB: block whose operands are fetched (-1: none);  BL: bias loads
+//      DMA  the 12 pieces of k-tile T + 3;  RD: fragment reads (off in the workgroup's very last k-step)
+template <bool SW_, int EB_, int AB_, bool BL_, bool DMA_, bool RD_> struct Nt4Cfg {
+  static constexpr bool SW = SW_, BL = BL_, DMA = DMA_, RD = RD_;
+  static constexpr int EB = EB_, AB = AB_;
+};
+template <typename TO, int EPI, class CFG, int Q>
+__device__ __forceinline__ void nt4_slot(f32x16 (&accC)[3][3], f32x16 (&accP)[3][3], bf16x8 (&fa)[2][3], bf16x8 (&fb)[2][3], f32x4 (&rbk)[4],
+                                         f32x4 (&bias)[3], Nt4Aux<EPI> (&aux)[2], const Nt4Uni& u, const Nt4Lane& l, unsigned char* smem) {
+  constexpr int st = Q / 9, blk = Q % 9, bi = blk / 3, bj = blk % 3;
+  constexpr int par = (st == 0) ? 1 : ((st - 1) & 1);
+  if constexpr (CFG::SW && st == 0) accP[bi][bj] = CLIMB_MFMA_H16(fb[par][bj], fa[par][bi], accC[bi][bj], 0, 0, 0);
+  else if constexpr (CFG::SW && st == 1) {
+    const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    accC[bi][bj] = CLIMB_MFMA_H16(fb[par][bj], fa[par][bi], z, 0, 0, 0);
+  } else accC[bi][bj] = CLIMB_MFMA_H16(fb[par][bj], fa[par][bi], accC[bi][bj], 0, 0, 0);
+  __builtin_amdgcn_sched_barrier(0);
+  // fragment reads of the next k-step (k-step `st` of the k-tile this window reads), in the order the next k-step consumes them
+  if constexpr (CFG::RD && blk < 6) {
+    if constexpr (blk == 0) fb[par ^ 1][0] = ntp_frag_(smem + (u.rdb + l.fo[st]));
+    if constexpr (blk == 1) fa[par ^ 1][0] = ntp_frag_(smem + (u.rda + l.fo[st]));
+    if constexpr (blk == 2) fb[par ^ 1][1] = ntp_frag_(smem + (u.rdb + l.fo[st]) + 4096);
+    if constexpr (blk == 3) fb[par ^ 1][2] = ntp_frag_(smem + (u.rdb + l.fo[st]) + 8192);
+    if constexpr (blk == 4) fa[par ^ 1][1] = ntp_frag_(smem + (u.rda + l.fo[st]) + 4096);
+    if constexpr (blk == 5) fa[par ^ 1][2] = ntp_frag_(smem + (u.rda + l.fo[st]) + 8192);
+  }
+  // switch window: block b of the finished tile leaves the accumulator file (MFMA results are AGPRs) one slot before block b of the next tile
+  // starts there -- otherwise both sets are live in the AGPR file at once (288 > 256: scratch spills, measured)
+  if constexpr (CFG::SW && CFG::RD && Q >= 8 && Q < 17) asm volatile("" : "+v"(accP[(Q - 8) / 3][(Q - 8) % 3]));
+  // operand loads of the block drained in the NEXT window (older than every DMA piece of this window: slots 0..3, first piece in slot 4)
+  if constexpr (Q < 4 && CFG::AB >= 0) nt4_aux_issue<EPI>(aux[CFG::AB & 1], Q, CFG::AB / 3, CFG::AB % 3, u, l);
+  if constexpr (Q < 3 && CFG::BL) nt4_bias_issue(bias, Q, u, l);
+  if constexpr (CFG::DMA && nt4_dma_piece(Q) >= 0) nt4_dma<(nt4_dma_piece(Q) < 0 ? 0 : nt4_dma_piece(Q))>(u, l, smem);
+  if constexpr (CFG::EB >= 0) {
+    constexpr int ei = CFG::EB / 3, ej = CFG::EB % 3;
+    // turn: 4 writes, then 4 row-major reads (LDS operations of one wave execute in order: no wait in between)
+    if constexpr (Q == 1) nt4_stage_write<0>(accP[ei][ej], l);
+    if constexpr (Q == 2) nt4_stage_write<1>(accP[ei][ej], l);
+    if constexpr (Q == 3) nt4_stage_write<2>(accP[ei][ej], l);
+    if constexpr (Q == 5) nt4_stage_write<3>(accP[ei][ej], l);
+    if constexpr (EPI == EPI_GELU || EPI == EPI_DGELU) {
+      // unit p = slots 7 + 6 p .. 13 + 6 p: readback, (one slot for the LDS latency), bias (+ pre-activation store), one element per slot, store
+      constexpr int p = Q >= 7 && Q < 31 ? (Q - 7) / 6 : -1, o = Q >= 7 && Q < 31 ? (Q - 7) % 6 : -1;
+      if constexpr (p >= 0 && o == 0) rbk[p] = *reinterpret_cast<const f32x4*>(smem + NT4_TURN + u.wid * 4096 + l.rd + p * 1024);
+      if constexpr (p >= 0 && o >= 2) nt4_unit<TO, EPI, o - 2>(rbk[p], bias[ej], aux[CFG::EB & 1], p, ei, ej, u, l);
+      // the last element + store of unit p share the slot of unit p + 1's readback (31 for the fourth)
+      if constexpr (Q == 13 || Q == 19 || Q == 25 || Q == 31) nt4_unit<TO, EPI, 4>(rbk[(Q - 13) / 6], bias[ej], aux[CFG::EB & 1], (Q - 13) / 6, ei, ej, u, l);
+    } else {
+      constexpr int p = Q == 12 ? 0 : Q == 18 ? 1 : Q == 24 ? 2 : Q == 30 ? 3 : -1;
+      constexpr int rp = Q == 9 ? 0 : Q == 15 ? 1 : Q == 21 ? 2 : Q == 27 ? 3 : -1;
+      if constexpr (rp >= 0) rbk[rp] = *reinterpret_cast<const f32x4*>(smem + NT4_TURN + u.wid * 4096 + l.rd + rp * 1024);
+      if constexpr (p >= 0) nt4_unit<TO, EPI, -1>(rbk[p], bias[ej], aux[CFG::EB & 1], p, ei, ej, u, l);
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+}
+template <typename TO, int EPI, class CFG, int Q, int QE>
+__device__ __forceinline__ void nt4_slots(f32x16 (&accC)[3][3], f32x16 (&accP)[3][3], bf16x8 (&fa)[2][3], bf16x8 (&fb)[2][3], f32x4 (&rbk)[4],
+                                          f32x4 (&bias)[3], Nt4Aux<EPI> (&aux)[2], const Nt4Uni& u, const Nt4Lane& l, unsigned char* smem) {
+  if constexpr (Q < QE) {
+    nt4_slot<TO, EPI, CFG, Q>(accC, accP, fa, fb, rbk, bias, aux, u, l, smem);
+    nt4_slots<TO, EPI, CFG, Q + 1, QE>(accC, accP, fa, fb, rbk, bias, aux, u, l, smem);
+  }
+}
+// end of a window: this wave has read the stage of k-tile T + 1 for the last time and its share of k-tile T + 2 has landed (only the VM youngest
+// loads -- the window's DMA pieces -- may still be in flight; everything older, the asm operand loads included, has returned); then everybody's
+__device__ __forceinline__ void nt4_set_rd(Nt4Uni& u, unsigned off) {
+  u.rd_off = off;
+  u.rda = off + (u.wid >> 1) * (96u * 128u);
+  u.rdb = off + NT4_OP + (u.wid & 1) * (96u * 128u);
+}
+template <int VM, int EPI>
+__device__ __forceinline__ void nt4_window_end(Nt4Uni& u, Nt4Aux<EPI> (&aux)[2], f32x4 (&bias)[3]) {
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM) : "memory");
+  nt4_pin<EPI>(aux[0]);
+  nt4_pin<EPI>(aux[1]);
+  asm volatile("" : "+v"(bias[0]), "+v"(bias[1]), "+v"(bias[2])::"memory");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+  u.dma_off = u.rd_off;
+  nt4_set_rd(u, u.rd_off + NT4_STAGE == 3 * NT4_STAGE ? 0u : u.rd_off + NT4_STAGE);
+}
+template <typename TO, int EPI, class CFG>
+__device__ __forceinline__ void nt4_window(f32x16 (&accC)[3][3], f32x16 (&accP)[3][3], bf16x8 (&fa)[2][3], bf16x8 (&fb)[2][3], f32x4 (&rbk)[4],
+                                           f32x4 (&bias)[3], Nt4Aux<EPI> (&aux)[2], Nt4Uni& u, const Nt4Lane& l, unsigned char* smem) {
+  nt4_dma_advance(u);
+  nt4_slots<TO, EPI, CFG, 0, 36>(accC, accP, fa, fb, rbk, bias, aux, u, l, smem);
+  nt4_window_end<12, EPI>(u, aux, bias);
+}
+
+template <typename TO, int EPI, int E0, int E1>
+__device__ __forceinline__ void nt4_final(f32x16 (&accP)[3][3], f32x4 (&rbk)[4], f32x4 (&bias)[3], const Nt4Uni& u, const Nt4Lane& l, unsigned char* smem) {
+  Nt4Aux<EPI> ax[E1 - E0];
+#pragma unroll
+  for (int e = E0; e < E1; ++e)
+#pragma unroll
+    for (int p = 0; p < 4; ++p) nt4_aux_issue<EPI>(ax[e - E0], p, e / 3, e % 3, u, l);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int e = E0; e < E1; ++e) nt4_pin<EPI>(ax[e - E0]);
+  asm volatile("" : "+v"(bias[0]), "+v"(bias[1]), "+v"(bias[2])::"memory");
+#pragma unroll
+  for (int e = E0; e < E1; ++e) {
+    nt4_stage_write<0>(accP[e / 3][e % 3], l); nt4_stage_write<1>(accP[e / 3][e % 3], l);
+    nt4_stage_write<2>(accP[e / 3][e % 3], l); nt4_stage_write<3>(accP[e / 3][e % 3], l);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) rbk[p] = *reinterpret_cast<const f32x4*>(smem + NT4_TURN + u.wid * 4096 + l.rd + p * 1024);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) nt4_unit<TO, EPI, -1>(rbk[p], bias[e % 3], ax[e - E0], p, e / 3, e % 3, u, l);
+  }
+}
+
+template <typename TO, int EPI>
+__global__ __launch_bounds__(256) void gemm_bf16_nt4_kernel(const bf16_t* A, long lda, const bf16_t* B, long ldb, TO* C, long ldc, int M, int N, int K, const float* bias_g,
+                                                            const void* aux_g, long ldaux, bf16_t* aux_out, long ldauxo) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = threadIdx.x & 63;
+  Nt4Uni u;
+  Nt4Lane l;
+  u.wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int half = lane >> 5, l31 = lane & 31;
+  const int nbm = M / NT4_T, nbn = N / NT4_T, nwg = nbm * nbn, G = gridDim.x;
+  const int ntw = (nwg - (int)blockIdx.x + G - 1) / G;          // tiles of this workgroup (>= 1)
+  u.nk = K / GB_BK;
+  // resources: raw buffers (stride 0), range = 2 GB (the launcher checks sizes); a missing bias reads as zeros through an empty range
+  u.ra = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, 0x7fffffff, 0x00020000);
+  u.rb = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, 0x7fffffff, 0x00020000);
+  u.rc = __builtin_amdgcn_make_buffer_rsrc((void*)C, 0, 0x7fffffff, 0x00020000);
+  u.rx = __builtin_amdgcn_make_buffer_rsrc((void*)aux_g, 0, 0x7fffffff, 0x00020000);
+  u.ro = __builtin_amdgcn_make_buffer_rsrc((void*)aux_out, 0, 0x7fffffff, 0x00020000);
+  u.rbias = __builtin_amdgcn_make_buffer_rsrc((void*)bias_g, 0, bias_g ? N * 4 : 0, 0x00020000);
+  u.lda2 = (unsigned)lda * 2u;
+  u.ldb2 = (unsigned)ldb * 2u;
+  u.ldc_b = (unsigned)ldc * (unsigned)sizeof(TO);
+  u.ldx_b = (unsigned)ldaux * (EPI == EPI_RESID ? 4u : 2u);
+  u.ldo_b = (unsigned)ldauxo * 2u;
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    u.pa[j] = (u.wid * 48u + 8u * j) * u.lda2;
+    u.pb[j] = (u.wid * 48u + 8u * j) * u.ldb2;
+  }
+  // lane constants
+  {
+    const int r8 = lane >> 3, sl = lane & 7;
+    const int ce = sl ^ swz(r8), co = sl ^ swz(8 + r8);
+    l.vo[0] = (unsigned)r8 * u.lda2 + ce * 16;
+    l.vo[1] = (unsigned)r8 * u.lda2 + co * 16;
+    l.vo[2] = (unsigned)r8 * u.ldb2 + ce * 16;
+    l.vo[3] = (unsigned)r8 * u.ldb2 + co * 16;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) l.fo[ks] = l31 * 128 + (((2 * ks + half) ^ swz(l31)) << 4);
+    const unsigned base = (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char*)smem;
+    l.wr0 = base + NT4_TURN + u.wid * 4096 + l31 * 128 + ((half ^ (l31 & 7)) << 4);
+    l.rd = r8 * 128 + (((sl ^ r8) & 7) << 4);
+    l.vc = (unsigned)r8 * u.ldc_b + sl * 4 * (unsigned)sizeof(TO);
+    l.vx = (unsigned)r8 * u.ldx_b + sl * (EPI == EPI_RESID ? 16u : 8u);
+    l.vo2 = (unsigned)r8 * u.ldo_b + sl * 8u;
+    l.vb = sl * 16u;
+  }
+  // tile walk: launch position id -> XCD id % 8, whose share is ONE supertile of gm = nbm / 8 M-tiles x all N-tiles, walked M first
+  Nt4Walk cw;
+  cw.gm = nbm / 8;
+  cw.step = G / 8;
+  cw.xcd = blockIdx.x & 7;
+  cw.tn = (blockIdx.x >> 3) / cw.gm;
+  cw.tml = (blockIdx.x >> 3) - cw.tn * cw.gm;
+  u.dw = cw;
+  u.dleft = ntw;
+  u.dkt = -1;
+  u.dma_off = 0;
+  f32x16 accC[3][3], accP[3][3];
+  bf16x8 fa[2][3], fb[2][3];
+  f32x4 rbk[4], bias[3];
+  Nt4Aux<EPI> aux[2];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) bias[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // prologue: k-tiles 0, 1, 2 of the stream into stages 0, 1, 2
+#pragma unroll
+  for (int s = 0; s < 3; ++s) {
+    nt4_dma_advance(u);
+    u.dma_off = s * NT4_STAGE;
+    nt4_dma<0>(u, l, smem); nt4_dma<1>(u, l, smem); nt4_dma<2>(u, l, smem); nt4_dma<3>(u, l, smem); nt4_dma<4>(u, l, smem); nt4_dma<5>(u, l, smem);
+    nt4_dma<6>(u, l, smem); nt4_dma<7>(u, l, smem); nt4_dma<8>(u, l, smem); nt4_dma<9>(u, l, smem); nt4_dma<10>(u, l, smem); nt4_dma<11>(u, l, smem);
+  }
+  asm volatile("s_waitcnt vmcnt(24)" ::: "memory");          // k-tile 0 is all this half window reads
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+  nt4_set_rd(u, 0);
+  fb[0][0] = ntp_frag_(smem + (u.rdb + l.fo[0]));
+  fa[0][0] = ntp_frag_(smem + (u.rda + l.fo[0]));
+  fb[0][1] = ntp_frag_(smem + (u.rdb + l.fo[0]) + 4096);
+  fb[0][2] = ntp_frag_(smem + (u.rdb + l.fo[0]) + 8192);
+  fa[0][1] = ntp_frag_(smem + (u.rda + l.fo[0]) + 4096);
+  fa[0][2] = ntp_frag_(smem + (u.rda + l.fo[0]) + 8192);
+  // the second half of a switch window: k-steps 0 - 2 of the first tile's k-tile 0 (no DMA: k-tile 2 is already on its way)
+  nt4_slots<TO, EPI, Nt4Cfg<true, -1, -1, false, false, true>, 9, 36>(accC, accP, fa, fb, rbk, bias, aux, u, l, smem);
+  nt4_window_end<0, EPI>(u, aux, bias);           // k-tiles 1 and 2 have landed
+  u.dma_off = 0;                                  // the stage k-tile 0 leaves at the end of the next window's k-step 3 ... which IS where piece 0 is issued (slot 4 of k-step 3: after this barrier every wave holds its k-step-3 fragments)
+  const int nk = u.nk;
+  for (int t = 0;; ++t) {
+    int w0 = 0;
+    if (t > 0) {
+      nt4_window<TO, EPI, Nt4Cfg<false, 0, 1, false, true, true>>(accC, accP, fa, fb, rbk, bias, aux, u, l, smem);
+      nt4_window<TO, EPI, Nt4Cfg<false, 1, 2, false, true, true>>(accC, accP, fa, fb, rbk, bias, aux, u, l, smem);
+      nt4_window<TO, EPI, Nt4Cfg<false, 2, 3, false, true, true>>(accC, accP, fa, fb, rbk, bias, aux, u, l, smem);
+      nt4_window<TO, EPI, Nt4Cfg<false, 3, 4, false, true, true>>(accC, accP, fa, fb, rbk, bias, aux, u, l, smem);
+      nt4_window<TO, EPI, Nt4Cfg<false, 4, 5, false, true, true>>(accC, accP, fa, fb, rbk, bias, aux, u, l, smem);
+      nt4_window<TO, EPI, Nt4Cfg<false, 5, 6, false, true, true>>(accC, accP, fa, fb, rbk, bias, aux, u, l, smem);
+      nt4_window<TO, EPI, Nt4Cfg<false, 6, 7, false, true, true>>(accC, accP, fa, fb, rbk, bias, aux, u, l, smem);
+      nt4_window<TO, EPI, Nt4Cfg<false, 7, 8, false, true, true>>(accC, accP, fa, fb, rbk, bias, aux, u, l, smem);
+      nt4_window<TO, EPI, Nt4Cfg<false, 8, -1, false, true, true>>(accC, accP, fa, fb, rbk, bias, aux, u, l, smem);
+      w0 = 9;
+    }
+    for (int w = w0; w + 1 < nk; ++w) nt4_window<TO, EPI, Nt4Cfg<false, -1, -1, false, true, true>>(accC, accP, fa, fb, rbk, bias, aux, u, l, smem);
+    // the tile is finished by the next k-step 3: its coordinates become the epilogue's
+    nt4_set_prev<TO, EPI>(u, cw.m0(), cw.n0());
+    if (t + 1 < ntw) {
+      nt4_window<TO, EPI, Nt4Cfg<true, -1, 0, true, true, true>>(accC, accP, fa, fb, rbk, bias, aux, u, l, smem);
+      cw.advance();
+    } else {
+      nt4_slots<TO, EPI, Nt4Cfg<true, -1, -1, false, false, false>, 0, 9>(accC, accP, fa, fb, rbk, bias, aux, u, l, smem);
+      break;
+    }
+  }
+  // the workgroup's last tile: nothing left to hide under.  Operands first (no store is pending that a load could queue behind), one wait,
+  // then the blocks; the fp32 residual (16 registers per block) in two rounds, the second behind the first round's stores
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int j = 0; j < 3; ++j) nt4_bias_issue(bias, j, u, l);
+  nt4_final<TO, EPI, 0, (EPI == EPI_RESID ? 5 : 9)>(accP, rbk, bias, u, l, smem);
+  if constexpr (EPI == EPI_RESID) nt4_final<TO, EPI, 5, 9>(accP, rbk, bias, u, l, smem);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // no LDS-DMA may outlive the workgroup's LDS allocation
+}
+
+static int g_nt4 = 1;             // climb_set_option 17: 0 = never, 1 = where it applies (default), 2 = also below the size the 8-wave kernels keep
+static int g_nt4_grid = 256;      // follows climb_set_option 9 (CUs left to RCCL)
+void climb_nt4_set(int v) { g_nt4 = v; }
+void climb_nt4_set_grid(int v) { g_nt4_grid = v; }
+
+template <typename TO, int EPI>
+static int nt4_launch_one(int nwg, hipStream_t st, const bf16_t* A, long lda, const bf16_t* B, long ldb, TO* C, long ldc, int M, int N, int K, const float* bias,
+                          const void* aux, long ldaux, bf16_t* aux_out, long ldauxo) {
+  static bool configured = false;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_nt4_kernel<TO, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, NT4_LDS);
+    if (e != hipSuccess) return (int)e;
+    configured = true;
+  }
+  hipLaunchKernelGGL((gemm_bf16_nt4_kernel<TO, EPI>), dim3(nwg), dim3(256), NT4_LDS, st, A, lda, B, ldb, C, ldc, M, N, K, bias, aux, ldaux, aux_out, ldauxo);
+  return CLIMB_OK;
+}
+
+int climb_nt4_launch(const bf16_t* A, long lda, const bf16_t* B, long ldb, void* C, long ldc, int c_dtype, int M, int N, int K, const float* bias, int epi,
+                     const void* aux, long ldaux, bf16_t* aux_out, long ldauxo, hipStream_t st) {
+  if (g_nt4 == 0) return CLIMB_EUNSUPPORTED;
+  if ((M % NT4_T) || (N % NT4_T) || ((M / NT4_T) % 8) || (K % GB_BK) || K < 10 * GB_BK) return CLIMB_EUNSUPPORTED;
+  const long lim = 1L << 31;
+  if (((long)M * lda + K) * 2 >= lim || ((long)N * ldb + K) * 2 >= lim || (long)M * ldc * 4 >= lim || (long)M * ldaux * 4 >= lim || (long)M * ldauxo * 2 >= lim)
+    return CLIMB_EUNSUPPORTED;
+  const int tiles = (M / NT4_T) * (N / NT4_T);
+  int grid = g_nt4_grid > 0 ? (g_nt4_grid / 8) * 8 : 256;
+  if (grid < 8) grid = 8;
+  const int nwg = tiles < grid ? tiles : grid;      // tiles is a multiple of 8
+#define L4(TO, E) return nt4_launch_one<TO, E>(nwg, st, A, lda, B, ldb, (TO*)C, ldc, M, N, K, bias, aux, ldaux, aux_out, ldauxo)
+  if (c_dtype == CLIMB_DT_BF16 && epi == EPI_NONE) L4(bf16_t, EPI_NONE);
+  if (c_dtype == CLIMB_DT_BF16 && epi == EPI_GELU) L4(bf16_t, EPI_GELU);
+  if (c_dtype == CLIMB_DT_BF16 && epi == EPI_DGELU) L4(bf16_t, EPI_DGELU);
+  if (c_dtype == CLIMB_DT_F32 && epi == EPI_RESID) L4(float, EPI_RESID);
+  if (c_dtype == CLIMB_DT_F32 && epi == EPI_NONE) L4(float, EPI_NONE);
+#undef L4
+  return CLIMB_EUNSUPPORTED;
+}
