@@ -482,6 +482,62 @@ def test_gemm_bf16_nt_256_race_screen_full_size(N, K, force):
         _lib.call("climb_set_option", 5, 1)
 
 
+@pytest.mark.parametrize("M,N,K", [(1536, 192, 640), (1536, 384, 704), (3072, 768, 1536), (12288, 768, 768), (12288, 2304, 768), (12288, 3072, 768), (12288, 768, 3072)])
+def test_gemm_bf16_nt4_two_accumulator_sets_bit_identical(M, N, K):
+    """r04: the 192 x 192 / four-wave / two-accumulator-set kernel (gemm_bf16_nt4.hip; option 17, ON by default where it applies) drains tile i inside
+    tile i + 1's k-loop: a hand-placed schedule of LDS-DMA pieces, asm operand loads, one counted wait and one barrier per k-tile.  It accumulates k in
+    the order of every other NT kernel and applies the same fp32 epilogue arithmetic, so EVERY output of every epilogue must equal the 8-wave kernels'
+    bit for bit -- at the minimum k-tile count (10), an odd one, one tile per workgroup (single round: everything in the exposed final drain), several
+    tiles per workgroup (the overlapped drain), with and without a bias -- and stay so when repeated under load (NaN-filled outputs: a block that is
+    never stored, or stored early, shows).  The 8-wave reference is itself pinned to float64 and to the two-barrier kernel by the tests above."""
+    from climb_amd import _lib
+    dev = _dev()
+    g = torch.Generator(device=dev).manual_seed(M + N + K)
+    A = torch.randn(M, K, device=dev, generator=g).to(_h16())
+    W = (torch.randn(N, K, device=dev, generator=g) * 0.05).to(_h16())
+    bias = torch.randn(N, device=dev, generator=g)
+    R = torch.randn(M, N, device=dev, generator=g)
+    Uin = torch.randn(M, N, device=dev, generator=g).to(_h16())
+
+    def run(cdt, epi, aux, b):
+        C = torch.full((M, N), float("nan"), device=dev, dtype=_h16() if cdt else torch.float32)
+        U = torch.full((M, N), float("nan"), device=dev, dtype=_h16()) if epi == 1 else None
+        _lib.call("climb_gemm_bf16_nt", A, K, W, K, C, N, cdt, M, N, K, b, epi, aux, N, U, N, None, 0, _st())
+        return [C] + ([U] if U is not None else [])
+    try:
+        rows = torch.arange(0, M, 61, device=dev)
+        r64 = A[rows].double() @ W.double().t() + bias.double()
+        for name, cdt, epi, aux, b in [("f32", 0, 0, None, bias), ("h16", 1, 0, None, bias), ("h16 no bias", 1, 0, None, None), ("gelu", 1, 1, None, bias),
+                                       ("resid", 0, 2, R, bias), ("dgelu", 1, 3, Uin, None)]:
+            _lib.call("climb_set_option", 17, 0)
+            ref = run(cdt, epi, aux, b)
+            if name == "f32":
+                assert _rel(ref[0][rows], r64) < 1e-5
+            _lib.call("climb_set_option", 17, 1)
+            for it in range(4):
+                got = run(cdt, epi, aux, b)
+                for r_, g_ in zip(ref, got):
+                    assert not bool(torch.isnan(g_.float()).any()), f"{name}, iteration {it}: elements never stored"
+                    bad = int((g_ != r_).sum())
+                    assert bad == 0, f"{name}, iteration {it}: {bad} elements differ from the 8-wave kernel"
+    finally:
+        _lib.call("climb_set_option", 17, 1)
+
+
+def test_gemm_bf16_nt4_declines_what_it_does_not_take():
+    """Shapes outside its contract (ragged tiles, fewer than 10 k-tiles, an M-tile count the 8 XCDs do not share evenly) fall through to the 8-wave kernels:
+    same call, right answer."""
+    from climb_amd import _lib
+    dev = _dev()
+    for M, N, K in [(1536, 192, 576), (1344, 192, 768), (1536, 200, 768), (200, 192, 768)]:
+        g = torch.Generator().manual_seed(M + N + K)
+        A, W = _bf(torch.randn(M, K, generator=g)), _bf(torch.randn(N, K, generator=g) * 0.05)
+        ref = A.double() @ W.double().t()
+        C = torch.empty(M, N, device=dev)
+        _lib.call("climb_gemm_bf16_nt", A.to(dev), K, W.to(dev), K, C, N, 0, M, N, K, None, 0, None, 0, None, 0, None, 0, _st())
+        assert _rel(C, ref) < 1e-5
+
+
 @pytest.mark.parametrize("K", [1536, 2304, 3072])
 @pytest.mark.parametrize("epi", ["none_16bit", "resid_fp32"])
 def test_gemm_bf16_nt_split_along_k_balancing(K, epi):
