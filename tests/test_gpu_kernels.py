@@ -561,6 +561,7 @@ def test_gemm_bf16_nt_split_along_k_balancing(K, epi):
         _lib.call("climb_gemm_bf16_nt", Ad, K, Wd, K, out, N, cdt, M, N, K, bias, e, resid, N, None, 0, None, 0, _st())
     nt_workspace(dev)
     try:
+        _lib.call("climb_set_option", 17, 0)          # (r04: this is an experiment on the 8-wave kernel -- keep the four-wave kernel out)
         _lib.call("climb_set_option", 14, 0)
         ref = mk()
         run(ref)
@@ -579,6 +580,7 @@ def test_gemm_bf16_nt_split_along_k_balancing(K, epi):
             run(out)
             assert torch.equal(out, first), f"iteration {it}: {int((out != first).sum())} elements differ from the first run"
     finally:
+        _lib.call("climb_set_option", 17, 1)
         _lib.call("climb_set_option", 14, 0)          # the library's default: measured slower than one workgroup per tile (see gemm_bf16_ntp.hip)
 
 
@@ -600,6 +602,7 @@ def test_gemm_bf16_nt_dephased_start_is_the_same_arithmetic(value):
         torch.cuda.synchronize()
         return out, pre
     try:
+        _lib.call("climb_set_option", 17, 0)          # (r04: the knob belongs to the 8-wave kernel)
         ref = run()
         _lib.call("climb_set_option", 16, value)
         for _ in range(3):
@@ -607,6 +610,7 @@ def test_gemm_bf16_nt_dephased_start_is_the_same_arithmetic(value):
             assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
     finally:
         _lib.call("climb_set_option", 16, 0)
+        _lib.call("climb_set_option", 17, 1)
 
 
 @pytest.mark.parametrize("M,N,K", [(64, 128, 128), (384, 768, 768), (1000, 2304, 768), (300, 768, 3072), (130, 48, 768)])
