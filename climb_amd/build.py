@@ -16,8 +16,23 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc"]
 
 
+# per-source flags; and sources compiled a second time under another object name (A/B builds of one kernel inside one library)
+SRC_FLAGS = {}
+TWICE = {"gemm_bf16_nt4.hip": ("gemm_bf16_nt4_slp", ["-DNT4_SLP_BUILD", "-fno-slp-vectorize"])}      # (17 = 2: epilogue arithmetic NOT packed, measured equal or slower)
+
+
 def sources():
     return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def units():
+    """(source, object stem, extra flags)"""
+    out = []
+    for s in sources():
+        out.append((s, s[:-4], SRC_FLAGS.get(s, [])))
+        if s in TWICE:
+            out.append((s, TWICE[s][0], TWICE[s][1]))
+    return out
 
 
 def _stale(target, deps):
@@ -36,15 +51,15 @@ def _build(LIB: str, objdir: str, extra, force: bool, verbose: bool) -> str:
     hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     os.makedirs(objdir, exist_ok=True)
     jobs = []
-    for s in sources():
+    for s, stem, fl in units():
         src = os.path.join(CSRC, s)
-        obj = os.path.join(objdir, s[:-4] + ".o")
+        obj = os.path.join(objdir, stem + ".o")
         if force or _stale(obj, [src] + hdrs):
-            jobs.append((src, obj))
+            jobs.append((src, obj, fl))
 
     def cc(job):
-        src, obj = job
-        cmd = [HIPCC] + FLAGS + extra + ["-c", src, "-o", obj]
+        src, obj, fl = job
+        cmd = [HIPCC] + FLAGS + extra + fl + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)
@@ -54,7 +69,7 @@ def _build(LIB: str, objdir: str, extra, force: bool, verbose: bool) -> str:
 
     with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
         list(ex.map(cc, jobs))
-    objs = [os.path.join(objdir, s[:-4] + ".o") for s in sources()]
+    objs = [os.path.join(objdir, stem + ".o") for _, stem, _ in units()]
     if force or jobs or _stale(LIB, objs):
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
         if verbose:

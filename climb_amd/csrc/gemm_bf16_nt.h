@@ -233,3 +233,4 @@ int climb_nt4_launch(const bf16_t* A, long lda, const bf16_t* B, long ldb, void*
                      const void* aux, long ldaux, bf16_t* aux_out, long ldauxo, hipStream_t st);
 void climb_nt4_set(int v);        // climb_set_option 17
 void climb_nt4_set_grid(int v);   // follows climb_set_option 9
+void climb_nt4_set_probe(int v);  // climb_set_option 18 (measurement only)

@@ -29,6 +29,12 @@
 //
 // Takes: M % 192 == 0, N % 192 == 0, (M / 192) % 8 == 0, K % 64 == 0, K >= 640, epilogues NONE / GELU / RESID / DGELU.
 #include "gemm_bf16_nt.h"
+// A/B aid (r04): the file is compiled twice -- as is (the product: hipcc packs the GELU polynomials of two elements into v_pk_fma_f32), and with
+// -DNT4_SLP_BUILD -fno-slp-vectorize under other names for climb_set_option(17, 2) (measured: equal or 2 - 5 % slower on the GELU kinds)
+#ifdef NT4_SLP_BUILD
+#define gemm_bf16_nt4_kernel gemm_bf16_nt4slp_kernel
+#define climb_nt4_launch climb_nt4slp_launch
+#endif
 
 #define NT4_T 192
 #define NT4_OP (NT4_T * 128)             // one operand image of a k-tile: 24 KB
@@ -56,7 +62,8 @@ struct Nt4Uni {             // wave-uniform state
   unsigned pa[6], pb[6];         // byte offset of this wave's DMA piece j inside the tile's A / B rows
   unsigned lda2, ldb2;           // bytes per operand row
   unsigned ldc_b, ldx_b, ldo_b;  // bytes per row of C / aux / aux_out
-  unsigned wid;
+  unsigned wid, stag;
+  int probe;
   // DMA stream
   Nt4Walk dw;
   int dkt, dleft, nk;
@@ -88,6 +95,8 @@ template <> __device__ __forceinline__ void nt4_aux_load<EPI_RESID>(Nt4Aux<EPI_R
 template <> __device__ __forceinline__ void nt4_aux_load<EPI_DGELU>(Nt4Aux<EPI_DGELU>& a, int p, const Nt4Uni& u, const Nt4Lane& l, unsigned soff) {
   nt4_ld64(a.v[p], u.rx, l.vx, soff);
 }
+template <int EPI> __device__ __forceinline__ u32x2 nt4_auxw(const Nt4Aux<EPI>&, int) { return (u32x2){0u, 0u}; }
+template <> __device__ __forceinline__ u32x2 nt4_auxw<EPI_DGELU>(const Nt4Aux<EPI_DGELU>& a, int p) { return a.v[p]; }
 // pins the registers of asm loads behind a wait (the compiler must not touch them between load and wait)
 template <int EPI> __device__ __forceinline__ void nt4_pin(Nt4Aux<EPI>&) {}
 template <> __device__ __forceinline__ void nt4_pin<EPI_RESID>(Nt4Aux<EPI_RESID>& a) { asm volatile("" : "+v"(a.v[0]), "+v"(a.v[1]), "+v"(a.v[2]), "+v"(a.v[3])::"memory"); }
@@ -133,10 +142,58 @@ __device__ __forceinline__ void nt4_stage_write(const f32x16& acc, const Nt4Lane
   f32x4 v = {acc[4 * G], acc[4 * G + 1], acc[4 * G + 2], acc[4 * G + 3]};
   asm volatile("ds_write_b128 %0, %1" ::"v"(l.wr0 ^ (unsigned)(G << 5)), "v"(v) : "memory");
 }
-// one row-major float4 (readback p of block (bi, bj) of the finished tile): bias, epilogue, store(s).  SUB: -1 = everything at once; the GELU
-// kinds spread their arithmetic over MFMA slots: 0 = bias (+ the pre-activation store), 1..4 = element SUB - 1, the last one also stores
+// The GELU kinds inside the k-loop.  gelu_fast / dgelu_fast (common.h) are Horner chains of 8 dependent FMAs per element: one element per MFMA
+// slot issues at the chain's latency (measured: the windows that carry them took 3 x the MFMA time).  Instead ONE stage of the chain runs per slot
+// for EIGHT elements (two readback pieces), so the eight chains interleave.  The arithmetic per element is exactly that of common.h (same
+// operations in the same order: bit-identical results).
+struct Nt4Act { float xc[8], t[8], q[8], u[8]; };
+template <int EPI, int STAGE>
+__device__ __forceinline__ void nt4_act_stage(Nt4Act& a, f32x4& v0, f32x4& v1, const u32x2& w0, const u32x2& w1) {
+  constexpr bool G = EPI == EPI_GELU;
+  constexpr float C = G ? 3.75f : 4.0f, S = G ? (1.0f / 14.0625f) : (1.0f / 16.0f);
+  constexpr float K0 = G ? -2.990306294e-01f : -5.764975740e+00f, K1 = G ? 1.411524049e+00f : 2.542120392e+01f, K2 = G ? -2.948430485e+00f : -4.785218948e+01f,
+                  K3 = G ? 3.672470736e+00f : 5.075452353e+01f, K4 = G ? -3.120830459e+00f : -3.378359828e+01f, K5 = G ? 1.952923920e+00f : 1.478723046e+01f,
+                  K6 = G ? -9.342629426e-01f : -4.235025071e+00f, K7 = G ? 3.989392092e-01f : 7.978034103e-01f;
+  if constexpr (STAGE == 0) {
+    if constexpr (G) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { a.u[k] = v0[k]; a.u[4 + k] = v1[k]; }
+    } else {
+      a.u[0] = h16lo_to_f32(w0[0]); a.u[1] = h16hi_to_f32(w0[0]); a.u[2] = h16lo_to_f32(w0[1]); a.u[3] = h16hi_to_f32(w0[1]);
+      a.u[4] = h16lo_to_f32(w1[0]); a.u[5] = h16hi_to_f32(w1[0]); a.u[6] = h16lo_to_f32(w1[1]); a.u[7] = h16hi_to_f32(w1[1]);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a.xc[k] = fminf(fmaxf(a.u[k], -C), C);
+  }
+  if constexpr (STAGE == 1) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a.t[k] = (a.xc[k] * a.xc[k]) * S;
+  }
+#define NT4_H(ST, KK, FIRST)                                                     \
+  if constexpr (STAGE == ST) {                                                   \
+    _Pragma("unroll") for (int k = 0; k < 8; ++k) a.q[k] = fmaf(FIRST ? K0 : a.q[k], a.t[k], KK); \
+  }
+  NT4_H(2, K1, true) NT4_H(3, K2, false) NT4_H(4, K3, false) NT4_H(5, K4, false) NT4_H(6, K5, false) NT4_H(7, K6, false) NT4_H(8, K7, false)
+#undef NT4_H
+  if constexpr (STAGE == 9) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a.q[k] = fmaf(a.xc[k], a.q[k], 0.5f);
+  }
+  if constexpr (STAGE == 10) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float r = a.u[k] < -C ? 0.f : a.q[k];
+      if (k < 4) v0[k] = v0[k] * r; else v1[k - 4] = v1[k - 4] * r;
+    }
+  }
+}
+
+// one row-major float4 (readback p of block (bi, bj) of the finished tile): bias, epilogue, store(s).  SUB: -1 = everything at once.  Inside the
+// k-loop the GELU kinds spread their arithmetic over MFMA slots and HOLD the packed result for the next window (stores issued late in a window are
+// still unacknowledged at its end, and the window's counted wait then waits for them -- measured with cold operands: +27 us on the up-projection):
+// 0 = bias (+ the pre-activation store), 1..4 = element SUB - 1 (4 also packs into `hold`), 5 = store `hold`
 template <typename TO, int EPI, int SUB>
-__device__ __forceinline__ void nt4_unit(f32x4& v, const f32x4& bias, const Nt4Aux<EPI>& ax, int p, int bi, int bj, const Nt4Uni& u, const Nt4Lane& l) {
+__device__ __forceinline__ void nt4_unit(f32x4& v, u32x2& hold, const f32x4& bias, const Nt4Aux<EPI>& ax, int p, int bi, int bj, const Nt4Uni& u, const Nt4Lane& l) {
   const unsigned rowoff = (unsigned)(bi * 32 + 8 * p);
   const unsigned csoff = u.cbase + rowoff * u.ldc_b + (unsigned)(bj * 32 * (int)sizeof(TO));
   if constexpr (EPI == EPI_NONE) {
@@ -146,29 +203,33 @@ __device__ __forceinline__ void nt4_unit(f32x4& v, const f32x4& bias, const Nt4A
     v += bias;
     v += ax.v[p];
     nt4_store<TO>(v, u.rc, l.vc, csoff);
-  } else if constexpr (EPI == EPI_GELU) {
+  } else {
+    static_assert(EPI == EPI_GELU || EPI == EPI_DGELU, "epilogue");
+    static_assert(sizeof(TO) == 2, "the GELU kinds have 16-bit outputs");
     if constexpr (SUB <= 0) {
       v += bias;
-      nt4_store<bf16_t>(v, u.ro, l.vo2, u.obase + rowoff * u.ldo_b + (unsigned)(bj * 64));
+      if constexpr (EPI == EPI_GELU) nt4_store<bf16_t>(v, u.ro, l.vo2, u.obase + rowoff * u.ldo_b + (unsigned)(bj * 64));
     }
     if constexpr (SUB < 0) {
+      if constexpr (EPI == EPI_GELU) {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) v[k] = gelu_fast(v[k]);
+        for (int k = 0; k < 4; ++k) v[k] = gelu_fast(v[k]);
+      } else {
+        const u32x2 w = ax.v[p];
+        v[0] *= dgelu_fast(h16lo_to_f32(w[0])); v[1] *= dgelu_fast(h16hi_to_f32(w[0]));
+        v[2] *= dgelu_fast(h16lo_to_f32(w[1])); v[3] *= dgelu_fast(h16hi_to_f32(w[1]));
+      }
+      nt4_store<TO>(v, u.rc, l.vc, csoff);
     }
-    if constexpr (SUB >= 1) v[SUB - 1] = gelu_fast(v[SUB - 1]);
-    if constexpr (SUB < 0 || SUB == 4) nt4_store<TO>(v, u.rc, l.vc, csoff);
-  } else if constexpr (EPI == EPI_DGELU) {
-    if constexpr (SUB <= 0) v += bias;
-    if constexpr (SUB < 0) {
-      const u32x2 w = ax.v[p];
-      v[0] *= dgelu_fast(h16lo_to_f32(w[0])); v[1] *= dgelu_fast(h16hi_to_f32(w[0]));
-      v[2] *= dgelu_fast(h16lo_to_f32(w[1])); v[3] *= dgelu_fast(h16hi_to_f32(w[1]));
+    if constexpr (SUB >= 1 && SUB <= 4) {
+      if constexpr (EPI == EPI_GELU) v[SUB - 1] = gelu_fast(v[SUB - 1]);
+      else {
+        const unsigned w = ax.v[p][(SUB - 1) >> 1];
+        v[SUB - 1] *= dgelu_fast(((SUB - 1) & 1) ? h16hi_to_f32(w) : h16lo_to_f32(w));
+      }
+      if constexpr (SUB == 4) hold = (u32x2){pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)};
     }
-    if constexpr (SUB >= 1) {
-      const unsigned w = ax.v[p][(SUB - 1) >> 1];
-      v[SUB - 1] *= dgelu_fast(((SUB - 1) & 1) ? h16hi_to_f32(w) : h16lo_to_f32(w));
-    }
-    if constexpr (SUB < 0 || SUB == 4) nt4_store<TO>(v, u.rc, l.vc, csoff);
+    if constexpr (SUB == 5) __builtin_amdgcn_raw_buffer_store_b64(hold, u.rc, l.vc, csoff, 0);
   }
 }
 // operand loads of block B of the finished tile, piece p
@@ -193,12 +254,15 @@ __device__ __forceinline__ void nt4_set_prev(Nt4Uni& u, int m0, int n0) {
 // CFG: SW   switch window (k-step 3 finishes a tile INTO accP, k-step 0 starts the next one from zero)
 //      EB   block of the finished tile drained in this window (-1: none);  AB: block whose operands are fetched (-1: none);  BL: bias loads
 //      DMA  the 12 pieces of k-tile T + 3;  RD: fragment reads (off in the workgroup's very last k-step)
-template <bool SW_, int EB_, int AB_, bool BL_, bool DMA_, bool RD_> struct Nt4Cfg {
-  static constexpr bool SW = SW_, BL = BL_, DMA = DMA_, RD = RD_;
-  static constexpr int EB = EB_, AB = AB_;
+//      SB   (GELU kinds) block whose results, held in packed form since the previous window, are stored in the first slots of this one
+//      PR   measurement builds (climb_set_option 18, 16-bit NONE kernel only; results are WRONG with bits 1 / 2): 1 = no DMA inside the windows,
+//           2 = no epilogue inside the windows, 4 = the 12 DMA pieces in slots 4 .. 15 (issued as early as the stage is free)
+template <int PR_, bool SW_, int EB_, int AB_, bool BL_, bool DMA_, bool RD_, int SB_ = -1> struct Nt4Cfg {
+  static constexpr bool SW = SW_, BL = BL_ && !(PR_ & 2), DMA = DMA_ && !(PR_ & 1), RD = RD_, STAG = (PR_ & 4) != 0;
+  static constexpr int EB = (PR_ & 2) ? -1 : EB_, AB = (PR_ & 2) ? -1 : AB_, SB = (PR_ & 2) ? -1 : SB_;
 };
 template <typename TO, int EPI, class CFG, int Q>
-__device__ __forceinline__ void nt4_slot(f32x16 (&accC)[3][3], f32x16 (&accP)[3][3], bf16x8 (&fa)[2][3], bf16x8 (&fb)[2][3], f32x4 (&rbk)[4],
+__device__ __forceinline__ void nt4_slot(f32x16 (&accC)[3][3], f32x16 (&accP)[3][3], bf16x8 (&fa)[2][3], bf16x8 (&fb)[2][3], f32x4 (&rbk)[4], u32x2 (&hold)[4], Nt4Act& act,
                                          f32x4 (&bias)[3], Nt4Aux<EPI> (&aux)[2], const Nt4Uni& u, const Nt4Lane& l, unsigned char* smem) {
   constexpr int st = Q / 9, blk = Q % 9, bi = blk / 3, bj = blk % 3;
   constexpr int par = (st == 0) ? 1 : ((st - 1) & 1);
@@ -223,7 +287,8 @@ __device__ __forceinline__ void nt4_slot(f32x16 (&accC)[3][3], f32x16 (&accP)[3]
   // operand loads of the block drained in the NEXT window (older than every DMA piece of this window: slots 0..3, first piece in slot 4)
   if constexpr (Q < 4 && CFG::AB >= 0) nt4_aux_issue<EPI>(aux[CFG::AB & 1], Q, CFG::AB / 3, CFG::AB % 3, u, l);
   if constexpr (Q < 3 && CFG::BL) nt4_bias_issue(bias, Q, u, l);
-  if constexpr (CFG::DMA && nt4_dma_piece(Q) >= 0) nt4_dma<(nt4_dma_piece(Q) < 0 ? 0 : nt4_dma_piece(Q))>(u, l, smem);
+  if constexpr (CFG::DMA && !CFG::STAG && nt4_dma_piece(Q) >= 0) nt4_dma<(nt4_dma_piece(Q) < 0 ? 0 : nt4_dma_piece(Q))>(u, l, smem);
+  if constexpr (CFG::DMA && CFG::STAG && Q >= 4 && Q < 16) nt4_dma<(Q >= 4 && Q < 16 ? Q - 4 : 0)>(u, l, smem);      // every piece early in the window
   if constexpr (CFG::EB >= 0) {
     constexpr int ei = CFG::EB / 3, ej = CFG::EB % 3;
     // turn: 4 writes, then 4 row-major reads (LDS operations of one wave execute in order: no wait in between)
@@ -232,27 +297,31 @@ __device__ __forceinline__ void nt4_slot(f32x16 (&accC)[3][3], f32x16 (&accP)[3]
     if constexpr (Q == 3) nt4_stage_write<2>(accP[ei][ej], l);
     if constexpr (Q == 5) nt4_stage_write<3>(accP[ei][ej], l);
     if constexpr (EPI == EPI_GELU || EPI == EPI_DGELU) {
-      // unit p = slots 7 + 6 p .. 13 + 6 p: readback, (one slot for the LDS latency), bias (+ pre-activation store), one element per slot, store
-      constexpr int p = Q >= 7 && Q < 31 ? (Q - 7) / 6 : -1, o = Q >= 7 && Q < 31 ? (Q - 7) % 6 : -1;
-      if constexpr (p >= 0 && o == 0) rbk[p] = *reinterpret_cast<const f32x4*>(smem + NT4_TURN + u.wid * 4096 + l.rd + p * 1024);
-      if constexpr (p >= 0 && o >= 2) nt4_unit<TO, EPI, o - 2>(rbk[p], bias[ej], aux[CFG::EB & 1], p, ei, ej, u, l);
-      // the last element + store of unit p share the slot of unit p + 1's readback (31 for the fourth)
-      if constexpr (Q == 13 || Q == 19 || Q == 25 || Q == 31) nt4_unit<TO, EPI, 4>(rbk[(Q - 13) / 6], bias[ej], aux[CFG::EB & 1], (Q - 13) / 6, ei, ej, u, l);
+      // readback p in slot 5 + p; bias (+ pre-activation store) of piece p in slot 8 + p; pieces 0, 1: one stage of the activation per slot in
+      // 12 .. 22, packed into `hold` in 23; pieces 2, 3: 24 .. 34, packed in 35.  NO result store in this window: held for the next one's first slots
+      if constexpr (Q >= 5 && Q < 9) rbk[Q - 5] = *reinterpret_cast<const f32x4*>(smem + NT4_TURN + u.wid * 4096 + l.rd + (Q - 5) * 1024);
+      if constexpr (Q >= 8 && Q < 12) nt4_unit<TO, EPI, 0>(rbk[Q - 8], hold[Q - 8], bias[ej], aux[CFG::EB & 1], Q - 8, ei, ej, u, l);
+      if constexpr (Q >= 12 && Q < 23) nt4_act_stage<EPI, Q - 12>(act, rbk[0], rbk[1], nt4_auxw<EPI>(aux[CFG::EB & 1], 0), nt4_auxw<EPI>(aux[CFG::EB & 1], 1));
+      if constexpr (Q >= 24 && Q < 35) nt4_act_stage<EPI, Q - 24>(act, rbk[2], rbk[3], nt4_auxw<EPI>(aux[CFG::EB & 1], 2), nt4_auxw<EPI>(aux[CFG::EB & 1], 3));
+      if constexpr (Q == 23) { hold[0] = (u32x2){pack_bf16x2(rbk[0].x, rbk[0].y), pack_bf16x2(rbk[0].z, rbk[0].w)}; hold[1] = (u32x2){pack_bf16x2(rbk[1].x, rbk[1].y), pack_bf16x2(rbk[1].z, rbk[1].w)}; }
+      if constexpr (Q == 35) { hold[2] = (u32x2){pack_bf16x2(rbk[2].x, rbk[2].y), pack_bf16x2(rbk[2].z, rbk[2].w)}; hold[3] = (u32x2){pack_bf16x2(rbk[3].x, rbk[3].y), pack_bf16x2(rbk[3].z, rbk[3].w)}; }
     } else {
-      constexpr int p = Q == 12 ? 0 : Q == 18 ? 1 : Q == 24 ? 2 : Q == 30 ? 3 : -1;
-      constexpr int rp = Q == 9 ? 0 : Q == 15 ? 1 : Q == 21 ? 2 : Q == 27 ? 3 : -1;
+      // every store in the first half of the window: readback p in slot 6 + 2 p, bias / residual / store in slot 9 + 2 p
+      constexpr int rp = Q == 6 ? 0 : Q == 8 ? 1 : Q == 10 ? 2 : Q == 12 ? 3 : -1;
+      constexpr int p = Q == 9 ? 0 : Q == 11 ? 1 : Q == 13 ? 2 : Q == 15 ? 3 : -1;
       if constexpr (rp >= 0) rbk[rp] = *reinterpret_cast<const f32x4*>(smem + NT4_TURN + u.wid * 4096 + l.rd + rp * 1024);
-      if constexpr (p >= 0) nt4_unit<TO, EPI, -1>(rbk[p], bias[ej], aux[CFG::EB & 1], p, ei, ej, u, l);
+      if constexpr (p >= 0) nt4_unit<TO, EPI, -1>(rbk[p], hold[p], bias[ej], aux[CFG::EB & 1], p, ei, ej, u, l);
     }
   }
+  if constexpr (CFG::SB >= 0 && Q < 4) nt4_unit<TO, EPI, 5>(rbk[Q], hold[Q], bias[0], aux[0], Q, CFG::SB / 3, CFG::SB % 3, u, l);
   __builtin_amdgcn_sched_barrier(0);
 }
 template <typename TO, int EPI, class CFG, int Q, int QE>
-__device__ __forceinline__ void nt4_slots(f32x16 (&accC)[3][3], f32x16 (&accP)[3][3], bf16x8 (&fa)[2][3], bf16x8 (&fb)[2][3], f32x4 (&rbk)[4],
+__device__ __forceinline__ void nt4_slots(f32x16 (&accC)[3][3], f32x16 (&accP)[3][3], bf16x8 (&fa)[2][3], bf16x8 (&fb)[2][3], f32x4 (&rbk)[4], u32x2 (&hold)[4], Nt4Act& act,
                                           f32x4 (&bias)[3], Nt4Aux<EPI> (&aux)[2], const Nt4Uni& u, const Nt4Lane& l, unsigned char* smem) {
   if constexpr (Q < QE) {
-    nt4_slot<TO, EPI, CFG, Q>(accC, accP, fa, fb, rbk, bias, aux, u, l, smem);
-    nt4_slots<TO, EPI, CFG, Q + 1, QE>(accC, accP, fa, fb, rbk, bias, aux, u, l, smem);
+    nt4_slot<TO, EPI, CFG, Q>(accC, accP, fa, fb, rbk, hold, act, bias, aux, u, l, smem);
+    nt4_slots<TO, EPI, CFG, Q + 1, QE>(accC, accP, fa, fb, rbk, hold, act, bias, aux, u, l, smem);
   }
 }
 // end of a window: this wave has read the stage of k-tile T + 1 for the last time and its share of k-tile T + 2 has landed (only the VM youngest
@@ -266,7 +335,9 @@ template <int VM, int EPI>
 __device__ __forceinline__ void nt4_window_end(Nt4Uni& u, Nt4Aux<EPI> (&aux)[2], f32x4 (&bias)[3]) {
   __builtin_amdgcn_sched_barrier(0);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM) : "memory");
+  if (VM == 0 || u.probe == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM) : "memory");
+  else if (u.probe == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM + 4) : "memory");        // MEASUREMENT ONLY (climb_set_option 18): results may be wrong
+  else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM + 8) : "memory");
   nt4_pin<EPI>(aux[0]);
   nt4_pin<EPI>(aux[1]);
   asm volatile("" : "+v"(bias[0]), "+v"(bias[1]), "+v"(bias[2])::"memory");
@@ -276,15 +347,15 @@ __device__ __forceinline__ void nt4_window_end(Nt4Uni& u, Nt4Aux<EPI> (&aux)[2],
   nt4_set_rd(u, u.rd_off + NT4_STAGE == 3 * NT4_STAGE ? 0u : u.rd_off + NT4_STAGE);
 }
 template <typename TO, int EPI, class CFG>
-__device__ __forceinline__ void nt4_window(f32x16 (&accC)[3][3], f32x16 (&accP)[3][3], bf16x8 (&fa)[2][3], bf16x8 (&fb)[2][3], f32x4 (&rbk)[4],
+__device__ __forceinline__ void nt4_window(f32x16 (&accC)[3][3], f32x16 (&accP)[3][3], bf16x8 (&fa)[2][3], bf16x8 (&fb)[2][3], f32x4 (&rbk)[4], u32x2 (&hold)[4], Nt4Act& act,
                                            f32x4 (&bias)[3], Nt4Aux<EPI> (&aux)[2], Nt4Uni& u, const Nt4Lane& l, unsigned char* smem) {
   nt4_dma_advance(u);
-  nt4_slots<TO, EPI, CFG, 0, 36>(accC, accP, fa, fb, rbk, bias, aux, u, l, smem);
+  nt4_slots<TO, EPI, CFG, 0, 36>(accC, accP, fa, fb, rbk, hold, act, bias, aux, u, l, smem);
   nt4_window_end<12, EPI>(u, aux, bias);
 }
 
 template <typename TO, int EPI, int E0, int E1>
-__device__ __forceinline__ void nt4_final(f32x16 (&accP)[3][3], f32x4 (&rbk)[4], f32x4 (&bias)[3], const Nt4Uni& u, const Nt4Lane& l, unsigned char* smem) {
+__device__ __forceinline__ void nt4_final(f32x16 (&accP)[3][3], f32x4 (&rbk)[4], u32x2 (&hold)[4], f32x4 (&bias)[3], const Nt4Uni& u, const Nt4Lane& l, unsigned char* smem) {
   Nt4Aux<EPI> ax[E1 - E0];
 #pragma unroll
   for (int e = E0; e < E1; ++e)
@@ -301,13 +372,13 @@ __device__ __forceinline__ void nt4_final(f32x16 (&accP)[3][3], f32x4 (&rbk)[4],
 #pragma unroll
     for (int p = 0; p < 4; ++p) rbk[p] = *reinterpret_cast<const f32x4*>(smem + NT4_TURN + u.wid * 4096 + l.rd + p * 1024);
 #pragma unroll
-    for (int p = 0; p < 4; ++p) nt4_unit<TO, EPI, -1>(rbk[p], bias[e % 3], ax[e - E0], p, e / 3, e % 3, u, l);
+    for (int p = 0; p < 4; ++p) nt4_unit<TO, EPI, -1>(rbk[p], hold[p], bias[e % 3], ax[e - E0], p, e / 3, e % 3, u, l);
   }
 }
 
-template <typename TO, int EPI>
+template <typename TO, int EPI, int PROBE = 0>
 __global__ __launch_bounds__(256) void gemm_bf16_nt4_kernel(const bf16_t* A, long lda, const bf16_t* B, long ldb, TO* C, long ldc, int M, int N, int K, const float* bias_g,
-                                                            const void* aux_g, long ldaux, bf16_t* aux_out, long ldauxo) {
+                                                            const void* aux_g, long ldaux, bf16_t* aux_out, long ldauxo, int probe) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63;
   Nt4Uni u;
@@ -317,6 +388,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt4_kernel(const bf16_t* A, lon
   const int nbm = M / NT4_T, nbn = N / NT4_T, nwg = nbm * nbn, G = gridDim.x;
   const int ntw = (nwg - (int)blockIdx.x + G - 1) / G;          // tiles of this workgroup (>= 1)
   u.nk = K / GB_BK;
+  u.probe = probe;
+  u.stag = u.wid % 3u;
   // resources: raw buffers (stride 0), range = 2 GB (the launcher checks sizes); a missing bias reads as zeros through an empty range
   u.ra = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, 0x7fffffff, 0x00020000);
   u.rb = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, 0x7fffffff, 0x00020000);
@@ -366,6 +439,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt4_kernel(const bf16_t* A, lon
   f32x16 accC[3][3], accP[3][3];
   bf16x8 fa[2][3], fb[2][3];
   f32x4 rbk[4], bias[3];
+  u32x2 hold[4];
+  Nt4Act act;
   Nt4Aux<EPI> aux[2];
 #pragma unroll
   for (int j = 0; j < 3; ++j) bias[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -388,32 +463,37 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt4_kernel(const bf16_t* A, lon
   fa[0][1] = ntp_frag_(smem + (u.rda + l.fo[0]) + 4096);
   fa[0][2] = ntp_frag_(smem + (u.rda + l.fo[0]) + 8192);
   // the second half of a switch window: k-steps 0 - 2 of the first tile's k-tile 0 (no DMA: k-tile 2 is already on its way)
-  nt4_slots<TO, EPI, Nt4Cfg<true, -1, -1, false, false, true>, 9, 36>(accC, accP, fa, fb, rbk, bias, aux, u, l, smem);
+  nt4_slots<TO, EPI, Nt4Cfg<PROBE, true, -1, -1, false, false, true>, 9, 36>(accC, accP, fa, fb, rbk, hold, act, bias, aux, u, l, smem);
   nt4_window_end<0, EPI>(u, aux, bias);           // k-tiles 1 and 2 have landed
   u.dma_off = 0;                                  // the stage k-tile 0 leaves at the end of the next window's k-step 3 ... which IS where piece 0 is issued (slot 4 of k-step 3: after this barrier every wave holds its k-step-3 fragments)
   const int nk = u.nk;
+  constexpr bool HOLD = EPI == EPI_GELU || EPI == EPI_DGELU;      // results held one window (see nt4_unit)
   for (int t = 0;; ++t) {
     int w0 = 0;
     if (t > 0) {
-      nt4_window<TO, EPI, Nt4Cfg<false, 0, 1, false, true, true>>(accC, accP, fa, fb, rbk, bias, aux, u, l, smem);
-      nt4_window<TO, EPI, Nt4Cfg<false, 1, 2, false, true, true>>(accC, accP, fa, fb, rbk, bias, aux, u, l, smem);
-      nt4_window<TO, EPI, Nt4Cfg<false, 2, 3, false, true, true>>(accC, accP, fa, fb, rbk, bias, aux, u, l, smem);
-      nt4_window<TO, EPI, Nt4Cfg<false, 3, 4, false, true, true>>(accC, accP, fa, fb, rbk, bias, aux, u, l, smem);
-      nt4_window<TO, EPI, Nt4Cfg<false, 4, 5, false, true, true>>(accC, accP, fa, fb, rbk, bias, aux, u, l, smem);
-      nt4_window<TO, EPI, Nt4Cfg<false, 5, 6, false, true, true>>(accC, accP, fa, fb, rbk, bias, aux, u, l, smem);
-      nt4_window<TO, EPI, Nt4Cfg<false, 6, 7, false, true, true>>(accC, accP, fa, fb, rbk, bias, aux, u, l, smem);
-      nt4_window<TO, EPI, Nt4Cfg<false, 7, 8, false, true, true>>(accC, accP, fa, fb, rbk, bias, aux, u, l, smem);
-      nt4_window<TO, EPI, Nt4Cfg<false, 8, -1, false, true, true>>(accC, accP, fa, fb, rbk, bias, aux, u, l, smem);
+      nt4_window<TO, EPI, Nt4Cfg<PROBE, false, 0, 1, false, true, true>>(accC, accP, fa, fb, rbk, hold, act, bias, aux, u, l, smem);
+      nt4_window<TO, EPI, Nt4Cfg<PROBE, false, 1, 2, false, true, true, HOLD ? 0 : -1>>(accC, accP, fa, fb, rbk, hold, act, bias, aux, u, l, smem);
+      nt4_window<TO, EPI, Nt4Cfg<PROBE, false, 2, 3, false, true, true, HOLD ? 1 : -1>>(accC, accP, fa, fb, rbk, hold, act, bias, aux, u, l, smem);
+      nt4_window<TO, EPI, Nt4Cfg<PROBE, false, 3, 4, false, true, true, HOLD ? 2 : -1>>(accC, accP, fa, fb, rbk, hold, act, bias, aux, u, l, smem);
+      nt4_window<TO, EPI, Nt4Cfg<PROBE, false, 4, 5, false, true, true, HOLD ? 3 : -1>>(accC, accP, fa, fb, rbk, hold, act, bias, aux, u, l, smem);
+      nt4_window<TO, EPI, Nt4Cfg<PROBE, false, 5, 6, false, true, true, HOLD ? 4 : -1>>(accC, accP, fa, fb, rbk, hold, act, bias, aux, u, l, smem);
+      nt4_window<TO, EPI, Nt4Cfg<PROBE, false, 6, 7, false, true, true, HOLD ? 5 : -1>>(accC, accP, fa, fb, rbk, hold, act, bias, aux, u, l, smem);
+      nt4_window<TO, EPI, Nt4Cfg<PROBE, false, 7, 8, false, true, true, HOLD ? 6 : -1>>(accC, accP, fa, fb, rbk, hold, act, bias, aux, u, l, smem);
+      nt4_window<TO, EPI, Nt4Cfg<PROBE, false, 8, -1, false, true, true, HOLD ? 7 : -1>>(accC, accP, fa, fb, rbk, hold, act, bias, aux, u, l, smem);
       w0 = 9;
+      if constexpr (HOLD) {          // the last block's results
+        nt4_window<TO, EPI, Nt4Cfg<PROBE, false, -1, -1, false, true, true, 8>>(accC, accP, fa, fb, rbk, hold, act, bias, aux, u, l, smem);
+        w0 = 10;
+      }
     }
-    for (int w = w0; w + 1 < nk; ++w) nt4_window<TO, EPI, Nt4Cfg<false, -1, -1, false, true, true>>(accC, accP, fa, fb, rbk, bias, aux, u, l, smem);
+    for (int w = w0; w + 1 < nk; ++w) nt4_window<TO, EPI, Nt4Cfg<PROBE, false, -1, -1, false, true, true>>(accC, accP, fa, fb, rbk, hold, act, bias, aux, u, l, smem);
     // the tile is finished by the next k-step 3: its coordinates become the epilogue's
     nt4_set_prev<TO, EPI>(u, cw.m0(), cw.n0());
     if (t + 1 < ntw) {
-      nt4_window<TO, EPI, Nt4Cfg<true, -1, 0, true, true, true>>(accC, accP, fa, fb, rbk, bias, aux, u, l, smem);
+      nt4_window<TO, EPI, Nt4Cfg<PROBE, true, -1, 0, true, true, true>>(accC, accP, fa, fb, rbk, hold, act, bias, aux, u, l, smem);
       cw.advance();
     } else {
-      nt4_slots<TO, EPI, Nt4Cfg<true, -1, -1, false, false, false>, 0, 9>(accC, accP, fa, fb, rbk, bias, aux, u, l, smem);
+      nt4_slots<TO, EPI, Nt4Cfg<PROBE, true, -1, -1, false, false, false>, 0, 9>(accC, accP, fa, fb, rbk, hold, act, bias, aux, u, l, smem);
       break;
     }
   }
@@ -422,32 +502,43 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt4_kernel(const bf16_t* A, lon
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int j = 0; j < 3; ++j) nt4_bias_issue(bias, j, u, l);
-  nt4_final<TO, EPI, 0, (EPI == EPI_RESID ? 5 : 9)>(accP, rbk, bias, u, l, smem);
-  if constexpr (EPI == EPI_RESID) nt4_final<TO, EPI, 5, 9>(accP, rbk, bias, u, l, smem);
+  nt4_final<TO, EPI, 0, (EPI == EPI_RESID ? 5 : 9)>(accP, rbk, hold, bias, u, l, smem);
+  if constexpr (EPI == EPI_RESID) nt4_final<TO, EPI, 5, 9>(accP, rbk, hold, bias, u, l, smem);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // no LDS-DMA may outlive the workgroup's LDS allocation
 }
 
-static int g_nt4 = 1;             // climb_set_option 17: 0 = never, 1 = where it applies (default), 2 = also below the size the 8-wave kernels keep
-static int g_nt4_grid = 256;      // follows climb_set_option 9 (CUs left to RCCL)
+#ifndef NT4_SLP_BUILD
+int g_nt4 = 1;             // climb_set_option 17: 0 = never, 1 = where it applies (default), 2 = the build with packed epilogue arithmetic (A/B)
+int g_nt4_probe = 0;       // climb_set_option 18 (measurement)
+int g_nt4_grid = 256;      // follows climb_set_option 9 (CUs left to RCCL)
+void climb_nt4_set_probe(int v) { g_nt4_probe = v; }
 void climb_nt4_set(int v) { g_nt4 = v; }
 void climb_nt4_set_grid(int v) { g_nt4_grid = v; }
+int climb_nt4slp_launch(const bf16_t* A, long lda, const bf16_t* B, long ldb, void* C, long ldc, int c_dtype, int M, int N, int K, const float* bias, int epi,
+                        const void* aux, long ldaux, bf16_t* aux_out, long ldauxo, hipStream_t st);
+#else
+extern int g_nt4, g_nt4_probe, g_nt4_grid;
+#endif
 
-template <typename TO, int EPI>
+template <typename TO, int EPI, int PROBE = 0>
 static int nt4_launch_one(int nwg, hipStream_t st, const bf16_t* A, long lda, const bf16_t* B, long ldb, TO* C, long ldc, int M, int N, int K, const float* bias,
                           const void* aux, long ldaux, bf16_t* aux_out, long ldauxo) {
   static bool configured = false;
   if (!configured) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_nt4_kernel<TO, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, NT4_LDS);
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_nt4_kernel<TO, EPI, PROBE>, hipFuncAttributeMaxDynamicSharedMemorySize, NT4_LDS);
     if (e != hipSuccess) return (int)e;
     configured = true;
   }
-  hipLaunchKernelGGL((gemm_bf16_nt4_kernel<TO, EPI>), dim3(nwg), dim3(256), NT4_LDS, st, A, lda, B, ldb, C, ldc, M, N, K, bias, aux, ldaux, aux_out, ldauxo);
+  hipLaunchKernelGGL((gemm_bf16_nt4_kernel<TO, EPI, PROBE>), dim3(nwg), dim3(256), NT4_LDS, st, A, lda, B, ldb, C, ldc, M, N, K, bias, aux, ldaux, aux_out, ldauxo, PROBE ? 0 : g_nt4_probe);
   return CLIMB_OK;
 }
 
 int climb_nt4_launch(const bf16_t* A, long lda, const bf16_t* B, long ldb, void* C, long ldc, int c_dtype, int M, int N, int K, const float* bias, int epi,
                      const void* aux, long ldaux, bf16_t* aux_out, long ldauxo, hipStream_t st) {
   if (g_nt4 == 0) return CLIMB_EUNSUPPORTED;
+#ifndef NT4_SLP_BUILD
+  if (g_nt4 == 2) return climb_nt4slp_launch(A, lda, B, ldb, C, ldc, c_dtype, M, N, K, bias, epi, aux, ldaux, aux_out, ldauxo, st);
+#endif
   if ((M % NT4_T) || (N % NT4_T) || ((M / NT4_T) % 8) || (K % GB_BK) || K < 10 * GB_BK) return CLIMB_EUNSUPPORTED;
   const long lim = 1L << 31;
   if (((long)M * lda + K) * 2 >= lim || ((long)N * ldb + K) * 2 >= lim || (long)M * ldc * 4 >= lim || (long)M * ldaux * 4 >= lim || (long)M * ldauxo * 2 >= lim)
@@ -457,7 +548,18 @@ int climb_nt4_launch(const bf16_t* A, long lda, const bf16_t* B, long ldb, void*
   if (grid < 8) grid = 8;
   const int nwg = tiles < grid ? tiles : grid;      // tiles is a multiple of 8
 #define L4(TO, E) return nt4_launch_one<TO, E>(nwg, st, A, lda, B, ldb, (TO*)C, ldc, M, N, K, bias, aux, ldaux, aux_out, ldauxo)
+#ifndef NT4_SLP_BUILD
+#define L4P(P) return nt4_launch_one<bf16_t, EPI_NONE, P>(nwg, st, A, lda, B, ldb, (bf16_t*)C, ldc, M, N, K, bias, aux, ldaux, aux_out, ldauxo)
+  if (c_dtype == CLIMB_DT_BF16 && epi == EPI_NONE && g_nt4_probe >= 101 && g_nt4_probe <= 104) {      // measurement builds (option 18 = 100 + bits)
+    if (g_nt4_probe == 101) L4P(1);
+    if (g_nt4_probe == 102) L4P(2);
+    if (g_nt4_probe == 103) L4P(3);
+    if (g_nt4_probe == 104) L4P(4);
+  }
+#undef L4P
+#endif
   if (c_dtype == CLIMB_DT_BF16 && epi == EPI_NONE) L4(bf16_t, EPI_NONE);
+  if ((epi == EPI_GELU || epi == EPI_DGELU) && K < 11 * GB_BK) return CLIMB_EUNSUPPORTED;      // one more k-tile: the held results of the ninth block
   if (c_dtype == CLIMB_DT_BF16 && epi == EPI_GELU) L4(bf16_t, EPI_GELU);
   if (c_dtype == CLIMB_DT_BF16 && epi == EPI_DGELU) L4(bf16_t, EPI_DGELU);
   if (c_dtype == CLIMB_DT_F32 && epi == EPI_RESID) L4(float, EPI_RESID);
