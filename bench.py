@@ -39,6 +39,8 @@ def main():
     ap.add_argument("--graph", action="store_true", help="replay the step as a captured hipGraph (measured equal to eager launches at bs=64: the GPU, not the host, is the bottleneck)")
     ap.add_argument("--no-cls-only-leg", action="store_true", help="skip the extra K steps with CLIMB_AMD_CLS_ONLY_LAST=1 (profiling runs: the trace then holds the default step only)")
     ap.add_argument("--cpu-steps", type=int, default=10, help="timed B=2 CPU steps (BASELINE.md section 4: 10)")
+    ap.add_argument("--spawn-check", action="store_true", help="N-rank launch plumbing only (no GPU needed): every rank joins a gloo group, one all-reduce, "
+                                                                "rank 0 prints a JSON line -- what tests/test_host_logic.py runs for `--gpus 2`")
     args = ap.parse_args()
 
     import numpy as np
@@ -49,8 +51,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world == 1:
-        raise SystemExit("for --gpus N>1 launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
-                         "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+        # started as plain `python bench.py --gpus N`: become the launcher -- N ranks of this same command line under torch.distributed.run on
+        # 127.0.0.1 and a free port; rank 0's JSON line is the last line of OUR stdout, the exit code is the job's
+        sys.exit(self_launch(args.gpus))
+    if args.spawn_check:
+        return spawn_check(world, rank)
     if rank != 0:
         os.dup2(2, 1)       # only rank 0 owns stdout: whatever another rank's libraries print (RCCL's banner sits in a C stdio buffer until exit) goes to stderr
     torch.cuda.set_device(local_rank)
@@ -150,6 +155,8 @@ def main():
         torch.cuda.synchronize()
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]      # step boundaries on the compute stream (median step time)
     fence()
+    if ddp is not None:
+        ddp.bytes_reduced = 0             # the payload of the TIMED steps only (warm-up, the overlap trial and the A/B leg are not in the divisor either)
     t0 = time.perf_counter()
     marks[0].record()
     for i in range(args.steps):
@@ -160,6 +167,7 @@ def main():
     eng.prof = None
     fence()
     dt = time.perf_counter() - t0
+    bytes_timed = ddp.bytes_reduced if ddp is not None else 0
     step_ms_seq = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
     if os.environ.get("CLIMB_AMD_BENCH_STEPS"):
         print("per-step ms:", " ".join(f"{v:.2f}" for v in step_ms_seq), file=sys.stderr)
@@ -270,7 +278,7 @@ def main():
             if dp_tuned:
                 out["dp_overlap_warmup_trial"] = dp_tuned
             out["dp_payload"] = ddp.compress
-            out["allreduce_MB_per_step"] = round(ddp.bytes_reduced / 1e6 / (args.steps + args.warmup + (args.steps + 2 if dp_ab else 0)), 1)
+            out["allreduce_MB_per_step"] = round(bytes_timed / 1e6 / args.steps, 1)
             if dp_ab:
                 out["dp_overlap_ab"] = dict(dp_ab, **{("overlap" if ddp.overlap else "deferred") + "_ms_per_step": round(ms, 3)})
         if world == 1 and args.child_check:
@@ -311,7 +319,35 @@ def fp16_operand_line(args):
         return {"error": repr(e)[:200]}
 
 
-NT_SOURCES = ("common.h", "gemm_bf16.hip", "gemm_bf16_nt.h", "gemm_bf16_nt2p.hip", "gemm_bf16_ntp.hip", "gemm_bf16_phase.h")
+NT_SOURCES = ("common.h", "gemm_bf16.hip", "gemm_bf16_nt.h", "gemm_bf16_nt2p.hip", "gemm_bf16_nt4.hip", "gemm_bf16_ntp.hip", "gemm_bf16_phase.h")
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: N ranks of the same command under torch.distributed.run, rendezvous on 127.0.0.1 (the container
+    hostname may not resolve) and a port the kernel hands out.  Children inherit stdout / stderr: rank 0's JSON line is the last line on stdout."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    return subprocess.call(cmd, env=env)
+
+
+def spawn_check(world, rank):
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo")
+    t = torch.tensor([float(rank + 1)])
+    dist.all_reduce(t)
+    if rank == 0:
+        print(json.dumps({"spawn_check": True, "n_gpus": world, "sum_of_ranks_plus_one": float(t.item()), "master_addr": os.environ.get("MASTER_ADDR")}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
 
 
 def csrc_hash():
@@ -355,10 +391,15 @@ def bf16_vs_reference(dev, precision="bf16"):
     norms = np.array([float(G[n].norm()) for n in names])
     big = z["grad_norms"] > 1e-3 * z["grad_norms"].max()
     gerr = np.abs(norms - z["grad_norms"])[big] / z["grad_norms"][big]
-    return {"fixture": "tests/golden/vqa_b64.npz (reference train_step, B=64)", "pooled": round(rel(pooled, z["pooled"]), 6),
-            "logits": round(rel(logits, z["logits"]), 6), "loss": round(rel(loss, z["loss"]), 8),
-            "argmax_agreement": float((logits.argmax(-1).cpu().numpy() == z["logits"].argmax(-1)).mean()),
-            "grad_norm_rel_err_median": round(float(np.median(gerr)), 6), "grad_norm_rel_err_max": round(float(gerr.max()), 6)}
+    r = {"fixture": "tests/golden/vqa_b64.npz (reference train_step, B=64)", "pooled": round(rel(pooled, z["pooled"]), 6),
+         "logits": round(rel(logits, z["logits"]), 6), "loss": round(rel(loss, z["loss"]), 8),
+         "argmax_agreement": float((logits.argmax(-1).cpu().numpy() == z["logits"].argmax(-1)).mean()),
+         "grad_norm_rel_err_median": round(float(np.median(gerr)), 6), "grad_norm_rel_err_max": round(float(gerr.max()), 6)}
+    # north_star's bar, clause by clause, for THIS arithmetic mode (1e-3 relative; argmax bit-exact): the headline's bf16 mode meets the loss and the
+    # typical gradient norm and misses the element-wise clauses by the 2^-9 operand rounding; fp32 mode meets all of them
+    r["meets_1e-3"] = {"loss": r["loss"] <= 1e-3, "grad_norm_median": r["grad_norm_rel_err_median"] <= 1e-3, "grad_norm_max": r["grad_norm_rel_err_max"] <= 1e-3,
+                       "pooled": r["pooled"] <= 1e-3, "logits": r["logits"] <= 1e-3, "argmax": r["argmax_agreement"] == 1.0}
+    return r
 
 
 def real_input_line(dev, args):

@@ -258,3 +258,43 @@ def test_grouped_weight_gradient_plan_covers_every_reduction_tile_once(layers, n
     bad = np.array([12288 + 64], dtype=np.int32)
     assert lib.climb_tn_grouped_plan(1, bad.ctypes.data, N.ctypes.data, K.ctypes.data, 256, items.ctypes.data, cap, first.ctypes.data) == -1   # M % 128
     assert lib.climb_tn_grouped_plan(len(shapes), M.ctypes.data, N.ctypes.data, K.ctypes.data, nwg, items.ctypes.data, 8, first.ctypes.data) == -2
+
+
+def test_bench_gpus_n_launches_itself_and_prints_one_json_line_last():
+    """the driver starts the scaling run as plain `python bench.py --gpus N` -- without a launcher around it bench.py must become
+    the launcher (N ranks of its own command line under torch.distributed.run on 127.0.0.1 / a free port) and rank 0's JSON line must be the last
+    line on stdout.  `--spawn-check` runs exactly that plumbing without a GPU (gloo group, one all-reduce across the ranks)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--spawn-check"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    last = [l for l in r.stdout.splitlines() if l.strip()][-1]
+    j = json.loads(last)
+    assert j["spawn_check"] is True and j["n_gpus"] == 2 and j["sum_of_ranks_plus_one"] == 3.0 and j["master_addr"] == "127.0.0.1"
+
+
+def test_nt4_tile_walk_is_a_bijection():
+    """The four-wave NT kernel (csrc/gemm_bf16_nt4.hip) walks its tiles without a division: launch position id -> XCD id % 8, whose share is one
+    supertile of nbm / 8 M-tiles x all N-tiles, walked M first, `step` = grid / 8 positions per persistent iteration.  The same arithmetic in
+    Python: every tile exactly once, for the benchmark's shapes, a reduced grid (CUs left to RCCL) and tile counts below the grid."""
+    def walk(nbm, nbn, G):
+        nwg = nbm * nbn
+        G = min(G // 8 * 8, nwg)
+        gm, step = nbm // 8, G // 8
+        seen = []
+        for b in range(G):
+            xcd, idx = b & 7, b >> 3
+            tn, tml = idx // gm, idx % gm
+            for _ in range((nwg - b + G - 1) // G):
+                seen.append((xcd * gm + tml, tn))
+                tml += step
+                while tml >= gm:
+                    tml -= gm
+                    tn += 1
+        return seen
+    for nbm, nbn, G in [(64, 4, 256), (64, 12, 256), (64, 16, 256), (64, 16, 224), (96, 16, 256), (8, 1, 256), (16, 3, 256), (48, 4, 256), (64, 12, 64)]:
+        seen = walk(nbm, nbn, G)
+        assert len(seen) == nbm * nbn and set(seen) == {(m, n) for m in range(nbm) for n in range(nbn)}, (nbm, nbn, G)

@@ -43,7 +43,8 @@ def run(name, model, task, images, tx, target, ewc=None, steps=12, warm=4):
         opt.zero_grad()
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / steps * 1e3
-    print(f"{name:46s} {ms:7.2f} ms/step  {64 / ms * 1e3:7.0f} encoder sequences/s")
+    nseq = int(tx["input_ids"].shape[0]) if task != "nlvr2" else int(images.shape[0])
+    print(f"{name:46s} {ms:7.2f} ms/step  {nseq / ms * 1e3:7.0f} encoder sequences/s")
 
 
 pix = torch.randn(B, 3, 384, 384, generator=g).to(dev)
@@ -79,3 +80,11 @@ m5 = make(["snli-ve", "vcr"])
 m5.eval()       # the VCR head's Dropout(0.1) is host-seeded; timing is the same
 run("VCR: 16 questions x 4 choices = 64 sequences", m5, "vcr", torch.randn(B // 4, 3, 384, 384, generator=g).to(dev), texts(B),
     torch.randint(0, 4, (B // 4,), generator=g).to(dev))
+
+# r04: the per-rank shares of `--batch_size 64` (the trajectory-preserving data-parallel launch of INTEGRATION.md keeps the GLOBAL batch: on 2 / 4 / 8
+# GPUs a rank steps 32 / 16 / 8 sequences) -- what one GPU does with them, so that the scaling that launch can reach is known before hardware sees it
+m6 = make(["vqa", "nlvr2"])
+for b in (32, 16, 8):
+    tb = torch.zeros(b, 3129)
+    tb[torch.arange(b), torch.randint(0, 3129, (b,), generator=g)] = 1.0
+    run(f"sequential FT, {b} sequences per GPU (= 64 / {64 // b} GPUs)", m6, "vqa", pix[:b].contiguous(), texts(b), tb.to(dev))
