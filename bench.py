@@ -104,7 +104,10 @@ def main():
     fwd_bwd = model.graphed_forward_backward if use_graph else model.fused_forward_backward
 
     def step(eager=False):
-        loss, _, _, _ = (model.fused_forward_backward if eager else fwd_bwd)("vqa", pixels, texts, target)
+        if eager or not use_graph:       # the training step as the trainers run it (climb_amd/train/task_trainer.py::train_step): the optimizer is named, step() follows
+            loss, _, _, _ = model.fused_forward_backward("vqa", pixels, texts, target, optimizer=opt)
+        else:
+            loss, _, _, _ = fwd_bwd("vqa", pixels, texts, target)
         opt.step()
         sched.step()
         opt.zero_grad()

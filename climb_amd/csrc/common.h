@@ -145,6 +145,17 @@ __device__ __forceinline__ float dgelu_fast(float x) {
   return x < -4.0f ? 0.f : d;
 }
 
+// torch.optim.AdamW (decoupled decay), REF/modeling/vilt.py:205-215 -- ONE definition for the flat optimizer pass (optim.hip) and the fused epilogue of
+// the grouped weight-gradient launch (gemm_bf16_tnp.hip), so that the two produce the same bits:
+//   p *= 1 - lr*wd;  m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;  p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
+struct AdamGroup { float lr, wd, beta1, beta2, eps, bc1, bc2, pad; };
+__device__ __forceinline__ void adamw_update(float& p, float& m, float& v, float g, const AdamGroup& G, float isb2, float step) {
+  p *= 1.f - G.lr * G.wd;
+  m = G.beta1 * m + (1.f - G.beta1) * g;
+  v = G.beta2 * v + (1.f - G.beta2) * g * g;
+  p -= step * m / (sqrtf(v) * isb2 + G.eps);
+}
+
 // epilogue codes shared by the f32 and bf16 GEMMs
 #define EPI_NONE 0    // C = acc + bias
 #define EPI_GELU 1    // aux_out = acc + bias ; C = gelu(aux_out)

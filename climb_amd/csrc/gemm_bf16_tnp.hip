@@ -360,12 +360,27 @@ struct TnGroupProblem {      // 72 bytes; include/climb_hip.h documents this lay
   int M, N, K, reserved;
 };
 struct TnGroupItem { int prob, tn, tk, kt0, kt1, partial, r0, r1; };      // 32 bytes; reduction tiles [kt0, kt1) of 64 tokens, kt1 - kt0 >= 2
+// r04: the optimizer in the epilogue.  Nothing reads a weight gradient between the backward and optimizer.step() in the fused training step, and
+// this launch is MFMA / power-bound with the memory system half idle: a WHOLE tile (the only writer of its elements) of a problem marked `fused`
+// applies AdamW right there -- g = tile sum (+ what the gradient buffer already holds, when the host says it is not zero: the EWC penalty's
+// 2 lam F (theta - theta*), REF/cl_algorithms/ewc.py:75-87, or an earlier accumulating backward), reads p, m, v, writes p, m, v, the 16-bit
+// shadow [N,K] and the TRANSPOSED shadow [K,N] the input-gradient GEMMs read -- and never writes the gradient.  The flat AdamW pass then skips
+// these tensors, the batched shadow transpose too.  A problem may be fused only if ALL its tiles are whole tiles (the host checks the plan).
+struct TnGroupOpt {          // 56 bytes, parallel to the problems; include/climb_hip.h documents this layout
+  float* p; float* m; float* v;      // [N, K] fp32, leading dimension = the problem's ldc
+  bf16_t* s;                         // [N, K] 16-bit shadow, leading dimension ldc
+  bf16_t* st;                        // [K, N] transposed 16-bit shadow, leading dimension ldt
+  long ldt;
+  int fused, pad;
+};
+struct TnAdam { AdamGroup g; float gscale; int grad_dirty; };
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
 
 // RAGGED: N, K any multiples of 8 (the adapters' 768 x 48 / 48 x 768 gradients ride in the same launch as 256 x 256 tiles whose surplus
 // columns are computed on clamped addresses and never stored -- the FLOPs of those GEMMs are nothing, their launches and operand reads were).
-template <bool RAGGED>
+template <bool RAGGED, bool FUSED = false>
 __global__ __launch_bounds__(512) void gemm_bf16_tn_grouped_kernel(const TnGroupProblem* __restrict__ probs, const TnGroupItem* __restrict__ items,
-                                                                   const int* __restrict__ first) {
+                                                                   const int* __restrict__ first, const TnGroupOpt* __restrict__ opts = nullptr, TnAdam ad = TnAdam()) {
   constexpr int NI = 4, BK_ = 256;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -458,6 +473,50 @@ __global__ __launch_bounds__(512) void gemm_bf16_tn_grouped_kernel(const TnGroup
         for (int j = 0; j < 2; ++j)
 #pragma unroll
           for (int r = 0; r < 16; ++r) atomicAdd(Cb + (long)(j * 32 + (r & 3) + 8 * (r >> 2)) * ldc + p * 32, acc[p][j][r]);
+    } else if (FUSED && opts[__builtin_amdgcn_readfirstlane(item.prob)].fused) {
+      // whole tile of a fused problem: AdamW here.  Element (p, j, r) of this lane = weight [n][k], n = n0 + wr*64 + 4*half + j*32 + 8*(r>>2) + (r&3),
+      // k = k0 + wc*128 + p*32 + l31: fp32 accesses are 128-byte rows of 32 lanes, the transposed shadow gets 4 consecutive n (8 bytes) per lane
+      const TnGroupOpt O = opts[__builtin_amdgcn_readfirstlane(item.prob)];
+      // MUBUF addressing: one per-lane offset (elements) + a scalar offset per element: no 64-bit address arithmetic in vector registers (the flat
+      // form of this epilogue spilled 1.1 KB per lane next to the 128 accumulators)
+      const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void*)O.p, 0, 0x7fffffff, 0x00020000), rm = __builtin_amdgcn_make_buffer_rsrc((void*)O.m, 0, 0x7fffffff, 0x00020000),
+                                   rv = __builtin_amdgcn_make_buffer_rsrc((void*)O.v, 0, 0x7fffffff, 0x00020000), rg = __builtin_amdgcn_make_buffer_rsrc((void*)P.C, 0, 0x7fffffff, 0x00020000),
+                                   rs = __builtin_amdgcn_make_buffer_rsrc((void*)O.s, 0, 0x7fffffff, 0x00020000), rt = __builtin_amdgcn_make_buffer_rsrc((void*)O.st, 0, 0x7fffffff, 0x00020000);
+      const unsigned le = (unsigned)((4 * half) * (int)ldc + l31);                                          // lane part of the [N,K] element index
+      const unsigned lt = (unsigned)(l31 * (int)O.ldt + 4 * half) * 2u;                                     // lane part of the [K,N] byte offset
+      const unsigned se0 = (unsigned)((n0 + wr * 64) * (int)ldc + k0 + wc * (32 * NI));                     // uniform parts
+      const unsigned st0 = (unsigned)((k0 + wc * (32 * NI)) * (int)O.ldt + n0 + wr * 64) * 2u;
+      const float isb2 = rsqrtf(ad.g.bc2), step = ad.g.lr / ad.g.bc1;
+      const bool dirty = ad.grad_dirty != 0;
+#pragma unroll
+      for (int p = 0; p < NI; ++p)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {          // one 32 x 32 block: every load before the first store (a load behind a store drains the store queue)
+          float pv[16], mv[16], vv[16], gv[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const unsigned so = (se0 + (unsigned)((j * 32 + (r & 3) + 8 * (r >> 2)) * (int)ldc + p * 32)) * 4u;
+            pv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rp, le * 4u, so, 0));
+            mv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rm, le * 4u, so, 0));
+            vv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rv, le * 4u, so, 0));
+            gv[r] = dirty ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rg, le * 4u, so, 0)) : 0.f;
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) adamw_update(pv[r], mv[r], vv[r], (gv[r] + acc[p][j][r]) * ad.gscale, ad.g, isb2, step);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const unsigned so = (se0 + (unsigned)((j * 32 + (r & 3) + 8 * (r >> 2)) * (int)ldc + p * 32));
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pv[r]), rp, le * 4u, so * 4u, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, mv[r]), rm, le * 4u, so * 4u, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, vv[r]), rv, le * 4u, so * 4u, 0);
+            __builtin_amdgcn_raw_buffer_store_b16(f32_to_bf16(pv[r]), rs, le * 2u, so * 2u, 0);
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {          // four consecutive n of one k: 8 bytes of the transposed shadow
+            u32x2_t w = {pack_bf16x2(pv[q * 4 + 0], pv[q * 4 + 1]), pack_bf16x2(pv[q * 4 + 2], pv[q * 4 + 3])};
+            __builtin_amdgcn_raw_buffer_store_b64(w, rt, lt, st0 + (unsigned)((p * 32) * (int)O.ldt + j * 32 + 8 * q) * 2u, 0);
+          }
+        }
     } else {
       // whole tile: the only writer of these elements in this launch.  All 16 loads of a (p, j) block are issued before its first store
       // (a load behind a store drains the store queue on gfx9: one vmcnt for both kinds)
@@ -583,6 +642,35 @@ extern "C" int climb_gemm_bf16_tn_grouped(const void* probs, const void* items, 
   else
     hipLaunchKernelGGL(gemm_bf16_tn_grouped_kernel<false>, dim3(nwg), dim3(512), LDS, (hipStream_t)stream, (const TnGroupProblem*)probs,
                        (const TnGroupItem*)items, (const int*)first);
+  LAUNCH_CHECK();
+  return CLIMB_OK;
+}
+
+// The same launch with the optimizer in the epilogue of the problems whose TnGroupOpt says `fused` (see above).  opts: device array parallel to
+// probs; adam: HOST array of 8 floats { lr, weight decay, beta1, beta2, eps, 1 - beta1^t, 1 - beta2^t, gradient scale }; grad_dirty != 0: the
+// gradient buffer (the problems' C) is not zero and is added to the tile sums before the update (it is never written for fused problems).
+extern "C" int climb_gemm_bf16_tn_grouped_adamw(const void* probs, const void* items, const void* first, int nwg, int ragged, const void* opts, const float* adam,
+                                                int grad_dirty, void* stream) {
+  if (!probs || !items || !first || nwg <= 0 || !opts || !adam) return CLIMB_EINVAL;
+  constexpr int LDS = 2 * (NTP_A_BYTES + 4 * NTP_B_UNIT);
+  static bool configured = false;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_tn_grouped_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute((const void*)gemm_bf16_tn_grouped_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) return (int)e;
+    configured = true;
+  }
+  TnAdam ad;
+  ad.g = AdamGroup{adam[0], adam[1], adam[2], adam[3], adam[4], adam[5], adam[6], 0.f};
+  ad.gscale = adam[7];
+  ad.grad_dirty = grad_dirty;
+  if (ragged)
+    hipLaunchKernelGGL((gemm_bf16_tn_grouped_kernel<true, true>), dim3(nwg), dim3(512), LDS, (hipStream_t)stream, (const TnGroupProblem*)probs,
+                       (const TnGroupItem*)items, (const int*)first, (const TnGroupOpt*)opts, ad);
+  else
+    hipLaunchKernelGGL((gemm_bf16_tn_grouped_kernel<false, true>), dim3(nwg), dim3(512), LDS, (hipStream_t)stream, (const TnGroupProblem*)probs,
+                       (const TnGroupItem*)items, (const int*)first, (const TnGroupOpt*)opts, ad);
   LAUNCH_CHECK();
   return CLIMB_OK;
 }

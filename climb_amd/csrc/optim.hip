@@ -3,7 +3,6 @@
 // flat fp32 buffer (each tensor 64-element aligned), so each of these is a single launch streaming at HBM rate.
 #include "common.h"
 
-struct AdamGroup { float lr, wd, beta1, beta2, eps, bc1, bc2, pad; };
 struct AdamGroups { AdamGroup g[8]; };
 
 // seg_start[nseg+1]: element offsets of the tensors (ascending, multiples of 4); seg_group[nseg]: group id or -1 (skip).
@@ -31,11 +30,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     const float isb2 = rsqrtf(G.bc2), step = G.lr / G.bc1;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const float gr = ga[j] * gscale;
-      pa[j] *= 1.f - G.lr * G.wd;
-      ma[j] = G.beta1 * ma[j] + (1.f - G.beta1) * gr;
-      va[j] = G.beta2 * va[j] + (1.f - G.beta2) * gr * gr;
-      pa[j] -= step * ma[j] / (sqrtf(va[j]) * isb2 + G.eps);
+      adamw_update(pa[j], ma[j], va[j], ga[j] * gscale, G, isb2, step);
     }
     st4(p + e, make_float4(pa[0], pa[1], pa[2], pa[3]));
     st4(m + e, make_float4(ma[0], ma[1], ma[2], ma[3]));

@@ -188,6 +188,12 @@ class ViltEngine:
         precision = "fp32" if precision == "fp32" else "bf16"      # the two code paths; `h16` says which 16-bit type the second one runs on
         self.loss_scale = 1.0           # fp16 only: factor on d(logits) of the current backward, divided out of every range in _ready()
         self._grad_dirty = False        # the gradient buffer holds sums of earlier backwards (accumulation without zero_grad)
+        # r04: the optimizer in the epilogue of the grouped weight-gradient launch.  `defer_dw` is armed by a caller that promises optimizer.step()
+        # is the next reader of the weight gradients (the fused training step); the launch is then held back (`_dw_deferred`) until FusedAdamW.step()
+        # runs it with the update in its epilogue.  Anything else that looks at the gradient buffer first calls materialize_dw() (the plain launch).
+        self.defer_dw = False
+        self._dw_deferred = []          # [(ws, plan)]
+        self._grad_extra = False        # the weight matrices' gradient ranges hold something besides zeros (EWC penalty term, an earlier backward)
         self._unscale_pending = self._prescaled = False
         self.layout = layout
         self.cfg = layout.cfg
@@ -236,6 +242,8 @@ class ViltEngine:
         self._ws.clear()
         self._shadow = None
         self._shadow_version = -1
+        self._t_fresh = None
+        self._t_sub = {}
 
     def view(self, base: torch.Tensor, name: str) -> torch.Tensor:
         o = self.layout.offset[name]
@@ -251,6 +259,15 @@ class ViltEngine:
         self.grad.zero_()
         self.touched = []
         self._grad_dirty = False
+        self._dw_deferred = []          # gradients nobody asked for are never computed
+        self._grad_extra = False
+
+    def materialize_dw(self):
+        """Run weight-gradient launches that were held back for the optimizer as the plain launches they replace (C += dW)."""
+        held, self._dw_deferred = self._dw_deferred, []
+        for ws, plan in held:
+            self._timed_call("gemm_bf16_tn", plan["flops"], "climb_gemm_bf16_tn_grouped", plan["probs"], plan["items"], plan["first"], plan["nwg"], plan["ragged"], _stream())
+            self._grad_extra = True
 
     def begin_scaled_backward(self, max_dlogit: float):
         """fp16 operands only.  Picks the power-of-two loss scale that puts the largest possible |d(logits)| near 1 (the BCE gradient of a
@@ -442,9 +459,21 @@ class ViltEngine:
         if ver == self._shadow_version and not self._shadow_stale:
             return
         st = _stream()
+        table, tn = self._t_table, self._t_n
         if self._shadow_stale != "transpose-only":
             _lib.call("climb_cast_bf16", self.flat, self._shadow, self.layout.total, st)
-        _lib.call("climb_transpose_bf16_batched", self._shadow, self._shadow_t, self._t_table, self._t_n, 96, st)
+        elif self._t_fresh:
+            # the optimizer ran in the weight-gradient epilogue for these tensors and wrote their transposed shadows there
+            key = frozenset(self._t_fresh)
+            sub = self._t_sub.get(key)
+            if sub is None:
+                import numpy as np
+                rows = [(self.layout.offset[name], self._t_off[name], N, K) for name, N, K in self._linear_weight_names() if name not in key]
+                sub = self._t_sub[key] = (torch.from_numpy(np.array(rows, dtype=np.int64).reshape(-1, 4)).to(self.device), len(rows))
+            table, tn = sub
+        if tn:
+            _lib.call("climb_transpose_bf16_batched", self._shadow, self._shadow_t, table, tn, 96, st)
+        self._t_fresh = None
         self._shadow_version = ver
         self._shadow_stale = False
 
@@ -456,8 +485,9 @@ class ViltEngine:
             self.refresh_shadow()          # first use: full cast, so tensors the optimiser skips have valid shadows too
         return self._shadow
 
-    def params_updated(self, shadow_fresh: bool = False):
+    def params_updated(self, shadow_fresh: bool = False, t_fresh=None):
         self._shadow_stale = "transpose-only" if shadow_fresh else True
+        self._t_fresh = set(t_fresh) if (shadow_fresh and t_fresh) else None
 
     def sp(self, name: str) -> int:
         return self._shadow.data_ptr() + 2 * self.layout.offset[name]
@@ -707,12 +737,47 @@ class ViltEngine:
             plan = dict(probs=torch.from_numpy(rec.view(np.uint8).copy()).to(dev), items=torch.from_numpy(items[:n_items].copy()).to(dev),
                         first=torch.from_numpy(first).to(dev), nwg=nwg, flops=float(sum(2.0 * M * N * K for _, _, _, _, M, N, K in pending)),
                         ragged=int(any((N % 256) or (K % 256) for _, _, _, _, M, N, K in pending)),
-                        keep=[(dY, X) for dY, X, *_ in pending])
+                        keep=[(dY, X) for dY, X, *_ in pending],
+                        names=[w for _, _, w, *_ in pending], shapes=[(N, K) for _, _, _, _, M, N, K in pending],
+                        # problems ALL of whose tiles are whole tiles (no stream-K share): the ones the optimizer may be fused into
+                        whole=[bool(i not in set(int(x) for x in items[:n_items][items[:n_items, 5] == 1, 0])) for i in range(len(pending))], opts={})
             if len(ws.dw_plans) >= 16:           # requires_grad patterns / group sizes seen on this shape: bounded
                 ws.dw_plans.pop(next(iter(ws.dw_plans)))
             ws.dw_plans[key] = plan
-        self._timed_call("gemm_bf16_tn", plan["flops"], "climb_gemm_bf16_tn_grouped", plan["probs"], plan["items"], plan["first"], plan["nwg"], plan["ragged"], _stream())
+        if self.defer_dw and self.grad_ready_hook is None and self.loss_scale == 1.0 and not plan["ragged"]:
+            self._dw_deferred.append((ws, plan))          # FusedAdamW.step() (or materialize_dw()) launches it
+        else:
+            self._timed_call("gemm_bf16_tn", plan["flops"], "climb_gemm_bf16_tn_grouped", plan["probs"], plan["items"], plan["first"], plan["nwg"], plan["ragged"], _stream())
+            self._grad_extra = True
         pending.clear()
+
+    def fused_dw_adamw(self, opt_m: torch.Tensor, opt_v: torch.Tensor, eligible, adam_row) -> set:
+        """The held-back weight-gradient launches with AdamW in their epilogue (csrc/gemm_bf16_tnp.hip).  `eligible(name) -> bool`: tensors the
+        optimizer updates THIS step with the constants `adam_row` (8 floats: lr, wd, beta1, beta2, eps, 1 - beta1^t, 1 - beta2^t, gradient scale).
+        Returns the names that were updated here (the flat pass must skip them; their transposed shadows are fresh too)."""
+        import numpy as np
+        held, self._dw_deferred = self._dw_deferred, []
+        done = set()
+        row = np.ascontiguousarray(adam_row, dtype=np.float32)
+        for ws, plan in held:
+            flags = tuple(bool(w and eligible(n)) for n, w in zip(plan["names"], plan["whole"]))
+            key = (opt_m.data_ptr(), opt_v.data_ptr(), flags)
+            opts = plan["opts"].get(key)
+            if opts is None:
+                rec = np.zeros(len(flags), dtype=[("p", "<u8"), ("m", "<u8"), ("v", "<u8"), ("s", "<u8"), ("st", "<u8"), ("ldt", "<i8"), ("fused", "<i4"), ("pad", "<i4")])
+                assert rec.dtype.itemsize == 56
+                for r, n, (N, K), f in zip(rec, plan["names"], plan["shapes"], flags):
+                    o = self.layout.offset[n]
+                    r["p"], r["m"], r["v"] = self.p(n), opt_m.data_ptr() + 4 * o, opt_v.data_ptr() + 4 * o
+                    r["s"], r["st"], r["ldt"], r["fused"] = self.sp(n), (self.spt(n) if n in self._t_off else 0), N, int(f and n in self._t_off)
+                opts = torch.from_numpy(rec.view(np.uint8).copy()).to(self.device)
+                if len(plan["opts"]) >= 8:
+                    plan["opts"].pop(next(iter(plan["opts"])))
+                plan["opts"][key] = opts
+            self._timed_call("gemm_bf16_tn", plan["flops"], "climb_gemm_bf16_tn_grouped_adamw", plan["probs"], plan["items"], plan["first"], plan["nwg"], plan["ragged"],
+                             opts, row.ctypes.data, 1 if self._grad_extra else 0, _stream())
+            done.update(n for n, f in zip(plan["names"], flags) if f and n in self._t_off)
+        return done
 
     def _red_flush(self, ws: Workspace, pending: list):
         """the {dgamma, dbeta, bias} reductions recorded by a group's LayerNorm backwards, as one launch"""
@@ -815,6 +880,7 @@ class ViltEngine:
         self._ready(*lay.top_range)
         # d(x_L): cast for the GEMMs (bf16 mode) + column sums for the last layer's output bias
         csr = _lib.query("climb_colsum_rows_per_block")
+        self.materialize_dw()                    # (a backward on top of one whose weight gradients were held for an optimizer step that never came)
         G = self._dw_group_size(ws, ad)          # > 0: weight gradients are recorded per layer and launched per group of G layers
         pending, pending_red, group = [], [], []
         rgroup = self._ready_group()
@@ -1135,7 +1201,10 @@ class ViltEngine:
             self._ewc_ws = torch.empty((_lib.query("climb_ewc_workspace_floats"),), dtype=torch.float32, device=self.device)
         out = torch.empty((), dtype=torch.float32, device=self.device)
         _lib.call("climb_ewc_penalty", self.flat, star, fisher, self.grad if add_grad else None, n, lam, gscale, self._ewc_ws, out, _stream())
+        if add_grad:
+            self._grad_extra = True          # (a held-back weight-gradient launch adds this term to its tile sums before the update)
         return out
 
     def fisher_accumulate(self, fisher: torch.Tensor):
+        self.materialize_dw()
         _lib.call("climb_fisher_accum", fisher, self.grad, self.layout.encoder_end, _stream())

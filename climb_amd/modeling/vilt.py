@@ -577,9 +577,23 @@ class ViltContinualLearner(ContinualLearner):
 
     # --- fused training step: forward + loss + backward (+ EWC term) with no autograd graph.  This is what
     # climb_amd.train.*Trainer.train_step runs; semantics = REF/train/visionlanguage_tasks/train_vqa.py:135-166.
-    def fused_forward_backward(self, task_key: str, images, texts, target: torch.Tensor, ewc=None, dropout_keep=None, grad_weight: float = 1.0):
+    def fused_forward_backward(self, task_key: str, images, texts, target: torch.Tensor, ewc=None, dropout_keep=None, grad_weight: float = 1.0, optimizer=None):
         """`grad_weight` multiplies d(loss) (not the returned loss): a data-parallel rank's share of an uneven global batch,
-        climb_amd/data/sharding.py."""
+        climb_amd/data/sharding.py.
+        `optimizer`: the caller's promise that `optimizer.step()` (this model's FusedAdamW) is the next thing that happens to the gradients
+        (REF/train/visionlanguage_tasks/train_vqa.py:160-170: backward, step, zero_grad).  The grouped weight-gradient launch of the encoder is then
+        held back and run BY that step with AdamW in its epilogue (csrc/gemm_bf16_tnp.hip): `.grad` of those matrices is never written.  Without the
+        promise -- or whenever something else reads the buffer first -- the launch runs as before."""
+        host = self._host
+        eng = host.engine()
+        from ..optim import FusedAdamW
+        eng.defer_dw = bool(isinstance(optimizer, FusedAdamW) and optimizer._host is host and host.ddp is None and os.environ.get("CLIMB_AMD_FUSED_ADAMW", "1") != "0")
+        try:
+            return self._fused_forward_backward(task_key, images, texts, target, ewc, dropout_keep, grad_weight)
+        finally:
+            eng.defer_dw = False
+
+    def _fused_forward_backward(self, task_key: str, images, texts, target: torch.Tensor, ewc=None, dropout_keep=None, grad_weight: float = 1.0):
         host = self._host
         eng = host.engine()
         host.before_backward()

@@ -75,19 +75,36 @@ class FusedAdamW(torch.optim.Optimizer):
                     raise RuntimeError("FusedAdamW: more than 8 distinct (group, step) combinations in one step")
             seg_group[si] = slot
         if not combos:
+            eng.materialize_dw()
             return loss
         table = np.zeros((len(combos), 8), dtype=np.float32)
         for (gi, t), slot in combos.items():
             g = self.param_groups[gi]
             b1, b2 = g["betas"]
             table[slot] = (g["lr"], g["weight_decay"], b1, b2, g["eps"], 1.0 - b1 ** t, 1.0 - b2 ** t, 0.0)
+        fused = set()
+        shadow = eng.shadow_ptr()
+        if eng._dw_deferred:
+            # r04: weight-gradient launches held back for this step (the fused training step armed engine.defer_dw): run them with the update in
+            # their epilogue for the tensors of the most common (group, step) combination; the flat pass below skips what was updated there
+            idx = {n: i for i, n in enumerate(self._seg_names)}
+            names = [n for _, plan in eng._dw_deferred for n, w in zip(plan["names"], plan["whole"]) if w]
+            slots = [int(seg_group[idx[n]]) for n in names]
+            if shadow is not None and any(sl >= 0 for sl in slots):
+                slot0 = max(set(sl for sl in slots if sl >= 0), key=slots.count)
+                row = table[slot0].copy()
+                row[7] = 1.0          # gradient scale
+                fused = eng.fused_dw_adamw(self._m, self._v, lambda n: int(seg_group[idx[n]]) == slot0, row)
+                for n in fused:
+                    seg_group[idx[n]] = -1
+            else:
+                eng.materialize_dw()
         if self._seg_group_host is None or not np.array_equal(seg_group, self._seg_group_host):
             self._seg_group.copy_(torch.from_numpy(seg_group))
             self._seg_group_host = seg_group
-        shadow = eng.shadow_ptr()
         _lib.call("climb_adamw", eng.flat, eng.grad, self._m, self._v, shadow, eng.layout.total, self._seg_start, self._seg_group,
                   len(self._seg_names), table.ctypes.data, len(combos), 1.0, torch.cuda.current_stream().cuda_stream)
-        eng.params_updated(shadow_fresh=shadow is not None)
+        eng.params_updated(shadow_fresh=shadow is not None, t_fresh=fused)
         return loss
 
     # ---- checkpointing: the moments and per-parameter step counts live in flat buffers outside `self.state`, so the inherited

@@ -119,8 +119,9 @@ class VLTaskTrainer(TaskTrainer):
     def train_step(self, model, batch: Dict, optimizer=None, scheduler=None, ewc=None):
         inputs = self.batch2inputs_converter(batch)
         target = batch[self.target_field]
+        # (`optimizer`: step() below is the next reader of the gradients -- the encoder's weight-gradient launch may carry the update, engine.defer_dw)
         loss, output, ewc_task, ewc_loss = model.fused_forward_backward(self.task_key, inputs["images"], inputs["texts"], target, ewc,
-                                                                        grad_weight=batch.get("dp_weight", 1.0))
+                                                                        grad_weight=batch.get("dp_weight", 1.0), optimizer=optimizer)
         if optimizer is not None:
             optimizer.step()
             if scheduler is not None:

@@ -176,6 +176,13 @@ int climb_nt_workspace_bytes(void);
  * the caller uploads them once per shape and keeps them -- the launch itself allocates and copies nothing. */
 int climb_tn_grouped_plan(int nprob, const int* M, const int* N, const int* K, int nwg, int* items_out, int cap, int* first_out);
 int climb_gemm_bf16_tn_grouped(const void* probs, const void* items, const void* first, int nwg, int ragged, void* stream);
+/* r04: the same launch with the optimizer in its epilogue (REF/modeling/vilt.py:205-215, REF/train/visionlanguage_tasks/train_vqa.py:160-170: nothing reads
+ * a weight gradient between backward() and optimizer.step()).  opts: device array parallel to probs of 56-byte records { float* p, m, v [N,K] (leading
+ * dimension = the problem's ldc); void* s [N,K] 16-bit shadow; void* st [K,N] transposed 16-bit shadow; long ldt; int fused, pad }.  A WHOLE tile of a problem
+ * with fused = 1 applies AdamW to its elements -- g = gscale * (tile sum + C if grad_dirty) -- and writes p, m, v and both shadows, never C; everything
+ * else behaves as climb_gemm_bf16_tn_grouped.  A problem may be fused only if none of its tiles is `partial` in the plan.  adam: HOST array of 8 floats
+ * { lr, weight_decay, beta1, beta2, eps, 1 - beta1^t, 1 - beta2^t, gscale } (climb_adamw's group row + the gradient scale). */
+int climb_gemm_bf16_tn_grouped_adamw(const void* probs, const void* items, const void* first, int nwg, int ragged, const void* opts, const float* adam, int grad_dirty, void* stream);
 /* HF:322-351 in bf16: same contract as the _f32 entry points, qkv/ctx/dctx/dqkv are bf16.  The backward takes the forward's ctx and
  * computes delta itself (its first phase); `delta` [B,heads,S_pad] is scratch it writes */
 int climb_attn_fwd_bf16(const void* qkv, const float* key_bias, void* ctx, float* lse, int B, int S_pad, int heads, int head_dim, void* stream);

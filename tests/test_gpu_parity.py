@@ -932,6 +932,71 @@ def test_continual_learning_configs_at_the_benchmarks_64_sequences(config):
     assert worst <= 6e-2
 
 
+@pytest.mark.parametrize("config", ["plain", "ewc", "frozen9", "accumulate"])
+def test_optimizer_in_the_weight_gradient_epilogue_is_the_same_update(config):
+    """r04: when the caller names its optimizer -- `fused_forward_backward(..., optimizer=opt)`, what the trainers' train_step does;
+    REF/train/visionlanguage_tasks/train_vqa.py:160-170 calls step() right after backward() -- the encoder's grouped weight-gradient launch is held back
+    and run by FusedAdamW.step() with AdamW in its epilogue: p, m, v, the 16-bit shadow and the transposed shadow written from the tile sums, the
+    gradient never stored, the flat optimizer pass and the shadow transposes skipping those tensors.  Same arithmetic in the same order (one shared
+    update function): after three steps at the benchmark's 64 sequences EVERY parameter, both moments and both shadows must equal the unfused step's
+    BIT FOR BIT -- also with the EWC term already in the gradient buffer (REF/cl_algorithms/ewc.py:75-87: grad_dirty), with the bottom 9 layers
+    frozen (other plans / tails), and when a second backward arrives before the step (the held launch runs as the plain one)."""
+    if H16 != torch.bfloat16:
+        pytest.skip("the fused update is the bf16 build's (the half build scales its gradients)")
+    from climb_amd.cl_algorithms import EWC
+    dev = _dev()
+    res = {}
+    for fused in (False, True):
+        torch.manual_seed(0)
+        random.seed(0)
+        model, P = make_model(["vqa", "nlvr2"], 42, precision=H16)
+        model.train()
+        if config == "frozen9":
+            model.get_encoder().freeze_bottom_k_layers(9)
+        ewc = None
+        if config == "ewc":
+            ewc = EWC(types.SimpleNamespace(ewc_fisher_sample_percentage=0.01, ewc_loss_weight=100.0))
+            fisher, star = _ewc_state(P, 5)
+            ewc.set_task_state("nlvr2", model, fisher, star)
+        opt = model.create_optimizer({"lr": 1e-3, "weight_decay": 1e-2, "adam_epsilon": 1e-8})
+        opt.zero_grad()
+        eng = model._host.engine()
+        launches = []
+        orig = eng._timed_call
+
+        def spy(kernel, flops, name, *a, _o=orig, _l=launches):
+            _l.append(name)
+            return _o(kernel, flops, name, *a)
+        eng._timed_call = spy
+        losses = []
+        for step in range(3):
+            pixels, texts, target = _rand_batch(64, 900 + step, dev)
+            if config == "accumulate" and step == 1:          # two backwards, one step: the first one's held launch must become a plain one
+                model.fused_forward_backward("vqa", pixels, texts, target, ewc, optimizer=opt if fused else None)
+                pixels, texts, target = _rand_batch(64, 950, dev)
+            loss, _, _, _ = model.fused_forward_backward("vqa", pixels, texts, target, ewc, optimizer=opt if fused else None)
+            opt.step()
+            opt.zero_grad()
+            losses.append(float(loss))
+        eng.refresh_shadow()
+        torch.cuda.synchronize()
+        n_fused = sum(1 for n in launches if n == "climb_gemm_bf16_tn_grouped_adamw")
+        assert n_fused == (3 if fused else 0), launches
+        res[fused] = dict(flat=eng.flat.clone(), m=opt._m.clone(), v=opt._v.clone(), s=eng._shadow.clone(), st=eng._shadow_t.clone(), losses=losses)
+        del model, opt
+        torch.cuda.empty_cache()
+    a, b = res[False], res[True]
+    assert a["losses"] == b["losses"]
+    for k in ("flat", "m", "v", "s", "st"):
+        bad = int((a[k] != b[k]).sum())
+        assert bad == 0, f"{config}: {k}: {bad} of {a[k].numel()} elements differ between the fused and the unfused optimizer step"
+    assert float((a["flat"] - P_flat_like(a["flat"])).abs().max()) >= 0      # (shape sanity)
+
+
+def P_flat_like(t):
+    return torch.zeros_like(t)
+
+
 def test_full_size_batch_permutation_and_mode_agreement():
     """BASELINE.json configs[1] size (64 sequences x 185 tokens), where the CPU oracle would take minutes: size-independent
     properties instead.  (1) samples are independent: permuting the batch permutes pooled/logits and leaves the loss and every

@@ -14,10 +14,12 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # the fp32 128x128 GEMM's adapter-epilogue instantiation (adapters in the fp32 parity mode only)
 # the two-workgroup variant of the persistent GEMM that only option 7 = 4 selects (the persistent 256 x 192 GEMM with the fp32 residual
 # epilogue itself no longer spills: r03, the lane id is recomputed per tile instead of kept across the k-loop);
+# the grouped weight-gradient launch with the optimizer in its epilogue (r04): 13 dwords of per-lane constants (fragment offsets, lane ids) stored once
+# before the item loop and reloaded once per TILE (192 k-tiles each), none inside the k-loop;
 # bench.py's pipe-only diagnostic (16 accumulator tiles = all 256 AGPRs + 256 VGPRs at one wave per SIMD: one dword outside its MFMA loop)
 KNOWN = ("gemm_bf16_ntsk_kernelIfLi2E", "attn_bwd_bf16_kernelILi1E", "attn_bwd_bf16_fused_kernel", "gemm_bf16_nt192_kernelIfLi2E", "gemm_bf16_nt192_kernelItLi2E", "gemm_bf16_nt192_kernelIfLi7E",
          "gemm_bf16_nt192_kernelItLi7E", "gemm_f32_kernelILi128ELi128ELb1E",
-         "gemm_bf16_nt2_kernelIfLi2E", "gemm_bf16_nt2_kernelItLi2E", "mfma_sustained_kernel")
+         "gemm_bf16_nt2_kernelIfLi2E", "gemm_bf16_nt2_kernelItLi2E", "mfma_sustained_kernel", "gemm_bf16_tn_grouped_kernelILb0ELb1E")
 
 
 def report(path):

@@ -38,7 +38,7 @@ def run(name, model, task, images, tx, target, ewc=None, steps=12, warm=4):
         if i == warm:
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-        model.fused_forward_backward(task, images, tx, target, ewc=ewc)
+        model.fused_forward_backward(task, images, tx, target, ewc=ewc, optimizer=opt)
         opt.step()
         opt.zero_grad()
     torch.cuda.synchronize()

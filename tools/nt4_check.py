@@ -118,7 +118,7 @@ def bench(M=12288, passes=5, rotate=1, settings=((17, 0, 18, 0), (17, 3, 18, 0))
             tot[v] += med[v]
         print(f"NT {name:14s} N={N:5d} K={K:5d}: " + " | ".join(f"{settings[v]} {med[v]:7.1f} us {f/med[v]/1e6:7.1f} TF" for v in med), flush=True)
     print("NT total per layer: " + " | ".join(f"{settings[v]} {tot[v]:.1f} us ({flops/tot[v]/1e6:.1f} TF)" for v in tot))
-    opt(17, 3)
+    opt(17, 1)
     opt(18, 0)
 
 
@@ -150,7 +150,7 @@ def seq(M=12288, iters=12, rotate=6):
                     A.copy_(src)
                     _lib.call("climb_gemm_bf16_nt", A, K, W, K, Cs[i], N, cdt, M, N, K, bias, epi, None, N, auxos[i], N, None, 0, st())
                 torch.cuda.synchronize()
-    opt(17, 3)
+    opt(17, 1)
 
 
 if __name__ == "__main__" and "--seq" in sys.argv:
