@@ -121,6 +121,20 @@ def append_task_result(results_file: str, task_num: int, task_key: str, best_sco
         with open(results_file) as f:
             results = json.load(f)
     results.append({"task_num": task_num, "task_key": task_key, "best_score": best_score, "best_epoch": best_epoch})
-    with open(results_file, "w") as f:
-        json.dump(results, f)
+    write_json_once(results_file, results)
     return results
+
+
+def write_json_once(path: str, obj) -> None:
+    """One writer per file under N ranks (identical content everywhere: the scores are all-reduced): rank 0 writes a temporary file and renames it over
+    `path`; nobody returns before it is there."""
+    from .. import parallel
+    from ..parallel import barrier, rank_world
+    rank, world = rank_world()
+    if rank == 0:
+        tmp = f"{path}.tmp.{os.getpid()}"
+        with open(tmp, "w") as f:
+            (parallel._real_json_dump or json.dump)(obj, f)          # (the driver-facing patch of json.dump is a collective: not from one rank)
+        os.replace(tmp, path)
+    if world > 1:
+        barrier()

@@ -150,6 +150,7 @@ __device__ __forceinline__ float dgelu_fast(float x) {
 //   p *= 1 - lr*wd;  m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;  p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
 struct AdamGroup { float lr, wd, beta1, beta2, eps, bc1, bc2, pad; };
 __device__ __forceinline__ void adamw_update(float& p, float& m, float& v, float g, const AdamGroup& G, float isb2, float step) {
+#pragma clang fp contract(off)      // no FMA contraction: the two kernels that inline this must round identically whatever surrounds the call
   p *= 1.f - G.lr * G.wd;
   m = G.beta1 * m + (1.f - G.beta1) * g;
   v = G.beta2 * v + (1.f - G.beta2) * g * g;

@@ -375,6 +375,19 @@ struct TnGroupOpt {          // 56 bytes, parallel to the problems; include/clim
 };
 struct TnAdam { AdamGroup g; float gscale; int grad_dirty; };
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
+// 4 x 4 transpose inside every quad of lanes: register i of lane b <-> register b of lane i (two exchange steps through DPP quad permutes)
+__device__ __forceinline__ float tn_dpp_quad(float x, bool hi) {
+  const int v = __builtin_bit_cast(int, x);
+  return __builtin_bit_cast(float, hi ? __builtin_amdgcn_mov_dpp(v, 0x4E, 0xf, 0xf, true) : __builtin_amdgcn_mov_dpp(v, 0xB1, 0xf, 0xf, true));
+}
+__device__ __forceinline__ void tn_quad_transpose(float (&r)[4], int lane) {
+  const bool o1 = lane & 1, o2 = lane & 2;
+  float t0 = tn_dpp_quad(o1 ? r[0] : r[1], false), t1 = tn_dpp_quad(o1 ? r[2] : r[3], false);
+  if (o1) { r[0] = t0; r[2] = t1; } else { r[1] = t0; r[3] = t1; }
+  t0 = tn_dpp_quad(o2 ? r[0] : r[2], true);
+  t1 = tn_dpp_quad(o2 ? r[1] : r[3], true);
+  if (o2) { r[0] = t0; r[1] = t1; } else { r[2] = t0; r[3] = t1; }
+}
 
 // RAGGED: N, K any multiples of 8 (the adapters' 768 x 48 / 48 x 768 gradients ride in the same launch as 256 x 256 tiles whose surplus
 // columns are computed on clamped addresses and never stored -- the FLOPs of those GEMMs are nothing, their launches and operand reads were).
@@ -482,8 +495,14 @@ __global__ __launch_bounds__(512) void gemm_bf16_tn_grouped_kernel(const TnGroup
       const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void*)O.p, 0, 0x7fffffff, 0x00020000), rm = __builtin_amdgcn_make_buffer_rsrc((void*)O.m, 0, 0x7fffffff, 0x00020000),
                                    rv = __builtin_amdgcn_make_buffer_rsrc((void*)O.v, 0, 0x7fffffff, 0x00020000), rg = __builtin_amdgcn_make_buffer_rsrc((void*)P.C, 0, 0x7fffffff, 0x00020000),
                                    rs = __builtin_amdgcn_make_buffer_rsrc((void*)O.s, 0, 0x7fffffff, 0x00020000), rt = __builtin_amdgcn_make_buffer_rsrc((void*)O.st, 0, 0x7fffffff, 0x00020000);
-      const unsigned le = (unsigned)((4 * half) * (int)ldc + l31);                                          // lane part of the [N,K] element index
-      const unsigned lt = (unsigned)(l31 * (int)O.ldt + 4 * half) * 2u;                                     // lane part of the [K,N] byte offset
+      // Memory shape.  In the accumulator layout a lane owns ONE k (l31) and four consecutive n per register group: 4-byte accesses, 7 per element --
+      // measured +0.41 ms on the launch (instruction-bound).  A 4 x 4 transpose inside every quad of lanes (two DPP exchange steps) turns a register
+      // group into one n (4 half + 8 q + l31 % 4) x four consecutive k (4 (l31 / 4) ..): p, m, v (and the gradient term) move as 16-byte accesses, 8 lanes
+      // a 128-byte row; the update runs in that layout, the 16-bit shadow is stored from it (8 bytes), and the new weights are transposed back for
+      // the [K,N] shadow (four consecutive n: 8 bytes).
+      const int b4 = l31 & 3, a8 = l31 >> 2;
+      const unsigned le = (unsigned)((4 * half + b4) * (int)ldc + 4 * a8);                                  // lane part of the [N,K] element index (transposed registers)
+      const unsigned lt = (unsigned)(l31 * (int)O.ldt + 4 * half) * 2u;                                     // lane part of the [K,N] byte offset (accumulator layout)
       const unsigned se0 = (unsigned)((n0 + wr * 64) * (int)ldc + k0 + wc * (32 * NI));                     // uniform parts
       const unsigned st0 = (unsigned)((k0 + wc * (32 * NI)) * (int)O.ldt + n0 + wr * 64) * 2u;
       const float isb2 = rsqrtf(ad.g.bc2), step = ad.g.lr / ad.g.bc1;
@@ -492,29 +511,38 @@ __global__ __launch_bounds__(512) void gemm_bf16_tn_grouped_kernel(const TnGroup
       for (int p = 0; p < NI; ++p)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {          // one 32 x 32 block: every load before the first store (a load behind a store drains the store queue)
-          float pv[16], mv[16], vv[16], gv[16];
+          f32x4 pv[4], mv[4], vv[4], gv[4];
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const unsigned so = (se0 + (unsigned)((j * 32 + (r & 3) + 8 * (r >> 2)) * (int)ldc + p * 32)) * 4u;
-            pv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rp, le * 4u, so, 0));
-            mv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rm, le * 4u, so, 0));
-            vv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rv, le * 4u, so, 0));
-            gv[r] = dirty ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rg, le * 4u, so, 0)) : 0.f;
+          for (int q = 0; q < 4; ++q) {
+            const unsigned so = (se0 + (unsigned)((j * 32 + 8 * q) * (int)ldc + p * 32)) * 4u;
+            pv[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rp, le * 4u, so, 0));
+            mv[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rm, le * 4u, so, 0));
+            vv[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rv, le * 4u, so, 0));
+            gv[q] = dirty ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rg, le * 4u, so, 0)) : (f32x4){0.f, 0.f, 0.f, 0.f};
           }
 #pragma unroll
-          for (int r = 0; r < 16; ++r) adamw_update(pv[r], mv[r], vv[r], (gv[r] + acc[p][j][r]) * ad.gscale, ad.g, isb2, step);
+          for (int q = 0; q < 4; ++q) {
+            float g4[4] = {acc[p][j][4 * q], acc[p][j][4 * q + 1], acc[p][j][4 * q + 2], acc[p][j][4 * q + 3]};
+            tn_quad_transpose(g4, l31);
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const unsigned so = (se0 + (unsigned)((j * 32 + (r & 3) + 8 * (r >> 2)) * (int)ldc + p * 32));
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pv[r]), rp, le * 4u, so * 4u, 0);
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, mv[r]), rm, le * 4u, so * 4u, 0);
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, vv[r]), rv, le * 4u, so * 4u, 0);
-            __builtin_amdgcn_raw_buffer_store_b16(f32_to_bf16(pv[r]), rs, le * 2u, so * 2u, 0);
+            for (int i = 0; i < 4; ++i) {
+              float pp = pv[q][i], mm = mv[q][i], v2 = vv[q][i];
+              adamw_update(pp, mm, v2, (gv[q][i] + g4[i]) * ad.gscale, ad.g, isb2, step);
+              pv[q][i] = pp; mv[q][i] = mm; vv[q][i] = v2;
+            }
           }
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {          // four consecutive n of one k: 8 bytes of the transposed shadow
-            u32x2_t w = {pack_bf16x2(pv[q * 4 + 0], pv[q * 4 + 1]), pack_bf16x2(pv[q * 4 + 2], pv[q * 4 + 3])};
-            __builtin_amdgcn_raw_buffer_store_b64(w, rt, lt, st0 + (unsigned)((p * 32) * (int)O.ldt + j * 32 + 8 * q) * 2u, 0);
+          for (int q = 0; q < 4; ++q) {
+            const unsigned so = se0 + (unsigned)((j * 32 + 8 * q) * (int)ldc + p * 32);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, pv[q]), rp, le * 4u, so * 4u, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, mv[q]), rm, le * 4u, so * 4u, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, vv[q]), rv, le * 4u, so * 4u, 0);
+            u32x2_t w = {pack_bf16x2(pv[q][0], pv[q][1]), pack_bf16x2(pv[q][2], pv[q][3])};
+            __builtin_amdgcn_raw_buffer_store_b64(w, rs, le * 2u, so * 2u, 0);
+            float t4[4] = {pv[q][0], pv[q][1], pv[q][2], pv[q][3]};
+            tn_quad_transpose(t4, l31);          // back: four consecutive n of this lane's k
+            u32x2_t wt = {pack_bf16x2(t4[0], t4[1]), pack_bf16x2(t4[2], t4[3])};
+            __builtin_amdgcn_raw_buffer_store_b64(wt, rt, lt, st0 + (unsigned)((p * 32) * (int)O.ldt + j * 32 + 8 * q) * 2u, 0);
           }
         }
     } else {

@@ -468,7 +468,7 @@ class ViltEngine:
             sub = self._t_sub.get(key)
             if sub is None:
                 import numpy as np
-                rows = [(self.layout.offset[name], self._t_off[name], N, K) for name, N, K in self._linear_weight_names() if name not in key]
+                rows = [(self.layout.offset[name], self._t_off[name], N, K) for name, N, K in self._linear_weight_names() if name not in key]      # (a fused QKV row is named by its query weight)
                 sub = self._t_sub[key] = (torch.from_numpy(np.array(rows, dtype=np.int64).reshape(-1, 4)).to(self.device), len(rows))
             table, tn = sub
         if tn:
@@ -751,6 +751,14 @@ class ViltEngine:
             self._grad_extra = True
         pending.clear()
 
+    def _covered(self, name: str, numel: int):
+        """layout tensors inside the flat range a weight-gradient problem writes (the fused QKV product covers query, key and value weights)"""
+        lo = self.layout.offset[name]
+        segs = getattr(self, "_segs", None)
+        if segs is None:
+            segs = self._segs = self.layout.segments()
+        return [n for n, start, length in segs if lo <= start < lo + numel]
+
     def fused_dw_adamw(self, opt_m: torch.Tensor, opt_v: torch.Tensor, eligible, adam_row) -> set:
         """The held-back weight-gradient launches with AdamW in their epilogue (csrc/gemm_bf16_tnp.hip).  `eligible(name) -> bool`: tensors the
         optimizer updates THIS step with the constants `adam_row` (8 floats: lr, wd, beta1, beta2, eps, 1 - beta1^t, 1 - beta2^t, gradient scale).
@@ -760,7 +768,8 @@ class ViltEngine:
         done = set()
         row = np.ascontiguousarray(adam_row, dtype=np.float32)
         for ws, plan in held:
-            flags = tuple(bool(w and eligible(n)) for n, w in zip(plan["names"], plan["whole"]))
+            cover = plan.setdefault("cover", [self._covered(n, N * K) for n, (N, K) in zip(plan["names"], plan["shapes"])])
+            flags = tuple(bool(w and n in self._t_off and all(eligible(c) for c in cv)) for n, w, cv in zip(plan["names"], plan["whole"], cover))
             key = (opt_m.data_ptr(), opt_v.data_ptr(), flags)
             opts = plan["opts"].get(key)
             if opts is None:
@@ -769,14 +778,16 @@ class ViltEngine:
                 for r, n, (N, K), f in zip(rec, plan["names"], plan["shapes"], flags):
                     o = self.layout.offset[n]
                     r["p"], r["m"], r["v"] = self.p(n), opt_m.data_ptr() + 4 * o, opt_v.data_ptr() + 4 * o
-                    r["s"], r["st"], r["ldt"], r["fused"] = self.sp(n), (self.spt(n) if n in self._t_off else 0), N, int(f and n in self._t_off)
+                    r["s"], r["st"], r["ldt"], r["fused"] = self.sp(n), (self.spt(n) if n in self._t_off else 0), N, int(f)
                 opts = torch.from_numpy(rec.view(np.uint8).copy()).to(self.device)
                 if len(plan["opts"]) >= 8:
                     plan["opts"].pop(next(iter(plan["opts"])))
                 plan["opts"][key] = opts
             self._timed_call("gemm_bf16_tn", plan["flops"], "climb_gemm_bf16_tn_grouped_adamw", plan["probs"], plan["items"], plan["first"], plan["nwg"], plan["ragged"],
                              opts, row.ctypes.data, 1 if self._grad_extra else 0, _stream())
-            done.update(n for n, f in zip(plan["names"], flags) if f and n in self._t_off)
+            for cv, f in zip(cover, flags):
+                if f:
+                    done.update(cv)
         return done
 
     def _red_flush(self, ws: Workspace, pending: list):

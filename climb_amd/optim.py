@@ -88,7 +88,7 @@ class FusedAdamW(torch.optim.Optimizer):
             # r04: weight-gradient launches held back for this step (the fused training step armed engine.defer_dw): run them with the update in
             # their epilogue for the tensors of the most common (group, step) combination; the flat pass below skips what was updated there
             idx = {n: i for i, n in enumerate(self._seg_names)}
-            names = [n for _, plan in eng._dw_deferred for n, w in zip(plan["names"], plan["whole"]) if w]
+            names = [n for _, plan in eng._dw_deferred for n, w in zip(plan["names"], plan["whole"]) if w]          # (a fused QKV problem is named by its query weight)
             slots = [int(seg_group[idx[n]]) for n in names]
             if shadow is not None and any(sl >= 0 for sl in slots):
                 slot0 = max(set(sl for sl in slots if sl >= 0), key=slots.count)

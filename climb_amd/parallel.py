@@ -131,7 +131,9 @@ class GradientAllReducer:
     def takes_scaled(self) -> bool:
         """True when ranges must reach on_ready() still multiplied by the engine's loss scale (half payload, more than one rank: with one
         rank nothing is cast and the engine unscales as usual)."""
-        return self.compress == "fp16" and self.world > 1
+        # (not while suspended(): the replicated Fisher pass reduces nothing, so nobody would divide the scale out again -- the engine must unscale
+        # those gradients itself before fisher_accumulate() squares them; ADVICE r3)
+        return self.enabled and self.compress == "fp16" and self.world > 1
 
     def begin(self):
         self._works.clear()
@@ -334,35 +336,72 @@ def init_data_parallel(backend: Optional[str] = None):
 
 _real_torch_save = None
 _real_makedirs = None
+_real_json_dump = None
+io_log = []          # (kind, path, wrote) per collective file operation of this process: what tests assert "one writer per file" on
 
 
 def rank0_only_io():
-    """Makes the reference driver's file IO safe for N processes running the same code.  It saves checkpoints with `torch.save` from its only
-    process (REF/train/train_upstream_continual_learning.py:261-267): under N ranks the replicas are bit-identical, so one copy is enough --
-    on ranks > 0 `torch.save` of a path becomes a no-op, and every rank leaves the call through a barrier so that a file exists for all
-    ranks once any of them has moved on.  It creates directories with `if not isdir: makedirs` (:118-119, :261-262), which two processes
-    race through: `os.makedirs` tolerates an existing directory.  (results.json / eval_results.json are written by every rank with
-    identical content; their readers in this package barrier first.)  Idempotent; `restore_io()` undoes it."""
-    global _real_torch_save, _real_makedirs
+    """Makes the reference driver's file IO safe for N processes running the same code (prefer the context manager `single_writer_io()`, which
+    also takes the patches away again).  The driver
+      * saves checkpoints with `torch.save` from its only process (REF/train/train_upstream_continual_learning.py:261-267): under N ranks the
+        replicas are bit-identical, so one copy is enough -- on ranks > 0 `torch.save` of a path is a no-op, and every rank leaves the call through a
+        barrier, so the file exists for all ranks once any of them has moved on.  (Consequence: while this is installed a path-based torch.save is a
+        COLLECTIVE -- a save only some ranks make would deadlock.)
+      * creates directories with `if not isdir: makedirs` (:118-119, :261-262), which two processes race through: `os.makedirs` tolerates an
+        existing directory;
+      * writes results.json / eval_results.json with `json.dump(obj, open(path, "w"))` from every rank (:269-277, :327) -- identical content, the same
+        path, concurrent writers: a torn file is possible.  `json.dump` into a file opened for writing becomes: barrier (every rank has opened -- and
+        truncated -- the path by now), rank 0 alone writes a temporary file next to it and `os.replace`s it over the path, barrier.  The handles the
+        other ranks hold point at the old inode; nothing they do can touch the new file.
+    Idempotent; `restore_io()` undoes it."""
+    global _real_torch_save, _real_makedirs, _real_json_dump
     rank, world = rank_world()
     if world == 1 or _real_torch_save is not None:
         return
-    _real_torch_save, _real_makedirs = torch.save, os.makedirs
+    import json
+    _real_torch_save, _real_makedirs, _real_json_dump = torch.save, os.makedirs, json.dump
 
     def makedirs(name, mode=0o777, exist_ok=False):
         return _real_makedirs(name, mode, exist_ok=True)
     os.makedirs = makedirs
 
     def save(obj, f, *a, **kw):
-        if rank == 0 or not isinstance(f, (str, os.PathLike)):
+        is_path = isinstance(f, (str, os.PathLike))
+        if rank == 0 or not is_path:
             _real_torch_save(obj, f, *a, **kw)
-        if isinstance(f, (str, os.PathLike)):
+        if is_path:
+            io_log.append(("torch.save", os.fspath(f), rank == 0))
             dist.barrier()
     torch.save = save
 
+    def dump(obj, fp, *a, **kw):
+        path = getattr(fp, "name", None)
+        if not (isinstance(path, str) and "w" in getattr(fp, "mode", "") and os.path.isfile(path)):
+            return _real_json_dump(obj, fp, *a, **kw)          # not a file on disk opened for writing: nobody else's business
+        dist.barrier()                                          # every rank is past its open(path, "w")
+        if rank == 0:
+            tmp = f"{path}.tmp.{os.getpid()}"
+            with open(tmp, "w") as t:
+                _real_json_dump(obj, t, *a, **kw)
+            os.replace(tmp, path)
+        io_log.append(("json.dump", path, rank == 0))
+        dist.barrier()
+    json.dump = dump
+
 
 def restore_io():
-    global _real_torch_save, _real_makedirs
+    global _real_torch_save, _real_makedirs, _real_json_dump
     if _real_torch_save is not None:
-        torch.save, os.makedirs = _real_torch_save, _real_makedirs
-        _real_torch_save = _real_makedirs = None
+        import json
+        torch.save, os.makedirs, json.dump = _real_torch_save, _real_makedirs, _real_json_dump
+        _real_torch_save = _real_makedirs = _real_json_dump = None
+
+
+@contextlib.contextmanager
+def single_writer_io():
+    """`with parallel.single_writer_io(): run the driver` -- the patches of rank0_only_io() exist for the duration of the driver call only."""
+    rank0_only_io()
+    try:
+        yield
+    finally:
+        restore_io()

@@ -8,7 +8,8 @@
 
 What this adds around the driver (REF/train/train_upstream_continual_learning.py has no distributed code):
   * binds the process to GPU LOCAL_RANK (the driver's `torch.device("cuda")`, :39-40, then means that GPU) and joins the RCCL job;
-  * checkpoints are written by rank 0 only (`climb_amd.parallel.rank0_only_io`); ranks > 0 log warnings only.
+  * checkpoints AND results files are written by rank 0 only, the latter through a temporary file + os.replace (`climb_amd.parallel.single_writer_io`,
+    a context manager held around the driver call); ranks > 0 log warnings only.
 Everything else happens inside the package the driver already calls: the trainers build rank-sharded loaders (`--batch_size` stays the
 GLOBAL batch, so lr / warm-up / steps per epoch are the single-GPU run's), attach the gradient all-reducer in `train()`, all-reduce the
 validation score in `eval()`; EWC's Fisher pass runs replicated and is broadcast from rank 0; the replay memory draws the same indices on
@@ -25,7 +26,6 @@ def main():
         raise SystemExit("usage: climb_torchrun.py <driver.py> [driver arguments ...]")
     from climb_amd import parallel
     rank, world, device = parallel.init_data_parallel(os.environ.get("CLIMB_AMD_DP_BACKEND"))
-    parallel.rank0_only_io()
     if rank != 0:
         logging.getLogger().setLevel(logging.WARNING)
     driver = sys.argv[1]
@@ -33,7 +33,8 @@ def main():
     # NOT from <CLiMB>/src as the working directory: the driver puts '.' first on sys.path (:19) and the reference's own `modeling` /
     # `cl_algorithms` packages there would shadow the shim
     try:
-        runpy.run_path(driver, run_name="__main__")
+        with parallel.single_writer_io():          # torch.save / os.makedirs / json.dump-to-file are N-process-safe for the driver call, and only for it
+            runpy.run_path(driver, run_name="__main__")
     finally:
         import torch.distributed as dist
         if dist.is_initialized():

@@ -72,6 +72,10 @@ def main():
         runpy.run_path(sys.argv[0], run_name="__main__")
         report["calls"] = [dict(c) for c in calls]
         driver_trace.uninstall()
+        # the launcher held the IO patches for the driver call only (parallel.single_writer_io); what it logged: one writer per file
+        import json as _json
+        report["patches_gone"] = bool(parallel._real_torch_save is None and _json.dump.__module__ == "json")
+        report["io_log"] = [list(x) for x in parallel.io_log]
         run_dirs = [d for d in os.listdir(a.out) if "singletask" not in d]
         report["results"] = json.load(open(os.path.join(a.out, run_dirs[0], "results.json")))
         json.dump(report, open(a.report, "w"))
@@ -102,6 +106,7 @@ def main():
     if a.abi == "hip":
         torch.cuda.synchronize()
     ewc, mem = out.get("ewc"), out.get("replay_memory")
+    report["io_log"] = [list(x) for x in parallel.io_log]
     parallel.restore_io()              # the report files below are written by rank 0 alone, outside the collective save protocol
     if ewc is not None:
         report["fisher"] = {k: checksum(v) for k, v in ewc.fisher_flat.items()}

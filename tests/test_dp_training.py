@@ -182,6 +182,10 @@ def test_two_rank_driver_run_matches_the_single_process_run(name, dp_tree, tmp_p
     for rep in rep2:
         assert rep["calls"] == golden["calls"]
         assert rep["reducer_attached"] and rep["replicas_in_sync"] and rep["collectives"] > 0 and rep["bytes_reduced"] > 0
+        # ONE writer per file -- checkpoints and results files alike (rank 0, the json files through a temporary + os.replace)
+        assert rep["io_log"] and all(wrote == (rep["rank"] == 0) for _, _, wrote in rep["io_log"])
+        assert any(kind == "json.dump" and path.endswith("results.json") for kind, path, _ in rep["io_log"])
+        assert any(kind == "torch.save" for kind, path, _ in rep["io_log"])
         assert rep["results"] == rep2[0]["results"] and rep["eval_results"] == rep2[0]["eval_results"]       # every rank: bit-identical
     assert _files(run2) == golden["files"]
     assert json.load(open(os.path.join(run2, "results.json"))) == rep2[0]["results"]
@@ -206,5 +210,10 @@ def test_the_unchanged_reference_driver_runs_data_parallel_through_the_torchrun_
     golden = json.load(open(os.path.join(golden_dir, "driver_calls.json")))["scenarios"]["ewc"]
     for rep in rep2:
         assert rep["calls"] == golden["calls"]
+        # the launcher's IO patches (torch.save / os.makedirs / json.dump-to-file) lived for the driver call only, and every file had ONE writer: the
+        # REFERENCE's own `json.dump(results, open(results_file, 'w'))` (REF/train/train_upstream_continual_learning.py:277) ran on both ranks
+        assert rep["patches_gone"]
+        assert all(wrote == (rep["rank"] == 0) for _, _, wrote in rep["io_log"])
+        assert any(kind == "json.dump" and path.endswith("results.json") for kind, path, _ in rep["io_log"])
     assert rep2[0]["results"] == rep2[1]["results"] and [r["task_key"] for r in rep2[0]["results"]] == sc.FOUR
     assert _files(os.path.join(out2, golden["experiment_dir"])) == golden["files"]

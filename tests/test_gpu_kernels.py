@@ -273,6 +273,90 @@ def test_gemm_bf16_tn_grouped_launch(nwg, ragged):
         assert _rel(a, b) < 1e-5
 
 
+@pytest.mark.parametrize("dirty", [False, True])
+def test_gemm_bf16_tn_grouped_with_adamw_in_the_epilogue_equals_launch_then_flat_adamw(dirty):
+    """r04: climb_gemm_bf16_tn_grouped_adamw applies AdamW in the epilogue of every WHOLE tile of a problem marked `fused` (p, m, v, the 16-bit shadow
+    and the transposed shadow written from the tile sum; the gradient never stored), everything else as climb_gemm_bf16_tn_grouped.  Against
+    { climb_gemm_bf16_tn_grouped ; climb_adamw ; climb_transpose_bf16 } on the same operands: the update function is shared and the tile sums are the
+    same sums, so every output of a fused problem must be BIT-IDENTICAL.  Problems: 2 x [768,3072] + [2304,768] + 2 x [768,768] + [256,512] = 119
+    tiles on 64 workgroups: one whole round and a stream-K tail; the problems the tail touches are NOT fused (their gradients land in C as before).
+    dirty: the gradient buffer already holds a term (the EWC penalty's, REF/cl_algorithms/ewc.py:75-87) that the fused update must add."""
+    from climb_amd import _lib
+    if _lib.torch_h16() != torch.bfloat16:
+        pytest.skip("bf16 build only")
+    dev = _dev()
+    M, nwg = 1024, 64
+    shapes = [(768, 3072), (768, 3072), (2304, 768), (768, 768), (768, 768), (256, 512)]
+    g = torch.Generator(device=dev).manual_seed(11)
+    total = sum(n * k for n, k in shapes)
+    offs = np.cumsum([0] + [n * k for n, k in shapes])
+    mk = lambda scale=1.0: torch.randn(total, device=dev, generator=g) * scale
+    P0, M0, V0 = mk(0.05), mk(0.01), (mk(0.01)).abs()
+    G0 = mk(0.02) if dirty else torch.zeros(total, device=dev)
+    dYs = [torch.randn(M, n, device=dev, generator=g).to(torch.bfloat16) for n, k in shapes]
+    Xs = [torch.randn(M, k, device=dev, generator=g).to(torch.bfloat16) for n, k in shapes]
+    Ms, Ns, Ks = (np.array(v, dtype=np.int32) for v in ([M] * len(shapes), [n for n, _ in shapes], [k for _, k in shapes]))
+    cap = int(sum((n // 256) * (k // 256) for n, k in shapes)) + nwg + 1
+    items, first = np.zeros((cap, 8), dtype=np.int32), np.zeros(nwg + 1, dtype=np.int32)
+    n_items = _lib.load().climb_tn_grouped_plan(len(shapes), Ms.ctypes.data, Ns.ctypes.data, Ks.ctypes.data, nwg, items.ctypes.data, cap, first.ctypes.data)
+    assert n_items > 0
+    partial_probs = set(int(x) for x in items[:n_items][items[:n_items, 5] == 1, 0])
+    assert partial_probs and len(partial_probs) < len(shapes)
+    fused = [i not in partial_probs for i in range(len(shapes))]
+    adam = np.array([1e-3, 1e-2, 0.9, 0.98, 1e-8, 1 - 0.9 ** 3, 1 - 0.98 ** 3, 1.0], dtype=np.float32)
+
+    def run(use_fused):
+        P, Mm, Vv, G = P0.clone(), M0.clone(), V0.clone(), G0.clone()
+        S = P.to(torch.bfloat16)
+        ST = torch.zeros(total, device=dev, dtype=torch.bfloat16)
+        rec = np.zeros(len(shapes), dtype=[("A", "<u8"), ("B", "<u8"), ("C", "<u8"), ("dbias", "<u8"), ("lda", "<i8"), ("ldb", "<i8"), ("ldc", "<i8"),
+                                           ("M", "<i4"), ("N", "<i4"), ("K", "<i4"), ("reserved", "<i4")])
+        opt = np.zeros(len(shapes), dtype=[("p", "<u8"), ("m", "<u8"), ("v", "<u8"), ("s", "<u8"), ("st", "<u8"), ("ldt", "<i8"), ("fused", "<i4"), ("pad", "<i4")])
+        for i, (n, k) in enumerate(shapes):
+            o = int(offs[i])
+            rec[i]["A"], rec[i]["B"], rec[i]["C"] = dYs[i].data_ptr(), Xs[i].data_ptr(), G.data_ptr() + 4 * o
+            rec[i]["lda"], rec[i]["ldb"], rec[i]["ldc"], rec[i]["M"], rec[i]["N"], rec[i]["K"] = n, k, k, M, n, k
+            opt[i]["p"], opt[i]["m"], opt[i]["v"] = P.data_ptr() + 4 * o, Mm.data_ptr() + 4 * o, Vv.data_ptr() + 4 * o
+            opt[i]["s"], opt[i]["st"], opt[i]["ldt"], opt[i]["fused"] = S.data_ptr() + 2 * o, ST.data_ptr() + 2 * o, n, int(fused[i])
+        d_rec = torch.from_numpy(rec.view(np.uint8).copy()).to(dev)
+        d_opt = torch.from_numpy(opt.view(np.uint8).copy()).to(dev)
+        d_items, d_first = torch.from_numpy(items[:n_items].copy()).to(dev), torch.from_numpy(first).to(dev)
+        starts = torch.from_numpy(np.asarray(offs, dtype=np.int64)).to(dev)
+        if use_fused:
+            _lib.call("climb_gemm_bf16_tn_grouped_adamw", d_rec, d_items, d_first, nwg, 0, d_opt, adam.ctypes.data, 1 if dirty else 0, _st())
+            groups = torch.tensor([-1 if f else 0 for f in fused], dtype=torch.int8, device=dev)
+        else:
+            _lib.call("climb_gemm_bf16_tn_grouped", d_rec, d_items, d_first, nwg, 0, _st())
+            groups = torch.zeros(len(shapes), dtype=torch.int8, device=dev)
+        table = adam.copy().reshape(1, 8)
+        table[0, 7] = 0.0
+        _lib.call("climb_adamw", P, G, Mm, Vv, S, total, starts, groups, len(shapes), table.ctypes.data, 1, 1.0, _st())
+        for i, (n, k) in enumerate(shapes):
+            if not (use_fused and fused[i]):
+                o = int(offs[i])
+                _lib.call("climb_transpose_bf16", S[o:o + n * k], ST[o:o + n * k], n, k, _st())
+        torch.cuda.synchronize()
+        return P, Mm, Vv, S, ST, G
+    ref, got = run(False), run(True)
+    for name, a, b in zip(("p", "m", "v", "shadow", "transposed shadow"), ref, got):
+        for i, (n, k) in enumerate(shapes):
+            if fused[i]:
+                o = int(offs[i])
+                bad = int((a[o:o + n * k] != b[o:o + n * k]).sum())
+                assert bad == 0, f"{name} of fused problem {i} {shapes[i]}: {bad} elements differ, max |d| {float((a[o:o + n * k].float() - b[o:o + n * k].float()).abs().max()):.3e} (max |ref| {float(a[o:o + n * k].float().abs().max()):.3e})"
+    # the update is really AdamW of the true gradient (float64 spot check of one fused problem), and its gradient range was never written
+    i = fused.index(True)
+    n, k = shapes[i]
+    o = int(offs[i])
+    gt = dYs[i].double().t() @ Xs[i].double() + G0[o:o + n * k].view(n, k).double()
+    lr, wd, b1, b2, eps, bc1, bc2, _ = [float(x) for x in adam]
+    mm = b1 * M0[o:o + n * k].view(n, k).double() + (1 - b1) * gt
+    vv = b2 * V0[o:o + n * k].view(n, k).double() + (1 - b2) * gt * gt
+    pp = P0[o:o + n * k].view(n, k).double() * (1 - lr * wd) - (lr / bc1) * mm / (vv.sqrt() / math.sqrt(bc2) + eps)
+    assert _rel(got[0][o:o + n * k].view(n, k), pp) < 1e-5 and _rel(got[1][o:o + n * k].view(n, k), mm) < 1e-4
+    assert torch.equal(got[5][o:o + n * k], G0[o:o + n * k])
+
+
 @pytest.mark.parametrize("S_pad,valid", [(64, 50), (192, 185), (224, 200), (288, 281)])
 def test_attention_f32_fwd_bwd(S_pad, valid):
     from climb_amd import _lib
