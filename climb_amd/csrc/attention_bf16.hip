@@ -621,7 +621,227 @@ __global__ __launch_bounds__(576) void attn_bwd_bf16_fused_kernel(const bf16_t* 
   __syncthreads();          // every wave is done with the K / V images and has left its rows' delta in LDS
   attn_bwd_body<1, true>(smem, qkv, key_bias, dctx, ctx, lse, delta, dqkv, S_pad, heads, scale);
 }
-static int g_attn_bwd_fused = 1;     // measurement knob (climb_set_option 13): 0 = the two launches
+// ------------------------------------------------------------------------------------------------------ backward, SINGLE PASS (r04)
+// S, dP, P and dS of a (key block, query block) pair are computed ONCE and feed all three products: 20 MFMAs and 16 exponentials per lane
+// and pair against 28 / 32 in the two phases above, and every operand is read from HBM once (151 MB per layer at B = 64, S_pad = 192: the
+// algorithmic figure).  One workgroup per (batch, head), one wave per KEY block j (NB <= 6 waves): the wave keeps K_j / V_j rows and the
+// K_j^T fragments in registers and owns dK_j^T, dV_j^T (64 accumulators); Q and dO are LDS images (X | Y halves of a block, as above).
+//   * dQ needs dS with the KEY index inside a lane (dQ^T[d][q] = sum_key K^T[d][key] dS^T[key][q]), but the wave holds dS[q][key] with the key
+//     on its lanes: the 32 x 32 block is turned through a 2 KB per-wave LDS tile (4 ds_write_b64, 4 ds_read_b64_tr_b16) -- not recomputed.
+//   * dQ_i sums over ALL key blocks, i.e. over all waves: the accumulators of the NB query blocks live in LDS (fp32, raw register layout, 8 KB
+//     each) and the waves walk the query blocks ROTATED -- in step t wave j works on query block (j + t) mod NB -- so no two waves touch the same
+//     block in a step: read 32 registers, 4 MFMAs on top, write them back; one s_barrier per step.  (Step 0 writes without reading.)
+//   * step 0 needs nothing from another wave (wave j brings in Q_j / dO_j itself and computes delta_j from the O_j / dO_j rows it loads), so
+//     there is no barrier and no cross-wave wait before the first MFMA.
+// LDS: NB x (8 KB images + 8 KB dQ + 2 KB turn) + lse / delta vectors = 110 KB at S_pad = 192: one workgroup per CU, which is why this
+// kernel takes S_pad <= 192 only; longer sequences stay on the two-phase kernel above.  ~210 VGPRs at 1.5 waves per SIMD.
+// The arithmetic is phase 1's (lanes = keys: the key bias is the lane's own term, -lse[query] / scale and delta[query] are the accumulators'
+// initial values, V rows sign-flipped so that dS comes out negated); dQ takes the same negated dS, hence its -scale at the store.
+#define AB1_TURN 2048
+__global__ __launch_bounds__(384) void attn_bwd_bf16_1p_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ key_bias,
+                                                               const bf16_t* __restrict__ dctx, const bf16_t* __restrict__ ctx,
+                                                               const float* __restrict__ lse, bf16_t* __restrict__ dqkv, int S_pad, int heads, float scale) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int NB = S_pad / 32;
+  unsigned char* dqs = smem + NB * AB_BLK;                        // fp32 dQ^T accumulators, raw: float4 (dd * 4 + g) of lane l at ((dd * 4 + g) * 64 + l) * 16
+  unsigned char* tsc = dqs + NB * AB_BLK;                         // per-wave turn tiles
+  float* lse_s = reinterpret_cast<float*>(tsc + NB * AB1_TURN);
+  float* delta_s = lse_s + AB_VEC(S_pad);
+  const int H = heads * AB_D, ld = 3 * H;
+  const int b = blockIdx.x / heads, h = blockIdx.x % heads;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), half = lane >> 5, l31 = lane & 31;
+  const bf16_t* Qg = qkv + (long)b * S_pad * ld + h * AB_D;
+  const bf16_t* Kg = Qg + H;
+  const bf16_t* Vg = Qg + 2 * H;
+  const bf16_t* dOg = dctx + (long)b * S_pad * H + h * AB_D;
+  const bf16_t* Og = ctx + (long)b * S_pad * H + h * AB_D;
+  const long rowv = ((long)b * heads + h) * S_pad;
+  const int my = w * 32 + l31;                                    // this lane's key; also the query row whose delta it computes
+  bf16x8 f1[4], f2[4];
+  float my_c;                                                     // this lane's key bias
+  {
+    bf16x8 fo[4], fd[4];
+    load_rows(f1, Kg, ld, w * 32, lane);
+    load_rows(f2, Vg, ld, w * 32, lane);
+    load_rows(fo, Og, H, w * 32, lane);
+    load_rows(fd, dOg, H, w * 32, lane);
+    my_c = key_bias[(long)b * S_pad + my];
+    float my_lse = lse[rowv + my];
+    __builtin_amdgcn_sched_barrier(0);
+    // this wave's own Q / dO block: 4 units of 8 rows each, X (Q) and Y (dO) back to back
+    {
+      const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)Qg, 0, 0x7fffffff, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)dOg, 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int slot = (4 * w + u) * 64 + lane, row = slot >> 3, c = (slot & 7) ^ aswz(row);
+        unsigned char* dst = smem + w * AB_BLK + u * 1024;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (lds_void_t*)dst, 16, row * (ld * 2) + c * 16, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, (lds_void_t*)(dst + AB_Y), 16, row * (H * 2) + c * 16, 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    ab_wait_vm<0>();
+    use_rows(f1); use_rows(f2); use_rows(fo); use_rows(fd);
+    asm volatile("" : "+v"(my_c), "+v"(my_lse));
+    float dsum = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dsum += (float)fo[ks][e] * (float)fd[ks][e];
+    const float my_delta = pair_sum(dsum);
+    if (half == 0) { delta_s[my] = my_delta; lse_s[my] = my_lse; }
+  }
+  // K_j^T fragments: the K rows go through LDS once (a 4 KB row image in this wave's own dQ block, which step 0 overwrites) and come back transposed
+  bf16x8 kT[2][2];
+  {
+    unsigned char* ksc = dqs + w * AB_BLK;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      union { bf16x8 b; u32x4 u; } c;
+      c.b = f1[ks];
+      *reinterpret_cast<u32x4*>(ksc + l31 * 128 + (((2 * ks + half) ^ aswz(l31)) << 4)) = c.u;
+    }
+    const ColAddr ka = col_addr(ksc, lane);
+    col_frags4<0>(kT, ka, 0);
+  }
+  negate_rows(f2);
+  const ColAddr xa = col_addr(smem, lane);
+  // turn tile [32 keys][32 queries] bf16, 64-byte rows, 16-byte chunks XOR (row >> 2) & 3
+  const unsigned tbase = (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char*)(tsc + w * AB1_TURN);
+  unsigned tw[4], ta, tb;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) tw[g] = tbase + l31 * 64 + ((g ^ ((l31 >> 2) & 3)) << 4) + 8 * half;
+  {
+    const int g16 = lane >> 4, i = lane & 15;
+    const int rowa = 4 * (g16 >> 1) + (i >> 2), rowb = rowa + 8, col = (g16 & 1) * 16 + 4 * (i & 3);
+    ta = tbase + rowa * 64 + (((col >> 3) ^ ((rowa >> 2) & 3)) << 4) + (col & 7) * 2;
+    tb = tbase + rowb * 64 + (((col >> 3) ^ ((rowb >> 2) & 3)) << 4) + (col & 7) * 2;
+  }
+  const float c1 = scale * AB_LOG2E, is = -1.0f / scale, k2 = fmaxf(my_c, AB_NEG) * AB_LOG2E;
+  f32x16 accK[2], accV[2];
+#pragma unroll
+  for (int d = 0; d < 2; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accK[d][r] = accV[d][r] = 0.f;
+  // transposed 8-byte reads the compiler schedules and counts itself (nothing is in flight on the DMA path after the prologue)
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4_t;
+#define AB1_TR(addr) __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(size_t)(addr))
+  // S and dP of step t + 1 are computed INSIDE step t (the images never change): with 1.5 waves per SIMD there is no other wave to cover the
+  // LDS round trips and the exponentials of a pair, so the pair's own next products are what the matrix pipe runs meanwhile
+  f32x16 s, dp;
+#define AB1_SDP(IB)                                                                                                                    \
+  {                                                                                                                                    \
+    const f32x4* ap = reinterpret_cast<const f32x4*>(lse_s + (IB) * 32 + 4 * half);                                                    \
+    const f32x4* dl = reinterpret_cast<const f32x4*>(delta_s + (IB) * 32 + 4 * half);                                                  \
+    _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                                                    \
+      const f32x4 v = ap[2 * g], dd = dl[2 * g];                                                                                       \
+      s[4 * g] = v.x * is; s[4 * g + 1] = v.y * is; s[4 * g + 2] = v.z * is; s[4 * g + 3] = v.w * is;                                  \
+      dp[4 * g] = dd.x; dp[4 * g + 1] = dd.y; dp[4 * g + 2] = dd.z; dp[4 * g + 3] = dd.w;                                              \
+    }                                                                                                                                  \
+    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                                                 \
+      s = CLIMB_MFMA_H16(row_frag(smem + (IB) * AB_BLK, ks, lane), f1[ks], s, 0, 0, 0);                                                \
+      dp = CLIMB_MFMA_H16(row_frag(smem + (IB) * AB_BLK + AB_Y, ks, lane), f2[ks], dp, 0, 0, 0);                                       \
+    }                                                                                                                                  \
+  }
+  AB1_SDP(w)                      // step 0 works on this wave's own block: nothing of another wave is needed yet
+  __syncthreads();                // every wave's Q / dO block, lse and delta are in LDS
+  for (int t = 0; t < NB; ++t) {
+    int ib = w + t;
+    ib = ib >= NB ? ib - NB : ib;
+    int ibn = ib + 1;
+    ibn = ibn >= NB ? 0 : ibn;
+    f32x4* dqp = reinterpret_cast<f32x4*>(dqs + ib * AB_BLK) + lane;
+    unsigned int pk[8], dsk[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const f32x2 e = f32x2{s[2 * i], s[2 * i + 1]} * c1 + k2;
+      const f32x2 pe = {__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y)};
+      const f32x2 d = f32x2{dp[2 * i], dp[2 * i + 1]} * pe;
+      pk[i] = pack_bf16x2(pe.x, pe.y);
+      dsk[i] = pack_bf16x2(d.x, d.y);
+    }
+    // dS[q][key = lane] into the turn tile: registers 4 g .. 4 g + 3 are queries 8 g + 4 half .. + 3 of row `key`
+#pragma unroll
+    for (int g = 0; g < 4; ++g) *reinterpret_cast<u32x2*>(tsc + w * AB1_TURN + (tw[g] - tbase)) = u32x2{dsk[2 * g], dsk[2 * g + 1]};
+    // the column fragments of Q_i (X half) and dO_i (Y half): f[st][dd]
+    bf16x8 xq[2][2], xo[2][2];
+    {
+      const unsigned o = ib * AB_BLK;
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {
+        union { s16x4 hh[2]; bf16x8 bb; } u;
+        u.hh[0] = AB1_TR(xa.a0 + o + st * 2048); u.hh[1] = AB1_TR(xa.b0 + o + st * 2048); xq[st][0] = u.bb;
+        u.hh[0] = AB1_TR(xa.a32 + o + st * 2048); u.hh[1] = AB1_TR(xa.b32 + o + st * 2048); xq[st][1] = u.bb;
+        u.hh[0] = AB1_TR(xa.a0 + o + AB_Y + st * 2048); u.hh[1] = AB1_TR(xa.b0 + o + AB_Y + st * 2048); xo[st][0] = u.bb;
+        u.hh[0] = AB1_TR(xa.a32 + o + AB_Y + st * 2048); u.hh[1] = AB1_TR(xa.b32 + o + AB_Y + st * 2048); xo[st][1] = u.bb;
+      }
+    }
+    // dS^T fragments (lane = query, 8 keys per k-step) back from the turn tile
+    bf16x8 dst[2];
+    {
+      union { s16x4 hh[2]; bf16x8 bb; } u;
+      u.hh[0] = AB1_TR(ta); u.hh[1] = AB1_TR(tb); dst[0] = u.bb;
+      u.hh[0] = AB1_TR(ta + 1024); u.hh[1] = AB1_TR(tb + 1024); dst[1] = u.bb;
+    }
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+      accK[0] = CLIMB_MFMA_H16(xq[st][0], packed4(dsk, st), accK[0], 0, 0, 0);
+      accK[1] = CLIMB_MFMA_H16(xq[st][1], packed4(dsk, st), accK[1], 0, 0, 0);
+      accV[0] = CLIMB_MFMA_H16(xo[st][0], packed4(pk, st), accV[0], 0, 0, 0);
+      accV[1] = CLIMB_MFMA_H16(xo[st][1], packed4(pk, st), accV[1], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);          // (register budget: the dQ accumulators come in only now, when xq / xo / pk / dsk are dead)
+    f32x16 dq[2];
+    if (t > 0) {
+#pragma unroll
+      for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 v = dqp[(d * 4 + g) * 64];
+          dq[d][4 * g] = v.x; dq[d][4 * g + 1] = v.y; dq[d][4 * g + 2] = v.z; dq[d][4 * g + 3] = v.w;
+        }
+    } else {
+#pragma unroll
+      for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dq[d][r] = 0.f;
+    }
+    if (t + 1 < NB) AB1_SDP(ibn)                // next step's S / dP: covers the round trip of the dQ accumulators
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+      dq[0] = CLIMB_MFMA_H16(kT[st][0], dst[st], dq[0], 0, 0, 0);
+      dq[1] = CLIMB_MFMA_H16(kT[st][1], dst[st], dq[1], 0, 0, 0);
+    }
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) dqp[(d * 4 + g) * 64] = f32x4{dq[d][4 * g], dq[d][4 * g + 1], dq[d][4 * g + 2], dq[d][4 * g + 3]};
+    __syncthreads();
+  }
+#undef AB1_SDP
+#undef AB1_TR
+  // every key block has added its share to every dQ block: this wave stores query block w, and its own dK / dV
+  f32x16 dq[2];
+  {
+    const f32x4* dqp = reinterpret_cast<const f32x4*>(dqs + w * AB_BLK) + lane;
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 v = dqp[(d * 4 + g) * 64];
+        dq[d][4 * g] = v.x; dq[d][4 * g + 1] = v.y; dq[d][4 * g + 2] = v.z; dq[d][4 * g + 3] = v.w;
+      }
+  }
+  bf16_t* orow = dqkv + ((long)b * S_pad + my) * ld + h * AB_D;
+  store_acc(orow, dq, half, -scale);
+  store_acc(orow + H, accK, half, -scale);
+  store_acc(orow + 2 * H, accV, half, 1.0f);
+}
+
+static int g_attn_bwd_fused = 2;     // climb_set_option 13: 0 = the two launches, 1 = both phases in one launch, 2 (default) = single pass where two workgroups fit a CU (S_pad <= 128),
+                                     // both phases in one launch above that, 3 = single pass wherever it runs (S_pad <= 192)
 void climb_attn_set_bwd_fused(int v) { g_attn_bwd_fused = v; }
 
 extern "C" int climb_attn_bwd_bf16(const void* qkv, const float* key_bias, const void* dctx, const void* ctx, const float* lse, float* delta,
@@ -642,6 +862,20 @@ extern "C" int climb_attn_bwd_bf16(const void* qkv, const float* key_bias, const
   // two outer blocks per wave: 64 nw >= S_pad threads (one element of the LDS vectors each) and 4 NB units over nw waves is at most 8 rounds;
   // measured at S_pad = 192: 3 waves 63 us, 6 waves 78 us per layer (register pressure: 3 workgroups x 3 waves fill the 168-VGPR budget)
   const int nthreads = 64 * ((S_pad / 32 + 1) / 2);
+  if ((g_attn_bwd_fused == 2 && S_pad <= 128) || (g_attn_bwd_fused == 3 && S_pad <= 192)) {
+    const int NB = S_pad / 32;
+    const size_t lds1 = (size_t)NB * (2 * AB_BLK + AB1_TURN) + (size_t)AB_VEC(S_pad) * 8;
+    static size_t lds1_set = 0;
+    if (lds1 > lds1_set) {
+      hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_bf16_1p_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+      if (e != hipSuccess) return (int)e;
+      lds1_set = lds1;
+    }
+    hipLaunchKernelGGL(attn_bwd_bf16_1p_kernel, dim3(B * heads), dim3(64 * NB), lds1, (hipStream_t)stream, (const bf16_t*)qkv, key_bias,
+                       (const bf16_t*)dctx, (const bf16_t*)ctx, lse, (bf16_t*)dqkv, S_pad, heads, scale);
+    LAUNCH_CHECK();
+    return CLIMB_OK;
+  }
   if (g_attn_bwd_fused) {
     hipLaunchKernelGGL(attn_bwd_bf16_fused_kernel, dim3(B * heads), dim3(nthreads), lds, (hipStream_t)stream, (const bf16_t*)qkv, key_bias,
                        (const bf16_t*)dctx, (const bf16_t*)ctx, lse, delta, (bf16_t*)dqkv, S_pad, heads, scale);

@@ -348,7 +348,7 @@ extern "C" int climb_set_option(int key, int value) {
   if (key == 10 && (value == 0 || value == 1)) { g_tn_p = value; return CLIMB_OK; }
   if (key == 11 && value >= 0) { climb_nt2_set_dephase(value); return CLIMB_OK; }
   if (key == 12 && value >= 0 && value <= 2) { climb_attn_set_qb(value); return CLIMB_OK; }
-  if (key == 13 && (value == 0 || value == 1)) { climb_attn_set_bwd_fused(value); return CLIMB_OK; }
+  if (key == 13 && value >= 0 && value <= 3) { climb_attn_set_bwd_fused(value); return CLIMB_OK; }
   if (key == 14 && (value == 0 || value == 1)) { climb_ntsk_enable(value); return CLIMB_OK; }
   if (key == 15 && (value == 0 || value == 1)) { climb_ntp_set_sw(value); return CLIMB_OK; }
   if (key == 16 && value >= 0 && value < 4000) { climb_ntp_set_dephase(value); return CLIMB_OK; }

@@ -57,6 +57,61 @@ extern "C" int climb_adamw(float* p, const float* g, float* m, float* v, void* s
   return CLIMB_OK;
 }
 
+// r04: the same update over the ACTIVE spans of the flat buffer only.  Since the weight matrices are updated in the epilogue of the grouped
+// weight-gradient launch (gemm_bf16_tnp.hip), three quarters of the buffer are skipped tensors; adamw_kernel still walked them (a binary search
+// per 4 elements: 290 us for 0.9 GB of real work).  spans[3 i .. 3 i + 2] = { first element, elements, first block } of span i (maximal runs of
+// tensors with a group, in 1024-element blocks); a workgroup looks its span up once per block.  ZERO: the gradient is cleared as it is consumed, so
+// the step leaves the gradient buffer all zeros and the next zero_grad() has nothing to do (engine._grad_clean).
+template <bool SHADOW, bool ZERO>
+__global__ __launch_bounds__(256) void adamw_spans_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                          bf16_t* __restrict__ shadow, const long* __restrict__ spans, int nspans, long nblocks,
+                                                          const long* __restrict__ seg_start, const signed char* __restrict__ seg_group, int nseg,
+                                                          AdamGroups groups, float gscale) {
+  for (long b = blockIdx.x; b < nblocks; b += gridDim.x) {
+    int lo = 0, hi = nspans - 1;                     // last span whose first block is <= b
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (spans[3 * mid + 2] <= b) lo = mid; else hi = mid - 1;
+    }
+    const long start = spans[3 * lo], len = spans[3 * lo + 1], off = (b - spans[3 * lo + 2]) * 1024 + threadIdx.x * 4;
+    if (off >= len) continue;
+    const long e = start + off;
+    const int sg = seg_group[find_seg(seg_start, nseg, e)];
+    if (sg < 0) continue;
+    const AdamGroup G = groups.g[sg];
+    float4 pp = ld4(p + e), gg = ld4(g + e), mm = ld4(m + e), vv = ld4(v + e);
+    float pa[4] = {pp.x, pp.y, pp.z, pp.w}, ga[4] = {gg.x, gg.y, gg.z, gg.w}, ma[4] = {mm.x, mm.y, mm.z, mm.w}, va[4] = {vv.x, vv.y, vv.z, vv.w};
+    const float isb2 = rsqrtf(G.bc2), step = G.lr / G.bc1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) adamw_update(pa[j], ma[j], va[j], ga[j] * gscale, G, isb2, step);
+    st4(p + e, make_float4(pa[0], pa[1], pa[2], pa[3]));
+    st4(m + e, make_float4(ma[0], ma[1], ma[2], ma[3]));
+    st4(v + e, make_float4(va[0], va[1], va[2], va[3]));
+    if (SHADOW) st4(shadow + e, make_float4(pa[0], pa[1], pa[2], pa[3]));
+    if (ZERO) st4(g + e, make_float4(0.f, 0.f, 0.f, 0.f));
+  }
+}
+
+extern "C" int climb_adamw_spans(float* p, float* g, float* m, float* v, void* shadow_bf16, const long* spans, int nspans, long nblocks,
+                                 const long* seg_start, const signed char* seg_group, int nseg, const float* groups, int ngroups, float gscale,
+                                 int zero_grad, void* stream) {
+  if (nspans <= 0 || nblocks <= 0 || nseg <= 0 || ngroups <= 0 || ngroups > 8 || !spans) return CLIMB_EINVAL;
+  AdamGroups G;
+  for (int i = 0; i < 8; ++i) {
+    const float* s = groups + (i < ngroups ? i : 0) * 8;
+    G.g[i] = AdamGroup{s[0], s[1], s[2], s[3], s[4], s[5], s[6], 0.f};
+  }
+  dim3 grid((unsigned)(nblocks < 16384 ? nblocks : 16384)), blk(256);
+#define ADAMW_SPANS(S_, Z_)                                                                                                                          \
+  hipLaunchKernelGGL((adamw_spans_kernel<S_, Z_>), grid, blk, 0, (hipStream_t)stream, p, g, m, v, (bf16_t*)shadow_bf16, spans, nspans, nblocks, seg_start, \
+                     seg_group, nseg, G, gscale)
+  if (shadow_bf16) { if (zero_grad) ADAMW_SPANS(true, true); else ADAMW_SPANS(true, false); }
+  else             { if (zero_grad) ADAMW_SPANS(false, true); else ADAMW_SPANS(false, false); }
+#undef ADAMW_SPANS
+  LAUNCH_CHECK();
+  return CLIMB_OK;
+}
+
 // EWC (REF/cl_algorithms/ewc.py:75-87): loss = lam * sum F (theta - theta*)^2 ;  dloss/dtheta = 2 lam F (theta - theta*).
 // One pass over the encoder range: block partial sums -> partials[grid]; grad (optional) accumulated in place.
 __global__ __launch_bounds__(256) void ewc_kernel(const float* __restrict__ theta, const float* __restrict__ star, const float* __restrict__ fisher,

@@ -194,6 +194,7 @@ class ViltEngine:
         self.defer_dw = False
         self._dw_deferred = []          # [(ws, plan)]
         self._grad_extra = False        # the weight matrices' gradient ranges hold something besides zeros (EWC penalty term, an earlier backward)
+        self._grad_clean = False        # set by FusedAdamW.step() when it leaves the gradient buffer all zeros; any backward clears it (before_backward)
         self._unscale_pending = self._prescaled = False
         self.layout = layout
         self.cfg = layout.cfg
@@ -256,7 +257,10 @@ class ViltEngine:
         return self.grad.data_ptr() + 4 * self.layout.offset[name]
 
     def zero_grad(self):
-        self.grad.zero_()
+        # (r04) the optimizer step that just ran cleared every gradient it consumed and nothing else had been written: the buffer is zeros already
+        if not self._grad_clean:
+            self.grad.zero_()
+        self._grad_clean = False
         self.touched = []
         self._grad_dirty = False
         self._dw_deferred = []          # gradients nobody asked for are never computed

@@ -214,6 +214,7 @@ class _EngineHost:
                     if p.grad is None:
                         eng.zero_grad()
                     break
+        eng._grad_clean = False          # gradients are about to be written
 
     def after_backward(self):
         """`.grad` of every parameter that received a gradient aliases its slice of the flat buffer; the others stay

@@ -35,6 +35,8 @@ class FusedAdamW(torch.optim.Optimizer):
             self._seg_names = [s[0] for s in segs]
             starts = np.array([s[1] for s in segs] + [lay.total], dtype=np.int64)
             self._seg_start = torch.from_numpy(starts).to(eng.device)
+            self._seg_start_host = starts
+            self._spans, self._nspans, self._nblocks = None, 0, 0
             self._seg_group = torch.full((len(segs),), -1, dtype=torch.int8, device=eng.device)
             self._seg_group_host = None
             by_id = {id(p): n for n, p in self._host._params.items()}
@@ -102,8 +104,37 @@ class FusedAdamW(torch.optim.Optimizer):
         if self._seg_group_host is None or not np.array_equal(seg_group, self._seg_group_host):
             self._seg_group.copy_(torch.from_numpy(seg_group))
             self._seg_group_host = seg_group
-        _lib.call("climb_adamw", eng.flat, eng.grad, self._m, self._v, shadow, eng.layout.total, self._seg_start, self._seg_group,
-                  len(self._seg_names), table.ctypes.data, len(combos), 1.0, torch.cuda.current_stream().cuda_stream)
+            # maximal runs of tensors the flat pass updates, as { first element, elements, first 1024-element block } (csrc/optim.hip::adamw_spans_kernel)
+            starts = self._seg_start_host
+            spans, nb = [], 0
+            for si in np.flatnonzero(seg_group >= 0):
+                a, b = int(starts[si]), int(starts[si + 1])
+                if spans and spans[-1][0] + spans[-1][1] == a:
+                    spans[-1][1] += b - a
+                else:
+                    spans.append([a, b - a, 0])
+            for sp in spans:
+                sp[2] = nb
+                nb += (sp[1] + 1023) // 1024
+            self._spans = torch.tensor(spans, dtype=torch.int64, device=eng.device).reshape(-1) if spans else None
+            self._nspans, self._nblocks = len(spans), nb
+        # The pass clears the gradients it consumes when that leaves the WHOLE buffer zero: every range the backward wrote is updated here (the
+        # matrices updated in the weight-gradient epilogue were never written), nothing else is parked in the buffer (EWC term, accumulated sums)
+        # and no reducer or loss scale is in play.  The optimizer.zero_grad() that follows (REF/.../train_vqa.py:170) then has nothing to fill.
+        clean = bool(fused) and not eng._grad_extra and self._host.ddp is None and eng.loss_scale == 1.0 and not eng._dw_deferred
+        if clean:
+            consumed = seg_group >= 0
+            consumed[[idx[n] for n in fused]] = True
+            starts = self._seg_start_host
+            for lo, hi in eng.touched:
+                i0, i1 = int(np.searchsorted(starts, lo, "right")) - 1, int(np.searchsorted(starts, hi, "left"))
+                if not consumed[i0:i1].all():
+                    clean = False
+                    break
+        if self._nspans:
+            _lib.call("climb_adamw_spans", eng.flat, eng.grad, self._m, self._v, shadow, self._spans, self._nspans, self._nblocks, self._seg_start,
+                      self._seg_group, len(self._seg_names), table.ctypes.data, len(combos), 1.0, 1 if clean else 0, torch.cuda.current_stream().cuda_stream)
+        eng._grad_clean = clean
         eng.params_updated(shadow_fresh=shadow is not None, t_fresh=fused)
         return loss
 

@@ -414,6 +414,51 @@ def test_losses():
         assert abs(loss.item() - ref.item()) < 2e-6 and _rel(dl, xr.grad) < 2e-6
 
 
+@pytest.mark.parametrize("zero", [0, 1])
+def test_adamw_spans_equals_the_flat_pass(zero):
+    """r04: climb_adamw_spans walks only the maximal runs of tensors that have a group (spans in 1024-element blocks, ragged ends, a span of
+    several tensors with different groups) and must update them bit for bit like climb_adamw; tensors outside the spans keep p, m, v AND g;
+    with zero_grad = 1 the consumed gradients are cleared, nothing else is."""
+    from climb_amd import _lib
+    dev = _dev()
+    g = torch.Generator().manual_seed(5 + zero)
+    sizes = [64 * 3, 64 * 40, 64 * 17, 64 * 1, 64 * 100, 64 * 2, 64 * 33]
+    groups = np.array([0, -1, 1, 0, -1, -1, 1], dtype=np.int8)
+    starts = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    n = int(starts[-1])
+    table = np.array([[1e-3, 1e-2, 0.9, 0.98, 1e-8, 1 - 0.9 ** 3, 1 - 0.98 ** 3, 0], [2e-3, 0.0, 0.9, 0.98, 1e-8, 1 - 0.9, 1 - 0.98, 0]], dtype=np.float32)
+    p0, g0 = torch.randn(n, generator=g), torch.randn(n, generator=g) * 0.1
+    m0, v0 = torch.rand(n, generator=g) * 0.01, torch.rand(n, generator=g) * 0.001
+    d_starts, d_groups = torch.from_numpy(starts).to(dev), torch.from_numpy(groups).to(dev)
+    ref = [t.to(dev).clone() for t in (p0, g0, m0, v0)]
+    sh_ref = torch.zeros(n, device=dev, dtype=_h16())
+    _lib.call("climb_adamw", ref[0], ref[1], ref[2], ref[3], sh_ref, n, d_starts, d_groups, len(sizes), table.ctypes.data, 2, 1.0, _st())
+    spans, nb = [], 0
+    for si in np.flatnonzero(groups >= 0):
+        a, b = int(starts[si]), int(starts[si + 1])
+        if spans and spans[-1][0] + spans[-1][1] == a:
+            spans[-1][1] += b - a
+        else:
+            spans.append([a, b - a, 0])
+    for sp in spans:
+        sp[2] = nb
+        nb += (sp[1] + 1023) // 1024
+    assert len(spans) == 3 and spans[1][1] == 64 * 18          # tensors 2 and 3 (different groups) form one span
+    out = [t.to(dev).clone() for t in (p0, g0, m0, v0)]
+    sh = torch.zeros(n, device=dev, dtype=_h16())
+    _lib.call("climb_adamw_spans", out[0], out[1], out[2], out[3], sh, torch.tensor(spans, dtype=torch.int64, device=dev).reshape(-1), len(spans), nb,
+              d_starts, d_groups, len(sizes), table.ctypes.data, 2, 1.0, zero, _st())
+    for a, b in ((out[0], ref[0]), (out[2], ref[2]), (out[3], ref[3]), (sh, sh_ref)):
+        assert torch.equal(a, b)
+    gexp = g0.clone()
+    if zero:
+        for si in np.flatnonzero(groups >= 0):
+            gexp[int(starts[si]):int(starts[si + 1])] = 0
+    assert torch.equal(out[1].cpu(), gexp)
+    with pytest.raises(RuntimeError):          # no spans: an argument error, not a launch
+        _lib.call("climb_adamw_spans", out[0], out[1], out[2], out[3], None, None, 0, 0, d_starts, d_groups, len(sizes), table.ctypes.data, 2, 1.0, 0, _st())
+
+
 def test_adamw_ewc_fisher_flat_kernels():
     from climb_amd import _lib
     dev = _dev()
@@ -769,6 +814,48 @@ def test_attention_bf16_forward_variants_agree(S_pad):
         _lib.call("climb_set_option", 12, 0)
     for c, l in outs[1:]:
         assert torch.equal(c, outs[0][0]) and torch.equal(l, outs[0][1])
+
+
+@pytest.mark.parametrize("S_pad,valid", [(32, 32), (64, 41), (128, 128), (160, 131), (192, 185)])
+def test_attention_bf16_backward_variants_agree(S_pad, valid):
+    """The three backward kernels (climb_set_option 13: 0 = one launch per phase, 1 = both phases in one launch, 3 = the single pass that
+    computes S / dP / P / dS once per block pair and keeps dQ in LDS -- the default, 2, takes it where S_pad <= 128) against the fp64 softmax
+    backward.  0 and 1 are the same arithmetic (identical); the single pass sums dQ over key blocks in another order (close, not identical)."""
+    from climb_amd import _lib
+    dev = _dev()
+    B, heads, d = 3, 5, 64
+    H = heads * d
+    g = torch.Generator().manual_seed(7 * S_pad + valid)
+    qkv = _bf(torch.randn(B, S_pad, 3 * H, generator=g))
+    bias = torch.zeros(B, S_pad)
+    bias[:, valid:] = -3.0e38
+    bias[2, 1:4] = -3.0e38
+    dctx = _bf(torch.randn(B, S_pad, H, generator=g))
+    dctx[:, valid:] = 0
+    qr = qkv.double().requires_grad_(True)
+    _attn_ref(qr, bias.double().clamp(min=-1e300), heads).backward(dctx.double())
+    qd, bd, dd = qkv.to(dev).view(B * S_pad, 3 * H), bias.to(dev), dctx.to(dev).view(B * S_pad, H)
+    ctx = torch.empty(B * S_pad, H, device=dev, dtype=_h16())
+    lse = torch.empty(B, heads, S_pad, device=dev)
+    _lib.call("climb_attn_fwd_bf16", qd, bd, ctx, lse, B, S_pad, heads, d, _st())
+    outs = {}
+    try:
+        for mode in (0, 1, 3):
+            _lib.call("climb_set_option", 13, mode)
+            delta = torch.full((B, heads, S_pad), float("nan"), device=dev)
+            dqkv = torch.full((B * S_pad, 3 * H), float("nan"), device=dev, dtype=_h16())
+            for _ in range(3):          # repeated launches into the same output: the LDS accumulators must not carry anything over
+                _lib.call("climb_attn_bwd_bf16", qd, bd, dd, ctx, lse, delta, dqkv, B, S_pad, heads, d, _st())
+            outs[mode] = dqkv.float().view(B, S_pad, 3 * H).cpu()
+    finally:
+        _lib.call("climb_set_option", 13, 2)
+    assert torch.equal(outs[0], outs[1])
+    for mode in (1, 3):
+        assert not torch.isnan(outs[mode]).any()
+        e = [_rel(outs[mode][..., k * H:(k + 1) * H], qr.grad[..., k * H:(k + 1) * H]) for k in range(3)]
+        print(f"attention bwd mode {mode} S_pad={S_pad}: dq {e[0]:.2e} dk {e[1]:.2e} dv {e[2]:.2e}")
+        assert max(e) < 2e-2
+    assert _rel(outs[3], outs[1]) < 1e-2
 
 
 @pytest.mark.parametrize("case", ["soft_bias", "peaked", "masked_row"])

@@ -979,7 +979,13 @@ def test_optimizer_in_the_weight_gradient_epilogue_is_the_same_training_step(con
                 pixels, texts, target = _rand_batch(64, 950, dev)
             loss, _, _, _ = model.fused_forward_backward("vqa", pixels, texts, target, ewc, optimizer=opt if fused else None)
             opt.step()
+            # the flat pass clears what it consumes when that leaves the whole buffer zero (no EWC term parked in it): zero_grad() then skips its fill
+            expect_clean = fused and config != "ewc" and not (config == "accumulate" and step == 1)
+            assert eng._grad_clean == expect_clean, (config, fused, step)
+            if expect_clean:
+                assert not bool(eng.grad.any()), "the step claimed a zero gradient buffer"
             opt.zero_grad()
+            assert not bool(eng.grad.any()) and not eng._grad_clean
             losses.append(float(loss))
         eng.refresh_shadow()
         torch.cuda.synchronize()
