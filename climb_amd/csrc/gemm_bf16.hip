@@ -338,6 +338,7 @@ void climb_ntsk_enable(int v);
 void climb_ntp_set_sw(int v);
 void climb_ntp_set_dephase(int v);
 void climb_ntsk_set_workspace(void* ptr, long bytes);
+void climb_skinny_set_probe(int v);
 extern "C" int climb_set_option(int key, int value) {
   if (key == 1 && (value == 4 || value == 8)) { g_nt_waves = value; return CLIMB_OK; }
   if (key == 2) { g_nt_small_m = value; return CLIMB_OK; }
@@ -355,6 +356,7 @@ extern "C" int climb_set_option(int key, int value) {
   if (key == 9 && value >= 0) { climb_nt256_set_grid(value); climb_nt4_set_grid(value); return CLIMB_OK; }
   if (key == 17 && value >= 0 && value <= 3) { climb_nt4_set(value); return CLIMB_OK; }
   if (key == 18 && value >= 0) { climb_nt4_set_probe(value); return CLIMB_OK; }
+  if (key == 19 && value >= 0 && value <= 2) { climb_skinny_set_probe(value); return CLIMB_OK; }
   if (key == 6 && (value == 4 || value == 8)) { g_tn_waves = value; return CLIMB_OK; }
   if (key == 3 && value > 0) { g_tn_target = value; return CLIMB_OK; }
   return CLIMB_EINVAL;

@@ -30,6 +30,10 @@ _UNSCALE_MODE = os.environ.get("CLIMB_AMD_FP16_UNSCALE", "end")      # measureme
 EPI_NONE, EPI_GELU, EPI_RESID, EPI_DGELU, EPI_TANH, EPI_SILU, EPI_DSILU, EPI_RESID2 = 0, 1, 2, 3, 4, 5, 6, 7
 
 
+# r04: the pooler / task-head products on csrc/heads.hip (0 = the r01-r03 launches: split-K GEMMs with atomics + separate activations)
+SKINNY = os.environ.get("CLIMB_AMD_SKINNY_HEADS", "1") != "0"
+
+
 def _stream():
     return torch.cuda.current_stream().cuda_stream
 
@@ -322,6 +326,12 @@ class ViltEngine:
         # split-K (atomic partial sums) only in the throughput mode: the fp32 parity mode stays run-to-run deterministic
         self._timed_call("gemm_f32", 2.0 * M * N * K, "climb_gemm_f32", A, sam, sak, Bm, sbn, sbk, C, ldc, M, N, K, bias, epi, aux, ldaux, aux_out,
                          ldauxo, beta, aux2, ldaux2, 1 if self.precision == "bf16" else 0, _stream())
+
+    def _skinny(self, A, lda, B, sbn, sbk, C, ldc, M, N, K, bias=None, epi=0, aux=None, ldaux=0, colsum=None, acol=None):
+        """csrc/heads.hip: C = epi(A B^T + bias) for M = batch rows; colsum / acol: parameter-gradient pointers that the column sums of C / of A are
+        ADDED to (the bias gradients on either side of the product)."""
+        self._timed_call("skinny_f32", 2.0 * M * N * K, "climb_skinny_f32", A, lda, B, sbn, sbk, C, ldc, M, N, K, bias, epi, aux, ldaux, colsum, 1.0,
+                         acol, 1.0, _stream())
 
     def linear_fwd(self, X, wname, bname, Y, M, N, K, epi=EPI_NONE, aux=None, aux_out=None, aux2=None, out_f32=False):
         if self.precision == "fp32":
@@ -631,7 +641,9 @@ class ViltEngine:
         # used by CLiMB (REF/modeling/vilt.py:123-124), so the other S-1 rows are dead work we skip
         _lib.call("climb_layernorm_fwd", xL, ldxL, self.p(ENC + "layernorm.weight"), self.p(ENC + "layernorm.bias"), cfg["ln_eps"],
                   ws.clsn, H, F32, ws.fmean, ws.frstd, B, H, st)
-        if self.precision == "bf16":      # skinny GEMM (M = batch): split-K over all CUs, then the activation (61 -> ~20 us at bs = 64)
+        if SKINNY:                        # r04: every row of a 16-column strip in one workgroup, K split inside it: tanh in the epilogue, no atomics
+            self._skinny(ws.clsn, H, self.p(ENC + "pooler.dense.weight"), H, 1, ws.pooled, H, B, H, H, self.p(ENC + "pooler.dense.bias"), epi=1)
+        elif self.precision == "bf16":    # skinny GEMM (M = batch): split-K over all CUs, then the activation (61 -> ~20 us at bs = 64)
             self._gemm_f32(ws.clsn, H, 1, self.p(ENC + "pooler.dense.weight"), H, 1, ws.pooled, H, B, H, H, self.p(ENC + "pooler.dense.bias"))
             _lib.call("climb_elementwise", 6, ws.pooled, None, ws.pooled, B * H, 1.0, st)
         else:
@@ -856,7 +868,7 @@ class ViltEngine:
             if hook is not None:
                 hook(a, b)
 
-    def encoder_backward(self, dpooled: torch.Tensor, first_layer: int = 0, embeddings: bool = True):
+    def encoder_backward(self, dpooled: torch.Tensor, first_layer: int = 0, embeddings: bool = True, dpooled_is_dpre: bool = False):
         """Accumulates parameter gradients into the flat grad buffer.  `first_layer` / `embeddings` let frozen prefixes
         (REF/modeling/vilt.py:126-144) be skipped entirely."""
         cfg, lay = self.cfg, self.layout
@@ -872,13 +884,20 @@ class ViltEngine:
         ad = sv.get("adapter")
         r = self.layout.adapters[ad] if ad is not None else 0
         # pooler: pooled = tanh(clsn Wp^T + b)
-        _lib.call("climb_elementwise", 2, dpooled, ws.pooled, ws.dpre, B * H, 1.0, st)
+        if dpooled_is_dpre:              # the head's last product already carried x (1 - pooled^2) in its epilogue
+            dpre = dpooled
+        else:
+            dpre = ws.dpre
+            _lib.call("climb_elementwise", 2, dpooled, ws.pooled, dpre, B * H, 1.0, st)
         pw, pb = ENC + "pooler.dense.weight", ENC + "pooler.dense.bias"
         if rg[pw]:
-            self._gemm_f32(ws.dpre, 1, H, ws.clsn, 1, H, self.g(pw), H, H, H, B, beta=1.0)
-        if rg[pb]:
-            self._gemm_f32(ws.dpre, 1, H, ws.ones, 0, 1, self.g(pb), 1, H, 1, B, beta=1.0)
-        self._gemm_f32(ws.dpre, H, 1, self.p(pw), 1, H, ws.dclsn, H, B, H, H)
+            self._gemm_f32(dpre, 1, H, ws.clsn, 1, H, self.g(pw), H, H, H, B, beta=1.0)
+        if SKINNY and B <= 64:           # d(clsn) = dpre Wp, and the bias gradient = the column sums of its A operand, in the same launch
+            self._skinny(dpre, H, self.p(pw), 1, H, ws.dclsn, H, B, H, H, acol=self.g(pb) if rg[pb] else None)
+        else:
+            if rg[pb]:
+                self._gemm_f32(dpre, 1, H, ws.ones, 0, 1, self.g(pb), 1, H, 1, B, beta=1.0)
+            self._gemm_f32(dpre, H, 1, self.p(pw), 1, H, ws.dclsn, H, B, H, H)
         # final LayerNorm (row 0 of every sequence); all other rows of d(x_L) are zero
         ws.dres.zero_()
         prune = bool(sv.get("cls_only"))
@@ -1113,6 +1132,12 @@ class ViltEngine:
             hs.z, hs.zn, hs.gz, hs.mean, hs.rstd = hb["z"], hb["zn"], hb["gz"], hb["mean"], hb["rstd"]
             ldl = _round_up(NL, 4)
             hs.logits = hb["logits"][:, :NL]
+            if SKINNY:                    # r04 (csrc/heads.hip): 3 launches instead of 7 (no zero-fill, no separate activation)
+                self._skinny(pooled_in, Kin, self.p(h + "0.weight"), Kin, 1, hs.z, D, Bh, D, Kin, self.p(h + "0.bias"))
+                _lib.call("climb_layernorm_gelu_fwd", hs.z, D, self.p(h + "1.weight"), self.p(h + "1.bias"), self.cfg["head_ln_eps"], hs.zn, hs.gz, D,
+                          hs.mean, hs.rstd, Bh, D, st)
+                self._skinny(hs.gz, D, self.p(h + "3.weight"), D, 1, hs.logits, ldl, Bh, NL, D, self.p(h + "3.bias"))
+                return hs.logits, hs
             self._gemm_f32(pooled_in, Kin, 1, self.p(h + "0.weight"), Kin, 1, hs.z, D, Bh, D, Kin, self.p(h + "0.bias"))
             _lib.call("climb_layernorm_fwd", hs.z, D, self.p(h + "1.weight"), self.p(h + "1.bias"), self.cfg["head_ln_eps"], hs.zn, D, F32,
                       hs.mean, hs.rstd, Bh, D, st)
@@ -1135,7 +1160,10 @@ class ViltEngine:
         self._gemm_f32(hs.xd, H, 1, self.p(h + "1.weight"), H, 1, hs.logits, 1, b * nc, 1, H, self.p(h + "1.bias"))
         return hs.logits, hs
 
-    def head_backward(self, hs: HeadState, dlogits: torch.Tensor) -> torch.Tensor:
+    def head_backward(self, hs: HeadState, dlogits: torch.Tensor, dtanh_of: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """`dtanh_of`: the pooler's tanh output the head consumed ([rows, Kin]-compatible memory).  When given and honoured (hs.dx_is_dpre is set),
+        the returned gradient is already multiplied by 1 - pooled^2: encoder_backward(..., dpooled_is_dpre=True) skips that pass."""
+        hs.dx_is_dpre = False
         task_key = hs.task
         tc = self.task_cfgs[task_key]
         H = self.cfg["hidden"]
@@ -1151,6 +1179,22 @@ class ViltEngine:
             ones = hb["ones"]
             if rg[h + "3.weight"]:
                 self._gemm_f32(dlogits, 1, ldl, hs.gz, 1, D, self.g(h + "3.weight"), D, NL, D, Bh, beta=1.0)
+            if SKINNY and Bh <= 64 and ldl % 4 == 0:
+                # r04 (csrc/heads.hip): 5 launches instead of 13 -- d(zn) = (dlogits W3) gelu'(zn) with d(b3) = colsum(dlogits) from the same launch; the
+                # LayerNorm backward's third partial sum IS d(b0); d(x) = dz W0 (x (1 - pooled^2) when the pooler's output is what the head consumed)
+                dzn, dz, part, dx = hb["dzn"], hb["dz"], hb["part"], hb["dx"]
+                self._skinny(dlogits, ldl, self.p(h + "3.weight"), 1, D, dzn, D, Bh, D, NL, epi=3, aux=hs.zn, ldaux=D,
+                             acol=self.g(h + "3.bias") if rg[h + "3.bias"] else None)
+                lnb = _lib.query("climb_layernorm_bwd_rows_per_block")
+                _lib.call("climb_layernorm_bwd", dzn, D, F32, hs.z, D, hs.mean, hs.rstd, self.p(h + "1.weight"), None, 0, dz, D, None, 0, part, Bh, D, st)
+                self.reduce3(part, (Bh + lnb - 1) // lnb, D, h + "1.weight", h + "1.bias", h + "0.bias")
+                if rg[h + "0.weight"]:
+                    self._gemm_f32(dz, 1, D, hs.x, 1, Kin, self.g(h + "0.weight"), Kin, D, Kin, Bh, beta=1.0)
+                fuse_tanh = dtanh_of is not None and dtanh_of.numel() == Bh * Kin and dtanh_of.is_contiguous()
+                self._skinny(dz, D, self.p(h + "0.weight"), 1, Kin, dx, Kin, Bh, Kin, D, epi=2 if fuse_tanh else 0, aux=dtanh_of if fuse_tanh else None, ldaux=Kin)
+                hs.dx_is_dpre = fuse_tanh
+                self._ready(*self.layout.head_range[task_key])
+                return dx
             if rg[h + "3.bias"]:
                 self._gemm_f32(dlogits, 1, ldl, ones, 0, 1, self.g(h + "3.bias"), 1, NL, 1, Bh, beta=1.0)
             dg = hb["dg"]

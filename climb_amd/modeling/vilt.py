@@ -617,10 +617,10 @@ class ViltContinualLearner(ContinualLearner):
         # fp16 operands: d(logits) is produced already multiplied by the loss scale (every |d logit| of both losses is <= 1 / rows)
         gs = eng.begin_scaled_backward(1.0 / max(1, logits.shape[0])) * float(grad_weight)
         loss, dlogits = eng.loss_and_grad(task_key, logits, target, gscale=gs, hs=hs)
-        dpool = eng.head_backward(hs, dlogits)
+        dpool = eng.head_backward(hs, dlogits, dtanh_of=pooled_seq)
         first, emb = host.frozen_prefix()
         if host.any_encoder_grad() is not None:
-            eng.encoder_backward(dpool.reshape(B, -1).contiguous(), first_layer=first, embeddings=emb)
+            eng.encoder_backward(dpool.reshape(B, -1).contiguous(), first_layer=first, embeddings=emb, dpooled_is_dpre=bool(getattr(hs, "dx_is_dpre", False)))
         eng.saved = None           # (also when the encoder is frozen and its backward never ran)
         eng.finish_scaled_backward()
         if host.ddp is not None:

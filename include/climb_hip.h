@@ -94,6 +94,16 @@ int climb_colsum_rows_per_block(void);
  * long K; epi 0 only) split K across workgroups with fp32 atomics (sum order then varies from run to run) */
 int climb_gemm_f32(const float* A, long sam, long sak, const float* B, long sbn, long sbk, float* C, long ldc, int M, int N, int K, const float* bias, int epi, const float* aux, long ldaux, float* aux_out, long ldauxo, float beta, const float* aux2, long ldaux2, int allow_splitk, void* stream);
 
+/* r04: the skinny fp32 products of the pooler and the task heads (REF/modeling/vilt.py:179-203, HF:650-663; M = batch rows): one workgroup per
+ * 16-column strip of C holding EVERY row, K split over its 8 waves and summed in LDS in a fixed order (no atomics: run-to-run identical).
+ * C[m,n] = epi(sum_k A[m*lda+k] * B[n*sbn+k*sbk] + bias[n]); epi: 0 none, 1 tanh, 2 * (1 - aux^2) (tanh backward), 3 * gelu'(aux).
+ * colsum != NULL (M <= 64): colsum[n] = colsum_beta * colsum[n] + sum_m C[m,n] (the bias gradient of the layer below);
+ * acol != NULL (M <= 64): acol[k] = acol_beta * acol[k] + sum_m A[m,k] (the bias gradient of the layer that produced A).  lda % 4 == 0. */
+int climb_skinny_f32(const float* A, long lda, const float* B, long sbn, long sbk, float* C, long ldc, int M, int N, int K, const float* bias, int epi, const float* aux, long ldaux, float* colsum, float colsum_beta, float* acol, float acol_beta, void* stream);
+
+/* REF/modeling/vilt.py:191-193 (head LayerNorm, eps 1e-5, then GELU): zn = LN(x), gz = gelu(zn), both [M, C] fp32 with leading dim ldy; C <= 1536 */
+int climb_layernorm_gelu_fwd(const float* x, long ldx, const float* gamma, const float* beta, float eps, float* zn, float* gz, long ldy, float* mean, float* rstd, int M, int C, void* stream);
+
 /* ---- attention ------------------------------------------------------------------------------------------------- */
 /* HF:322-351 ViltSelfAttention: softmax(Q K^T / sqrt(d) + key_bias) V per (batch, head); scores never leave the CU.
  * qkv [B*S_pad, 3H] columns [q|k|v]; ctx [B*S_pad, H]; lse [B, heads, S_pad] saved for backward */

@@ -414,6 +414,79 @@ def test_losses():
         assert abs(loss.item() - ref.item()) < 2e-6 and _rel(dl, xr.grad) < 2e-6
 
 
+@pytest.mark.parametrize("M,N,K,kcontig,epi", [(64, 768, 768, True, 1), (64, 1536, 768, True, 0), (64, 3129, 1536, True, 0), (64, 1536, 3129, False, 3),
+                                                (64, 768, 1536, False, 2), (32, 1536, 1536, True, 0), (5, 3, 70, True, 0), (130, 40, 33, False, 1)])
+def test_skinny_f32_products_of_the_heads(M, N, K, kcontig, epi):
+    """r04 csrc/heads.hip: C = epi(A B^T + bias) with every row of a 16-column strip in one workgroup (K split over 8 waves, summed in LDS in a
+    fixed order), against float64: the pooler / head shapes at the benchmark's batch (K = 3129 is not a multiple of the 16-deep k-block), both B
+    layouts (weights [N, K] and transposed use [K, N]), every epilogue, ragged M / N / K, M > 64 (two row tiles); the column sums of C and of A
+    (bias gradients, M <= 64) are added to what the target held; two launches give identical bits."""
+    from climb_amd import _lib
+    dev = _dev()
+    g = torch.Generator().manual_seed(M * 7 + N + K)
+    lda = (K + 3) // 4 * 4
+    A = torch.zeros(M, lda)
+    A[:, :K] = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) / math.sqrt(K)
+    bias = torch.randn(N, generator=g)
+    aux = torch.randn(M, N, generator=g)
+    ref = A[:, :K].double() @ W.double().t() + bias.double()
+    if epi == 1:
+        ref = torch.tanh(ref)
+    elif epi == 2:
+        ref = ref * (1 - aux.double() ** 2)
+    elif epi == 3:
+        x = aux.double()
+        ref = ref * (0.5 * (1 + torch.erf(x / math.sqrt(2))) + x * torch.exp(-0.5 * x * x) / math.sqrt(2 * math.pi))
+    Ad, auxd, bd = A.to(dev), aux.to(dev), bias.to(dev)
+    if kcontig:
+        Kp = (K + 3) // 4 * 4
+        Wd = torch.zeros(N, Kp, device=dev)
+        Wd[:, :K] = W.to(dev)
+        sbn, sbk = Kp, 1
+    else:
+        Wd = W.t().contiguous().to(dev)          # [K, N]: B(n, k) = Wd[k, n]
+        sbn, sbk = 1, N
+    want_sums = M <= 64
+    cs0, ac0 = torch.randn(N, generator=g), torch.randn(K, generator=g)
+    outs = []
+    for _ in range(2):
+        C = torch.full((M, N + 3), float("nan"), device=dev)
+        cs, ac = cs0.to(dev), ac0.to(dev)
+        _lib.call("climb_skinny_f32", Ad, lda, Wd, sbn, sbk, C, N + 3, M, N, K, bd, epi, auxd if epi >= 2 else None, N, cs if want_sums else None, 1.0,
+                  ac if want_sums else None, 1.0, _st())
+        outs.append((C.cpu(), cs.cpu(), ac.cpu()))
+    C, cs, ac = outs[0]
+    assert torch.isnan(C[:, N:]).all()                       # nothing outside the N columns
+    assert _rel(C[:, :N], ref) < 3e-6
+    if want_sums:
+        assert _rel(cs, cs0.double() + ref.sum(0)) < 3e-6
+        assert _rel(ac, ac0.double() + A[:, :K].double().sum(0)) < 3e-6
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a[:, :N] if a.dim() == 2 else a, b[:, :N] if b.dim() == 2 else b)
+    if not want_sums:
+        with pytest.raises(RuntimeError):
+            _lib.call("climb_skinny_f32", Ad, lda, Wd, sbn, sbk, C.to(dev), N + 3, M, N, K, bd, 0, None, 0, cs0.to(dev), 1.0, None, 1.0, _st())
+
+
+def test_layernorm_gelu_forward_of_the_head():
+    """zn = LayerNorm(z) and gz = gelu(zn) in one pass (REF/modeling/vilt.py:191-193) = climb_layernorm_fwd followed by the gelu pass, bit for bit"""
+    from climb_amd import _lib
+    dev = _dev()
+    g = torch.Generator().manual_seed(3)
+    for M, C in ((64, 1536), (7, 768), (33, 1536)):
+        z = (torch.randn(M, C, generator=g) * 2 + 0.3).to(dev)
+        gam, bet = torch.randn(C, generator=g).to(dev), torch.randn(C, generator=g).to(dev)
+        zn, gz, mu, rs = (torch.empty(M, C, device=dev), torch.empty(M, C, device=dev), torch.empty(M, device=dev), torch.empty(M, device=dev))
+        _lib.call("climb_layernorm_gelu_fwd", z, C, gam, bet, 1e-5, zn, gz, C, mu, rs, M, C, _st())
+        zn2, gz2, mu2, rs2 = (torch.empty(M, C, device=dev), torch.empty(M, C, device=dev), torch.empty(M, device=dev), torch.empty(M, device=dev))
+        _lib.call("climb_layernorm_fwd", z, C, gam, bet, 1e-5, zn2, C, 0, mu2, rs2, M, C, _st())
+        _lib.call("climb_elementwise", 0, zn2, None, gz2, M * C, 1.0, _st())
+        assert torch.equal(zn, zn2) and torch.equal(gz, gz2) and torch.equal(mu, mu2) and torch.equal(rs, rs2)
+        ref = torch.nn.functional.gelu(torch.nn.functional.layer_norm(z.double().cpu(), (C,), gam.double().cpu(), bet.double().cpu(), 1e-5))
+        assert _rel(gz, ref) < 3e-6
+
+
 @pytest.mark.parametrize("zero", [0, 1])
 def test_adamw_spans_equals_the_flat_pass(zero):
     """r04: climb_adamw_spans walks only the maximal runs of tensors that have a group (spans in 1024-element blocks, ragged ends, a span of

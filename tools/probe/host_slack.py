@@ -32,7 +32,7 @@ def run(d_fwd, d_opt, steps=20):
         if i == 5:
             torch.cuda.synchronize(); t0 = time.perf_counter()
         spin(d_fwd)
-        model.fused_forward_backward("vqa", pixels, texts, target)
+        model.fused_forward_backward("vqa", pixels, texts, target, optimizer=opt)
         spin(d_opt)
         opt.step(); opt.zero_grad()
     torch.cuda.synchronize()
@@ -44,7 +44,7 @@ for d_fwd, d_opt in [(0, 0), (0, 200), (0, 1000), (200, 0), (1000, 0), (2000, 20
 # host time of one step's launches with the GPU idle-proof: enqueue without waiting
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(10):
-    model.fused_forward_backward("vqa", pixels, texts, target); opt.step(); opt.zero_grad()
+    model.fused_forward_backward("vqa", pixels, texts, target, optimizer=opt); opt.step(); opt.zero_grad()
 t_host = (time.perf_counter() - t0) / 10 * 1e3
 torch.cuda.synchronize()
 print(f"host enqueue time per step (includes back-pressure if the queue fills): {t_host:.3f} ms")
