@@ -840,9 +840,252 @@ __global__ __launch_bounds__(384) void attn_bwd_bf16_1p_kernel(const bf16_t* __r
   store_acc(orow + 2 * H, accV, half, 1.0f);
 }
 
-static int g_attn_bwd_fused = 2;     // climb_set_option 13: 0 = the two launches, 1 = both phases in one launch, 2 (default) = single pass where two workgroups fit a CU (S_pad <= 128),
-                                     // both phases in one launch above that, 3 = single pass wherever it runs (S_pad <= 192)
+// ------------------------------------------------------------------------------------------------------ single pass, PERSISTENT (r04)
+// The kernel above at S_pad = 192 needs 110 KB of LDS: one workgroup per CU, so a CU loads (144 KB, 5 us when 256 CUs ask at once), then
+// computes (9 us), then stores, and the chip alternates between an HBM burst and an idle fabric -- 60 us per layer against the two-phase
+// kernel's 54.  Here a workgroup WALKS (batch, head) items (grid = CUs) and the Q / dO images are double-buffered: the eight LDS-DMA
+// instructions that bring in the NEXT item's block go out right after the barrier that publishes the current one and land while its six steps
+// run.  What stays exposed per item is the round trip of the wave's own K / V / O rows (12 KB per wave, registers).
+// With DMA in flight inside the step loop every LDS access in it follows the rules of the streamed kernels at the top of this file: no
+// __restrict__ on the kernel's pointers, reads are typed vector loads or asm, every WRITE is asm (hipcc puts a vmcnt(0) in front of a ds_write
+// it can see while LDS DMA is pending -- that would be the whole prefetch), the barrier is a raw s_barrier behind an explicit lgkmcnt(0)
+// (__syncthreads() carries a workgroup-scope release fence = vmcnt(0)).
+// LDS: 2 x NB x 8 KB images | NB x 8 KB dQ accumulators | NB x 2 KB turn tiles | lse, delta = 157.5 KB at S_pad = 192.
+__device__ __forceinline__ void ab1_ds_write_b128(unsigned addr, const f32x4& v) { asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(v) : "memory"); }
+__device__ __forceinline__ void ab1_lds_fence_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+}
+__global__ __launch_bounds__(384) void attn_bwd_bf16_1pp_kernel(const bf16_t* qkv, const float* key_bias, const bf16_t* dctx, const bf16_t* ctx, const float* lse,
+                                                                bf16_t* dqkv, int S_pad, int heads, float scale, int items) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int NB = S_pad / 32;
+  unsigned char* dqs = smem + 2 * NB * AB_BLK;
+  unsigned char* tsc = dqs + NB * AB_BLK;
+  float* lse_s = reinterpret_cast<float*>(tsc + NB * AB1_TURN);
+  float* delta_s = lse_s + AB_VEC(S_pad);
+  const int H = heads * AB_D, ld = 3 * H;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), half = lane >> 5, l31 = lane & 31;
+  const unsigned lds0 = (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char*)smem;
+  // lane constants: turn tile, dQ accumulators (raw float4 (dd * 4 + g) of lane l at ((dd * 4 + g) * 64 + l) * 16), K scratch
+  const unsigned tbase = lds0 + (unsigned)(tsc - smem) + w * AB1_TURN;
+  unsigned tw[4], ta, tb;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) tw[g] = tbase + l31 * 64 + ((g ^ ((l31 >> 2) & 3)) << 4) + 8 * half;
+  {
+    const int g16 = lane >> 4, i = lane & 15;
+    const int rowa = 4 * (g16 >> 1) + (i >> 2), rowb = rowa + 8, col = (g16 & 1) * 16 + 4 * (i & 3);
+    ta = tbase + rowa * 64 + (((col >> 3) ^ ((rowa >> 2) & 3)) << 4) + (col & 7) * 2;
+    tb = tbase + rowb * 64 + (((col >> 3) ^ ((rowb >> 2) & 3)) << 4) + (col & 7) * 2;
+  }
+  const unsigned dq0 = lds0 + (unsigned)(dqs - smem) + lane * 16;
+  const float c1 = scale * AB_LOG2E, is = -1.0f / scale;
+  // this wave's block of an item's Q / dO into image buffer `buf`
+  auto prefetch = [&](int item, int buf) {
+    const int b = item / heads, h = item % heads;
+    const bf16_t* Qg = qkv + (long)b * S_pad * ld + h * AB_D;
+    const bf16_t* dOg = dctx + (long)b * S_pad * H + h * AB_D;
+    const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)Qg, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)dOg, 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int slot = (4 * w + u) * 64 + lane, row = slot >> 3, c = (slot & 7) ^ aswz(row);
+      unsigned char* dst = smem + buf * NB * AB_BLK + w * AB_BLK + u * 1024;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (lds_void_t*)dst, 16, row * (ld * 2) + c * 16, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, (lds_void_t*)(dst + AB_Y), 16, row * (H * 2) + c * 16, 0, 0, 0);
+    }
+  };
+  int item = blockIdx.x;
+  if (item < items) prefetch(item, 0);
+  for (int n = 0; item < items; ++n, item += gridDim.x) {
+    const int buf = n & 1;
+    unsigned char* img = smem + buf * NB * AB_BLK;
+    const int b = item / heads, h = item % heads;
+    const bf16_t* Kg = qkv + (long)b * S_pad * ld + h * AB_D + H;
+    const bf16_t* Vg = Kg + H;
+    const bf16_t* Og = ctx + (long)b * S_pad * H + h * AB_D;
+    const long rowv = ((long)b * heads + h) * S_pad;
+    const int my = w * 32 + l31;
+    bf16x8 f1[4], f2[4];
+    float my_c;
+    {
+      bf16x8 fo[4];
+      load_rows(f1, Kg, ld, w * 32, lane);
+      load_rows(f2, Vg, ld, w * 32, lane);
+      load_rows(fo, Og, H, w * 32, lane);
+      my_c = key_bias[(long)b * S_pad + my];
+      float my_lse = lse[rowv + my];
+      __builtin_amdgcn_sched_barrier(0);
+      ab_wait_vm<0>();                 // this wave's rows, its block of the item's images (asked for an item ago), and the previous item's stores
+      use_rows(f1); use_rows(f2); use_rows(fo);
+      asm volatile("" : "+v"(my_c), "+v"(my_lse));
+      float dsum = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8 fd = row_frag(img + w * AB_BLK + AB_Y, ks, lane);          // dO rows of this wave's own block: same elements as fo's
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dsum += (float)fo[ks][e] * (float)fd[e];
+      }
+      const float my_delta = pair_sum(dsum);
+      if (half == 0) { delta_s[my] = my_delta; lse_s[my] = my_lse; }      // (no LDS DMA is in flight here: plain stores)
+    }
+    bf16x8 kT[2][2];
+    {
+      unsigned char* ksc = dqs + w * AB_BLK;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        union { bf16x8 b; u32x4 u; } c;
+        c.b = f1[ks];
+        *reinterpret_cast<u32x4*>(ksc + l31 * 128 + (((2 * ks + half) ^ aswz(l31)) << 4)) = c.u;
+      }
+      const ColAddr ka = col_addr(ksc, lane);
+      col_frags4<0>(kT, ka, 0);
+    }
+    negate_rows(f2);
+    const ColAddr xa = col_addr(img, lane);
+    const float k2 = fmaxf(my_c, AB_NEG) * AB_LOG2E;
+    ab1_lds_fence_barrier();           // every wave's block of this item, lse and delta are in LDS; nobody reads the other image buffer any more
+    if (item + (int)gridDim.x < items) prefetch(item + gridDim.x, buf ^ 1);
+    __builtin_amdgcn_sched_barrier(0);
+    f32x16 accK[2], accV[2];
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) accK[d][r] = accV[d][r] = 0.f;
+    for (int t = 0; t < NB; ++t) {
+      int ib = w + t;
+      ib = ib >= NB ? ib - NB : ib;
+      f32x16 s, dp;
+      {
+        const f32x4* ap = reinterpret_cast<const f32x4*>(lse_s + ib * 32 + 4 * half);
+        const f32x4* dl = reinterpret_cast<const f32x4*>(delta_s + ib * 32 + 4 * half);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 v = ap[2 * g], dd = dl[2 * g];
+          s[4 * g] = v.x * is; s[4 * g + 1] = v.y * is; s[4 * g + 2] = v.z * is; s[4 * g + 3] = v.w * is;
+          dp[4 * g] = dd.x; dp[4 * g + 1] = dd.y; dp[4 * g + 2] = dd.z; dp[4 * g + 3] = dd.w;
+        }
+      }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        s = CLIMB_MFMA_H16(row_frag(img + ib * AB_BLK, ks, lane), f1[ks], s, 0, 0, 0);
+        dp = CLIMB_MFMA_H16(row_frag(img + ib * AB_BLK + AB_Y, ks, lane), f2[ks], dp, 0, 0, 0);
+      }
+      unsigned int pk[8], dsk[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const f32x2 e = f32x2{s[2 * i], s[2 * i + 1]} * c1 + k2;
+        const f32x2 pe = {__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y)};
+        const f32x2 d = f32x2{dp[2 * i], dp[2 * i + 1]} * pe;
+        pk[i] = pack_bf16x2(pe.x, pe.y);
+        dsk[i] = pack_bf16x2(d.x, d.y);
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const u32x2 v = {dsk[2 * g], dsk[2 * g + 1]};
+        asm volatile("ds_write_b64 %0, %1" ::"v"(tw[g]), "v"(v) : "memory");
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      bf16x8 f[2];
+      col_frags2<0, 0>(f, xa, ib);
+      accK[0] = CLIMB_MFMA_H16(f[0], packed4(dsk, 0), accK[0], 0, 0, 0);
+      accK[1] = CLIMB_MFMA_H16(f[1], packed4(dsk, 0), accK[1], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      col_frags2<1, 0>(f, xa, ib);
+      accV[0] = CLIMB_MFMA_H16(f[0], packed4(pk, 0), accV[0], 0, 0, 0);
+      accV[1] = CLIMB_MFMA_H16(f[1], packed4(pk, 0), accV[1], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      col_frags2<0, 1>(f, xa, ib);
+      accK[0] = CLIMB_MFMA_H16(f[0], packed4(dsk, 1), accK[0], 0, 0, 0);
+      accK[1] = CLIMB_MFMA_H16(f[1], packed4(dsk, 1), accK[1], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      col_frags2<1, 1>(f, xa, ib);
+      accV[0] = CLIMB_MFMA_H16(f[0], packed4(pk, 1), accV[0], 0, 0, 0);
+      accV[1] = CLIMB_MFMA_H16(f[1], packed4(pk, 1), accV[1], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      // the dQ accumulators of block ib (nobody else touches them in this step) and the turned dS
+      f32x16 dq[2];
+      const unsigned dqa = dq0 + ib * AB_BLK;
+      if (t > 0) {
+        const f32x4* dqp = reinterpret_cast<const f32x4*>(dqs + ib * AB_BLK) + lane;
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const f32x4 v = dqp[(d * 4 + g) * 64];
+            dq[d][4 * g] = v.x; dq[d][4 * g + 1] = v.y; dq[d][4 * g + 2] = v.z; dq[d][4 * g + 3] = v.w;
+          }
+      } else {
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) dq[d][r] = 0.f;
+      }
+      bf16x8 dst[2];
+      {
+        s16x4 l0, h0, l1, h1;
+        asm volatile(
+            "ds_read_b64_tr_b16 %0, %4\n\t"
+            "ds_read_b64_tr_b16 %1, %5\n\t"
+            "ds_read_b64_tr_b16 %2, %4 offset:1024\n\t"
+            "ds_read_b64_tr_b16 %3, %5 offset:1024\n\t"
+            "s_waitcnt lgkmcnt(0)"
+            : "=&v"(l0), "=&v"(h0), "=&v"(l1), "=&v"(h1)
+            : "v"(ta), "v"(tb)
+            : "memory");
+        union { s16x4 hh[2]; bf16x8 bb; } u;
+        u.hh[0] = l0; u.hh[1] = h0; dst[0] = u.bb;
+        u.hh[0] = l1; u.hh[1] = h1; dst[1] = u.bb;
+      }
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {
+        dq[0] = CLIMB_MFMA_H16(kT[st][0], dst[st], dq[0], 0, 0, 0);
+        dq[1] = CLIMB_MFMA_H16(kT[st][1], dst[st], dq[1], 0, 0, 0);
+      }
+      // hipcc's hazard recognizer does not look inside inline asm: an asm ds_write that reads the registers a just-issued MFMA is still writing
+      // gets no wait states (the compiler's own ds_write gets `s_nop 11` here) and stores stale accumulators -- found as a wrong dQ only
+#pragma unroll
+      for (int d = 0; d < 2; ++d) {
+        asm volatile("s_nop 15" : "+v"(dq[d]));
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          ab1_ds_write_b128(dqa + (d * 4 + g) * 1024, f32x4{dq[d][4 * g], dq[d][4 * g + 1], dq[d][4 * g + 2], dq[d][4 * g + 3]});
+      }
+      ab1_lds_fence_barrier();
+    }
+    f32x16 dq[2];
+    {
+      const f32x4* dqp = reinterpret_cast<const f32x4*>(dqs + w * AB_BLK) + lane;
+#pragma unroll
+      for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 v = dqp[(d * 4 + g) * 64];
+          dq[d][4 * g] = v.x; dq[d][4 * g + 1] = v.y; dq[d][4 * g + 2] = v.z; dq[d][4 * g + 3] = v.w;
+        }
+    }
+    bf16_t* orow = dqkv + ((long)b * S_pad + my) * ld + h * AB_D;
+    store_acc(orow, dq, half, -scale);
+    store_acc(orow + H, accK, half, -scale);
+    store_acc(orow + 2 * H, accV, half, 1.0f);
+    // the next item's prologue overwrites lse_s / delta_s and this wave's own dQ block: its first LDS write must not pass a slower wave's last
+    // read of this item -- the step loop's final barrier already orders that (everything after it reads only the wave's own dQ block)
+  }
+  ab_wait_vm<0>();                     // no LDS DMA may outlive the workgroup's allocation
+}
+
+// climb_set_option 13: 0 = the two launches, 1 = both phases in one launch, 2 (default) = the single pass where two workgroups fit a CU (S_pad <= 128:
+// 28.2 against 33.9 us per layer at S_pad = 128, B = 64) and both phases in one launch above that, 3 / 4 = the plain / the persistent single pass
+// wherever it runs (S_pad <= 192).  Measured at the benchmark's S_pad = 192 (tools/attn_bench.py): two phases 53.9 us, single pass 60.4, persistent
+// single pass 55.9 -- 30 % fewer MFMAs, half the exponentials and 151 instead of 231 MB do NOT win there: at 208 - 241 registers and 110 - 158 KB of
+// LDS one workgroup of six waves owns the CU (1.5 waves per SIMD, two SIMDs with one wave), and a block pair is a dependent chain (fragments ->
+// S / dP -> exponentials -> turn -> four fragment round trips -> dQ read-modify-write -> barrier) that nothing else on the SIMD covers: 18 us per
+// item with its loads prefetched.  The two-phase kernel keeps nine waves per CU.  Kept as tested options and as the priced answer.
+static int g_attn_bwd_fused = 2;
 void climb_attn_set_bwd_fused(int v) { g_attn_bwd_fused = v; }
+static int g_attn_1pp_grid = 0;
+void climb_attn_set_1pp_grid(int v) { g_attn_1pp_grid = v; }
 
 extern "C" int climb_attn_bwd_bf16(const void* qkv, const float* key_bias, const void* dctx, const void* ctx, const float* lse, float* delta,
                                    void* dqkv, int B, int S_pad, int heads, int head_dim, void* stream) {
@@ -862,6 +1105,30 @@ extern "C" int climb_attn_bwd_bf16(const void* qkv, const float* key_bias, const
   // two outer blocks per wave: 64 nw >= S_pad threads (one element of the LDS vectors each) and 4 NB units over nw waves is at most 8 rounds;
   // measured at S_pad = 192: 3 waves 63 us, 6 waves 78 us per layer (register pressure: 3 workgroups x 3 waves fill the 168-VGPR budget)
   const int nthreads = 64 * ((S_pad / 32 + 1) / 2);
+  if (g_attn_bwd_fused == 4 && S_pad <= 192) {
+    const int NB = S_pad / 32, items = B * heads;
+    const size_t ldsp = (size_t)NB * (3 * AB_BLK + AB1_TURN) + (size_t)AB_VEC(S_pad) * 8;
+    static size_t ldsp_set = 0;
+    static int ncu = 0;
+    if (ldsp > ldsp_set) {
+      hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_bf16_1pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp);
+      if (e != hipSuccess) return (int)e;
+      ldsp_set = ldsp;
+    }
+    if (!ncu) {
+      int dev = 0;
+      hipDeviceProp_t prop;
+      if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return CLIMB_EINVAL;
+      ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    const int per_cu = (int)(163840 / ldsp) > 0 ? (int)(163840 / ldsp) : 1;          // resident workgroups per CU by LDS
+    int grid = g_attn_1pp_grid > 0 ? g_attn_1pp_grid : ncu * per_cu;          // (climb_set_option 20: tests walk several items per workgroup on small problems)
+    if (grid > items) grid = items;
+    hipLaunchKernelGGL(attn_bwd_bf16_1pp_kernel, dim3(grid), dim3(64 * NB), ldsp, (hipStream_t)stream, (const bf16_t*)qkv, key_bias, (const bf16_t*)dctx,
+                       (const bf16_t*)ctx, lse, (bf16_t*)dqkv, S_pad, heads, scale, items);
+    LAUNCH_CHECK();
+    return CLIMB_OK;
+  }
   if ((g_attn_bwd_fused == 2 && S_pad <= 128) || (g_attn_bwd_fused == 3 && S_pad <= 192)) {
     const int NB = S_pad / 32;
     const size_t lds1 = (size_t)NB * (2 * AB_BLK + AB1_TURN) + (size_t)AB_VEC(S_pad) * 8;

@@ -339,6 +339,7 @@ void climb_ntp_set_sw(int v);
 void climb_ntp_set_dephase(int v);
 void climb_ntsk_set_workspace(void* ptr, long bytes);
 void climb_skinny_set_probe(int v);
+void climb_attn_set_1pp_grid(int v);
 extern "C" int climb_set_option(int key, int value) {
   if (key == 1 && (value == 4 || value == 8)) { g_nt_waves = value; return CLIMB_OK; }
   if (key == 2) { g_nt_small_m = value; return CLIMB_OK; }
@@ -349,7 +350,7 @@ extern "C" int climb_set_option(int key, int value) {
   if (key == 10 && (value == 0 || value == 1)) { g_tn_p = value; return CLIMB_OK; }
   if (key == 11 && value >= 0) { climb_nt2_set_dephase(value); return CLIMB_OK; }
   if (key == 12 && value >= 0 && value <= 2) { climb_attn_set_qb(value); return CLIMB_OK; }
-  if (key == 13 && value >= 0 && value <= 3) { climb_attn_set_bwd_fused(value); return CLIMB_OK; }
+  if (key == 13 && value >= 0 && value <= 4) { climb_attn_set_bwd_fused(value); return CLIMB_OK; }
   if (key == 14 && (value == 0 || value == 1)) { climb_ntsk_enable(value); return CLIMB_OK; }
   if (key == 15 && (value == 0 || value == 1)) { climb_ntp_set_sw(value); return CLIMB_OK; }
   if (key == 16 && value >= 0 && value < 4000) { climb_ntp_set_dephase(value); return CLIMB_OK; }
@@ -357,6 +358,7 @@ extern "C" int climb_set_option(int key, int value) {
   if (key == 17 && value >= 0 && value <= 3) { climb_nt4_set(value); return CLIMB_OK; }
   if (key == 18 && value >= 0) { climb_nt4_set_probe(value); return CLIMB_OK; }
   if (key == 19 && value >= 0 && value <= 2) { climb_skinny_set_probe(value); return CLIMB_OK; }
+  if (key == 20 && value >= 0) { climb_attn_set_1pp_grid(value); return CLIMB_OK; }
   if (key == 6 && (value == 4 || value == 8)) { g_tn_waves = value; return CLIMB_OK; }
   if (key == 3 && value > 0) { g_tn_target = value; return CLIMB_OK; }
   return CLIMB_EINVAL;

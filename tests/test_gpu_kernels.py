@@ -891,9 +891,11 @@ def test_attention_bf16_forward_variants_agree(S_pad):
 
 @pytest.mark.parametrize("S_pad,valid", [(32, 32), (64, 41), (128, 128), (160, 131), (192, 185)])
 def test_attention_bf16_backward_variants_agree(S_pad, valid):
-    """The three backward kernels (climb_set_option 13: 0 = one launch per phase, 1 = both phases in one launch, 3 = the single pass that
-    computes S / dP / P / dS once per block pair and keeps dQ in LDS -- the default, 2, takes it where S_pad <= 128) against the fp64 softmax
-    backward.  0 and 1 are the same arithmetic (identical); the single pass sums dQ over key blocks in another order (close, not identical)."""
+    """The backward kernels (climb_set_option 13: 0 = one launch per phase, 1 = both phases in one launch, 3 = the single pass that computes
+    S / dP / P / dS once per block pair and keeps dQ in LDS, 4 = its persistent form that walks (batch, head) items with the next item's Q / dO
+    images prefetched -- the default, 2, takes 3 where S_pad <= 128 and 1 above) against the fp64 softmax backward.  0 and 1 are the same
+    arithmetic (identical), 3 and 4 too; the single pass sums dQ over key blocks in another order than the phases (close, not identical).
+    The persistent kernel runs on a grid of 4 workgroups here (option 20): every workgroup walks 3 - 4 items through both image buffers."""
     from climb_amd import _lib
     dev = _dev()
     B, heads, d = 3, 5, 64
@@ -913,7 +915,8 @@ def test_attention_bf16_backward_variants_agree(S_pad, valid):
     _lib.call("climb_attn_fwd_bf16", qd, bd, ctx, lse, B, S_pad, heads, d, _st())
     outs = {}
     try:
-        for mode in (0, 1, 3):
+        _lib.call("climb_set_option", 20, 4)
+        for mode in (0, 1, 3, 4):
             _lib.call("climb_set_option", 13, mode)
             delta = torch.full((B, heads, S_pad), float("nan"), device=dev)
             dqkv = torch.full((B * S_pad, 3 * H), float("nan"), device=dev, dtype=_h16())
@@ -922,8 +925,10 @@ def test_attention_bf16_backward_variants_agree(S_pad, valid):
             outs[mode] = dqkv.float().view(B, S_pad, 3 * H).cpu()
     finally:
         _lib.call("climb_set_option", 13, 2)
+        _lib.call("climb_set_option", 20, 0)
     assert torch.equal(outs[0], outs[1])
-    for mode in (1, 3):
+    assert torch.equal(outs[3], outs[4])
+    for mode in (1, 3, 4):
         assert not torch.isnan(outs[mode]).any()
         e = [_rel(outs[mode][..., k * H:(k + 1) * H], qr.grad[..., k * H:(k + 1) * H]) for k in range(3)]
         print(f"attention bwd mode {mode} S_pad={S_pad}: dq {e[0]:.2e} dk {e[1]:.2e} dv {e[2]:.2e}")

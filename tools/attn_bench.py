@@ -37,12 +37,12 @@ print(f"fwd  {t*1e6:7.1f} us  {f/t/1e12:6.1f} TF")
 t = timeit(lambda: _lib.call("climb_attn_delta", dctx, ctx, 1, delta, B, S_pad, heads, st()))
 print(f"delta {t*1e6:6.1f} us")
 outs = {}
-for fused in (3, 1, 0):       # r04: single pass (the default takes it where S_pad <= 128) / r03: both phases in one launch / one launch per phase
+for fused in (4, 3, 1, 0):    # r04: single pass, persistent / one workgroup per item (default up to S_pad = 128) / r03: both phases in one launch (default above) / one launch per phase
     _lib.call("climb_set_option", 13, fused)
     t = timeit(lambda: _lib.call("climb_attn_bwd_bf16", qkv, bias, dctx, ctx, lse, delta, dqkv, B, S_pad, heads, d, st()))
     outs[fused] = dqkv.float().clone()
-    nprod = 5 if (fused == 3 and S_pad <= 192) else 7
-    print(f"bwd  {t*1e6:7.1f} us  {nprod / 2 * f/t/1e12:6.1f} TF ({nprod} products)  {('two launches', 'one launch, two phases', '', 'single pass')[fused]}")
+    nprod = 5 if (fused >= 3 and S_pad <= 192) else 7
+    print(f"bwd  {t*1e6:7.1f} us  {nprod / 2 * f/t/1e12:6.1f} TF ({nprod} products)  {('two launches', 'one launch, two phases', '', 'single pass', 'single pass, persistent')[fused]}")
 _lib.call("climb_set_option", 13, 2)
 d21 = (outs[3] - outs[1]).norm() / outs[1].norm()
-print(f"single pass vs two-phase: relative L2 difference {d21:.2e} (different summation order of the 16-bit products)")
+print(f"single pass vs two-phase: relative L2 difference {d21:.2e} (different summation order of the 16-bit products); persistent == plain single pass: {bool(torch.equal(outs[4], outs[3]))}")
