@@ -115,3 +115,8 @@ def call(name: str, *args):
 
 def query(name: str) -> int:
     return getattr(load(), name)()
+
+
+def query_arg(name: str, *args) -> int:
+    """an `int f(int, ...)` entry point whose return value is the answer, not an error code (climb_get_option)"""
+    return int(getattr(load(), name)(*args))

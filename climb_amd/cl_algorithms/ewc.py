@@ -107,7 +107,8 @@ class EWC:
         _lib.call("climb_scale", fisher, n, 1.0 / max(1, num_samples_completed), torch.cuda.current_stream().cuda_stream)
         if world > 1:
             import torch.distributed as dist
-            dist.broadcast(fisher, src=0)
+            pg = getattr(host.ddp, "pg", None)          # the reducer's group, not WORLD: a job may run several replicas' groups side by side
+            dist.broadcast(fisher, src=dist.get_global_rank(pg, 0) if pg is not None else 0, group=pg)
         self.fisher_flat[task_key] = fisher
         self.fisher_dict[task_key] = _views(fisher, eng)
         self.param_dict[task_key] = _views(self.param_flat[task_key], eng)

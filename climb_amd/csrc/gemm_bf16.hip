@@ -339,7 +339,10 @@ void climb_ntp_set_sw(int v);
 void climb_ntp_set_dephase(int v);
 void climb_ntsk_set_workspace(void* ptr, long bytes);
 void climb_skinny_set_probe(int v);
+int climb_nt256_get_grid();
 void climb_attn_set_1pp_grid(int v);
+// current value of a library option (only the ones a caller has to put back: 9 = persistent NT grid); -1 = not readable
+extern "C" int climb_get_option(int key) { return key == 9 ? climb_nt256_get_grid() : -1; }
 extern "C" int climb_set_option(int key, int value) {
   if (key == 1 && (value == 4 || value == 8)) { g_nt_waves = value; return CLIMB_OK; }
   if (key == 2) { g_nt_small_m = value; return CLIMB_OK; }

@@ -534,6 +534,7 @@ static int ntsk_try(const bf16_t* A, long lda, const bf16_t* B, long ldb, void* 
 
 void climb_nt256_set_probe(int v) { g_nt256_probe = v; }      // bit 0: k-loop only; v >> 8: supertile height override (measurement)
 void climb_nt256_set_grid(int v) { g_nt256_grid = v; }
+int climb_nt256_get_grid() { return g_nt256_grid; }
 
 // MEASURED (r03, M = 12288, same box): QKV 51.6 -> 57.2 us, up-projection + GELU 82.4 -> 93.3 us, step 10.51 -> 10.71 ms.  The stores do
 // leave the loading waves' vmcnt, but (i) waves 4-7 now drain two regions each while waves 0-3 idle at the barriers (the k-buffers ARE the

@@ -716,10 +716,14 @@ class ViltEngine:
         n = max(0, int(n))
         if n == self._cu_reserve:
             return
-        self._cu_reserve = n
         if self.precision == "bf16":
-            ncu = torch.cuda.get_device_properties(self.device).multi_processor_count
-            _lib.call("climb_set_option", 9, max(8, (ncu - n) // 8 * 8))        # persistent NT grid (a library-wide setting)
+            # the persistent NT grid is a library-wide setting: remember what was in force before the FIRST reserve (the library default, or a grid
+            # pinned through CLIMB_AMD_OPTIONS / tools) and put exactly that back with n = 0
+            if self._cu_reserve == 0:
+                self._nt_grid_before_reserve = int(_lib.query_arg("climb_get_option", 9))
+            base = self._nt_grid_before_reserve
+            _lib.call("climb_set_option", 9, base if n == 0 else max(8, (base - n) // 8 * 8))
+        self._cu_reserve = n
 
     def _dw_defer(self, pending: list, dY, X, wname, M, N, K, bname=None, ws=None):
         """linear_dw, but recorded for the group's launch when the shape fits its 256 x 256 tiles (else run now)."""

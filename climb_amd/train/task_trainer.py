@@ -189,7 +189,7 @@ class VLTaskTrainer(TaskTrainer):
     def eval_forgetting(self, model, model_path: str) -> float:
         parallel.barrier()                    # rank 0 wrote the checkpoint (parallel.rank0_only_io); nobody reads it before it is complete
         model.to(self.device)
-        model.load_state_dict(torch.load(model_path))
+        model.load_state_dict(torch.load(model_path, map_location=self.device))      # (rank 0 saved from cuda:0: without map_location every rank would stage the checkpoint there)
         return self.eval(model)
 
 

@@ -50,6 +50,7 @@ def install_fake_c_abi():
     _lib.load = lambda: None
     _lib.call = fake_call
     _lib.query = lambda name: 32
+    _lib.query_arg = lambda name, *a: 256
     # everything ViltEngine asks the library about itself (r02's fp16 build added these).  tests/test_dp_training.py (a CPU test) runs whole
     # driver scenarios -- engines constructed, fused steps, plug-ins -- on this stand-in, so the recorder cannot silently rot again when the
     # host code grows another query
