@@ -244,3 +244,47 @@ extern "C" int climb_layernorm_gelu_fwd(const float* x, long ldx, const float* g
   LAUNCH_CHECK();
   return CLIMB_OK;
 }
+
+// Rank-M weight-gradient updates of the pooler and the heads (M = batch rows): C[n, k] += sum_m dY[m, n] * X[m, k].  climb_gemm_f32 walks the
+// 64 rows in four 16-deep trips (load, LDS, barrier, MFMA: 29 us for the 3129 x 1536 update); here a 64 x 64 tile's operands go global -> registers
+// in ONE round trip (for a fixed m both operands are contiguous along the lanes: coalesced 128-byte loads, 32 + 32 dwords per lane for 64 rows) and
+// straight into v_mfma_f32_32x32x2_f32; the tile is then read-modified-written once.  Exact fp32, one fixed summation order.
+__global__ __launch_bounds__(256) void rank_update_f32_kernel(const float* __restrict__ dY, long lddy, const float* __restrict__ X, long ldx, float* __restrict__ C,
+                                                               long ldc, int M, int N, int K) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, half = lane >> 5, l31 = lane & 31;
+  const int n0 = blockIdx.y * 64 + (w >> 1) * 32, k0 = blockIdx.x * 64 + (w & 1) * 32;
+  const int n = n0 + l31, k = k0 + l31;
+  const bool nok = n < N, kok = k < K;
+  const float* yp = dY + (nok ? n : 0);
+  const float* xp = X + (kok ? k : 0);
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int m0 = 0; m0 < M; m0 += 64) {
+    float a[32], b[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      const int m = m0 + 2 * i + half;
+      const int mc = m < M ? m : M - 1;
+      a[i] = yp[(long)mc * lddy];
+      b[i] = xp[(long)mc * ldx];
+    }
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      const bool mok = m0 + 2 * i + half < M;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32((mok && nok) ? a[i] : 0.f, (mok && kok) ? b[i] : 0.f, acc, 0, 0, 0);
+    }
+  }
+  if (!kok) return;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int nn = n0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+    if (nn < N) C[(long)nn * ldc + k] += acc[r];
+  }
+}
+extern "C" int climb_rank_update_f32(const float* dY, long lddy, const float* X, long ldx, float* C, long ldc, int M, int N, int K, void* stream) {
+  if (M <= 0 || N <= 0 || K <= 0 || !dY || !X || !C) return CLIMB_EINVAL;
+  hipLaunchKernelGGL(rank_update_f32_kernel, dim3((K + 63) / 64, (N + 63) / 64), dim3(256), 0, (hipStream_t)stream, dY, lddy, X, ldx, C, ldc, M, N, K);
+  LAUNCH_CHECK();
+  return CLIMB_OK;
+}

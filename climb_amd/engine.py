@@ -327,6 +327,13 @@ class ViltEngine:
         self._timed_call("gemm_f32", 2.0 * M * N * K, "climb_gemm_f32", A, sam, sak, Bm, sbn, sbk, C, ldc, M, N, K, bias, epi, aux, ldaux, aux_out,
                          ldauxo, beta, aux2, ldaux2, 1 if self.precision == "bf16" else 0, _stream())
 
+    def _rank_update(self, dY, lddy, X, ldx, wname, M, N, K):
+        """grad(W)[N, K] += dY[M, N]^T X[M, K] for M = batch rows (csrc/heads.hip); exact fp32"""
+        if SKINNY:
+            self._timed_call("skinny_f32", 2.0 * M * N * K, "climb_rank_update_f32", dY, lddy, X, ldx, self.g(wname), K, M, N, K, _stream())
+        else:
+            self._gemm_f32(dY, 1, lddy, X, 1, ldx, self.g(wname), K, N, K, M, beta=1.0)
+
     def _skinny(self, A, lda, B, sbn, sbk, C, ldc, M, N, K, bias=None, epi=0, aux=None, ldaux=0, colsum=None, acol=None):
         """csrc/heads.hip: C = epi(A B^T + bias) for M = batch rows; colsum / acol: parameter-gradient pointers that the column sums of C / of A are
         ADDED to (the bias gradients on either side of the product)."""
@@ -895,7 +902,7 @@ class ViltEngine:
             _lib.call("climb_elementwise", 2, dpooled, ws.pooled, dpre, B * H, 1.0, st)
         pw, pb = ENC + "pooler.dense.weight", ENC + "pooler.dense.bias"
         if rg[pw]:
-            self._gemm_f32(dpre, 1, H, ws.clsn, 1, H, self.g(pw), H, H, H, B, beta=1.0)
+            self._rank_update(dpre, H, ws.clsn, H, pw, B, H, H)
         if SKINNY and B <= 64:           # d(clsn) = dpre Wp, and the bias gradient = the column sums of its A operand, in the same launch
             self._skinny(dpre, H, self.p(pw), 1, H, ws.dclsn, H, B, H, H, acol=self.g(pb) if rg[pb] else None)
         else:
@@ -1182,7 +1189,7 @@ class ViltEngine:
             hb = hs.buf
             ones = hb["ones"]
             if rg[h + "3.weight"]:
-                self._gemm_f32(dlogits, 1, ldl, hs.gz, 1, D, self.g(h + "3.weight"), D, NL, D, Bh, beta=1.0)
+                self._rank_update(dlogits, ldl, hs.gz, D, h + "3.weight", Bh, NL, D)
             if SKINNY and Bh <= 64 and ldl % 4 == 0:
                 # r04 (csrc/heads.hip): 5 launches instead of 13 -- d(zn) = (dlogits W3) gelu'(zn) with d(b3) = colsum(dlogits) from the same launch; the
                 # LayerNorm backward's third partial sum IS d(b0); d(x) = dz W0 (x (1 - pooled^2) when the pooler's output is what the head consumed)
@@ -1193,7 +1200,7 @@ class ViltEngine:
                 _lib.call("climb_layernorm_bwd", dzn, D, F32, hs.z, D, hs.mean, hs.rstd, self.p(h + "1.weight"), None, 0, dz, D, None, 0, part, Bh, D, st)
                 self.reduce3(part, (Bh + lnb - 1) // lnb, D, h + "1.weight", h + "1.bias", h + "0.bias")
                 if rg[h + "0.weight"]:
-                    self._gemm_f32(dz, 1, D, hs.x, 1, Kin, self.g(h + "0.weight"), Kin, D, Kin, Bh, beta=1.0)
+                    self._rank_update(dz, D, hs.x, Kin, h + "0.weight", Bh, D, Kin)
                 fuse_tanh = dtanh_of is not None and dtanh_of.numel() == Bh * Kin and dtanh_of.is_contiguous()
                 self._skinny(dz, D, self.p(h + "0.weight"), 1, Kin, dx, Kin, Bh, Kin, D, epi=2 if fuse_tanh else 0, aux=dtanh_of if fuse_tanh else None, ldaux=Kin)
                 hs.dx_is_dpre = fuse_tanh

@@ -103,6 +103,8 @@ int climb_gemm_f32(const float* A, long sam, long sak, const float* B, long sbn,
  * acol != NULL (M <= 64): acol[k] = acol_beta * acol[k] + sum_m A[m,k] (the bias gradient of the layer that produced A).  lda % 4 == 0. */
 int climb_skinny_f32(const float* A, long lda, const float* B, long sbn, long sbk, float* C, long ldc, int M, int N, int K, const float* bias, int epi, const float* aux, long ldaux, float* colsum, float colsum_beta, float* acol, float acol_beta, void* stream);
 
+/* weight gradient of a head / pooler linear for M = batch rows (REF/modeling/vilt.py:190-195 backward): C[n,k] (ldc) += sum_m dY[m,n] * X[m,k], exact fp32 */
+int climb_rank_update_f32(const float* dY, long lddy, const float* X, long ldx, float* C, long ldc, int M, int N, int K, void* stream);
 /* REF/modeling/vilt.py:191-193 (head LayerNorm, eps 1e-5, then GELU): zn = LN(x), gz = gelu(zn), both [M, C] fp32 with leading dim ldy; C <= 1536 */
 int climb_layernorm_gelu_fwd(const float* x, long ldx, const float* gamma, const float* beta, float eps, float* zn, float* gz, long ldy, float* mean, float* rstd, int M, int C, void* stream);
 

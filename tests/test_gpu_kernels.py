@@ -469,6 +469,27 @@ def test_skinny_f32_products_of_the_heads(M, N, K, kcontig, epi):
             _lib.call("climb_skinny_f32", Ad, lda, Wd, sbn, sbk, C.to(dev), N + 3, M, N, K, bd, 0, None, 0, cs0.to(dev), 1.0, None, 1.0, _st())
 
 
+@pytest.mark.parametrize("M,N,K", [(64, 3129, 1536), (64, 1536, 768), (32, 768, 768), (5, 70, 33), (100, 130, 64)])
+def test_rank_update_f32_weight_gradients_of_the_heads(M, N, K):
+    """C[n, k] += sum_m dY[m, n] X[m, k] (csrc/heads.hip) against float64, added onto what C held, ragged tiles, more than 64 rows, strided operands;
+    nothing is written outside the N x K block; two launches from the same start give identical bits."""
+    from climb_amd import _lib
+    dev = _dev()
+    g = torch.Generator().manual_seed(M + N + K)
+    lddy, ldx, ldc = N + 3, K + 1, K + 2
+    dY = torch.randn(M, lddy, generator=g)
+    X = torch.randn(M, ldx, generator=g)
+    C0 = torch.randn(N, ldc, generator=g)
+    ref = C0[:, :K].double() + dY[:, :N].double().t() @ X[:, :K].double()
+    outs = []
+    for _ in range(2):
+        C = C0.to(dev)
+        _lib.call("climb_rank_update_f32", dY.to(dev), lddy, X.to(dev), ldx, C, ldc, M, N, K, _st())
+        outs.append(C.cpu())
+    assert _rel(outs[0][:, :K], ref) < 3e-6
+    assert torch.equal(outs[0][:, K:], C0[:, K:]) and torch.equal(outs[0], outs[1])
+
+
 def test_layernorm_gelu_forward_of_the_head():
     """zn = LayerNorm(z) and gz = gelu(zn) in one pass (REF/modeling/vilt.py:191-193) = climb_layernorm_fwd followed by the gelu pass, bit for bit"""
     from climb_amd import _lib
