@@ -59,27 +59,35 @@ extern "C" int climb_adamw(float* p, const float* g, float* m, float* v, void* s
 
 // r04: the same update over the ACTIVE spans of the flat buffer only.  Since the weight matrices are updated in the epilogue of the grouped
 // weight-gradient launch (gemm_bf16_tnp.hip), three quarters of the buffer are skipped tensors; adamw_kernel still walked them (a binary search
-// per 4 elements: 290 us for 0.9 GB of real work).  spans[3 i .. 3 i + 2] = { first element, elements, first block } of span i (maximal runs of
+// per 4 elements: 290 us for 0.9 GB of real work).  spans[4 i .. 4 i + 3] = { first element, elements, first block, gradient source } of span i (maximal runs of
 // tensors with a group, in 1024-element blocks); a workgroup looks its span up once per block.  ZERO: the gradient is cleared as it is consumed, so
 // the step leaves the gradient buffer all zeros and the next zero_grad() has nothing to do (engine._grad_clean).
+// Data parallel (r04): a span flagged in spans[4 i + 3] takes its gradient from `g16` -- the reducer's 16-bit staging buffer, laid out like the
+// gradient buffer, holding the all-reduced payload -- times g16_scale (the averaging factor / loss scale the un-cast pass used to apply): that pass
+// (2 B read + 4 B written per parameter) and the 4 B read of its result disappear.  Same product, same rounding as un-cast followed by this kernel.
 template <bool SHADOW, bool ZERO>
 __global__ __launch_bounds__(256) void adamw_spans_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                                           bf16_t* __restrict__ shadow, const long* __restrict__ spans, int nspans, long nblocks,
                                                           const long* __restrict__ seg_start, const signed char* __restrict__ seg_group, int nseg,
-                                                          AdamGroups groups, float gscale) {
+                                                          AdamGroups groups, float gscale, const bf16_t* __restrict__ g16, float g16_scale) {
   for (long b = blockIdx.x; b < nblocks; b += gridDim.x) {
     int lo = 0, hi = nspans - 1;                     // last span whose first block is <= b
     while (lo < hi) {
       const int mid = (lo + hi + 1) >> 1;
-      if (spans[3 * mid + 2] <= b) lo = mid; else hi = mid - 1;
+      if (spans[4 * mid + 2] <= b) lo = mid; else hi = mid - 1;
     }
-    const long start = spans[3 * lo], len = spans[3 * lo + 1], off = (b - spans[3 * lo + 2]) * 1024 + threadIdx.x * 4;
+    const long start = spans[4 * lo], len = spans[4 * lo + 1], off = (b - spans[4 * lo + 2]) * 1024 + threadIdx.x * 4;
+    const bool from16 = spans[4 * lo + 3] != 0;
     if (off >= len) continue;
     const long e = start + off;
     const int sg = seg_group[find_seg(seg_start, nseg, e)];
     if (sg < 0) continue;
     const AdamGroup G = groups.g[sg];
-    float4 pp = ld4(p + e), gg = ld4(g + e), mm = ld4(m + e), vv = ld4(v + e);
+    float4 pp = ld4(p + e), gg, mm = ld4(m + e), vv = ld4(v + e);
+    if (from16) {
+      gg = ld4(g16 + e);
+      gg.x *= g16_scale; gg.y *= g16_scale; gg.z *= g16_scale; gg.w *= g16_scale;
+    } else gg = ld4(g + e);
     float pa[4] = {pp.x, pp.y, pp.z, pp.w}, ga[4] = {gg.x, gg.y, gg.z, gg.w}, ma[4] = {mm.x, mm.y, mm.z, mm.w}, va[4] = {vv.x, vv.y, vv.z, vv.w};
     const float isb2 = rsqrtf(G.bc2), step = G.lr / G.bc1;
 #pragma unroll
@@ -94,7 +102,7 @@ __global__ __launch_bounds__(256) void adamw_spans_kernel(float* __restrict__ p,
 
 extern "C" int climb_adamw_spans(float* p, float* g, float* m, float* v, void* shadow_bf16, const long* spans, int nspans, long nblocks,
                                  const long* seg_start, const signed char* seg_group, int nseg, const float* groups, int ngroups, float gscale,
-                                 int zero_grad, void* stream) {
+                                 int zero_grad, const void* g16, float g16_scale, void* stream) {
   if (nspans <= 0 || nblocks <= 0 || nseg <= 0 || ngroups <= 0 || ngroups > 8 || !spans) return CLIMB_EINVAL;
   AdamGroups G;
   for (int i = 0; i < 8; ++i) {
@@ -104,7 +112,7 @@ extern "C" int climb_adamw_spans(float* p, float* g, float* m, float* v, void* s
   dim3 grid((unsigned)(nblocks < 16384 ? nblocks : 16384)), blk(256);
 #define ADAMW_SPANS(S_, Z_)                                                                                                                          \
   hipLaunchKernelGGL((adamw_spans_kernel<S_, Z_>), grid, blk, 0, (hipStream_t)stream, p, g, m, v, (bf16_t*)shadow_bf16, spans, nspans, nblocks, seg_start, \
-                     seg_group, nseg, G, gscale)
+                     seg_group, nseg, G, gscale, (const bf16_t*)g16, g16_scale)
   if (shadow_bf16) { if (zero_grad) ADAMW_SPANS(true, true); else ADAMW_SPANS(true, false); }
   else             { if (zero_grad) ADAMW_SPANS(false, true); else ADAMW_SPANS(false, false); }
 #undef ADAMW_SPANS

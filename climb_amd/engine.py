@@ -199,6 +199,7 @@ class ViltEngine:
         self._dw_deferred = []          # [(ws, plan)]
         self._grad_extra = False        # the weight matrices' gradient ranges hold something besides zeros (EWC penalty term, an earlier backward)
         self._grad_clean = False        # set by FusedAdamW.step() when it leaves the gradient buffer all zeros; any backward clears it (before_backward)
+        self._g16 = None                # data parallel: {stage, scale, ranges}: averaged gradients that still live in the reducer's 16-bit payload buffer
         self._unscale_pending = self._prescaled = False
         self.layout = layout
         self.cfg = layout.cfg
@@ -265,10 +266,19 @@ class ViltEngine:
         if not self._grad_clean:
             self.grad.zero_()
         self._grad_clean = False
+        self._g16 = None
         self.touched = []
         self._grad_dirty = False
         self._dw_deferred = []          # gradients nobody asked for are never computed
         self._grad_extra = False
+
+    def materialize_g16(self):
+        """Cast averaged gradients the data-parallel reducer left in its 16-bit payload buffer (GradientAllReducer.finish(defer_uncast=True)) back into
+        the fp32 gradient buffer: what finish() does itself when nobody promised that FusedAdamW.step() is the next reader."""
+        pend, self._g16 = self._g16, None
+        if pend:
+            for lo, hi in pend["ranges"]:
+                _lib.call("climb_uncast_bf16_scale", pend["stage"][lo:hi], self.grad[lo:hi], hi - lo, pend["scale"], _stream())
 
     def materialize_dw(self):
         """Run weight-gradient launches that were held back for the optimizer as the plain launches they replace (C += dW)."""

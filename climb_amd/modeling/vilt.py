@@ -215,6 +215,8 @@ class _EngineHost:
                         eng.zero_grad()
                     break
         eng._grad_clean = False          # gradients are about to be written
+        if eng._g16 is not None:         # (a backward on top of averaged gradients nobody consumed: they belong in the buffer this one accumulates into)
+            eng.materialize_g16()
 
     def after_backward(self):
         """`.grad` of every parameter that received a gradient aliases its slice of the flat buffer; the others stay
@@ -588,11 +590,16 @@ class ViltContinualLearner(ContinualLearner):
         host = self._host
         eng = host.engine()
         from ..optim import FusedAdamW
-        eng.defer_dw = bool(isinstance(optimizer, FusedAdamW) and optimizer._host is host and host.ddp is None and os.environ.get("CLIMB_AMD_FUSED_ADAMW", "1") != "0")
+        promised = isinstance(optimizer, FusedAdamW) and optimizer._host is host
+        eng.defer_dw = bool(promised and host.ddp is None and os.environ.get("CLIMB_AMD_FUSED_ADAMW", "1") != "0")
+        # data parallel: with the same promise the averaged 16-bit payload is not cast back into the gradient buffer; FusedAdamW.step() reads it in place
+        # (not when an EWC term has to be ADDED to the averaged gradients: that needs them in fp32)
+        self._defer_uncast = bool(promised and host.ddp is not None and not (ewc is not None and ewc.do_ewc()))
         try:
             return self._fused_forward_backward(task_key, images, texts, target, ewc, dropout_keep, grad_weight)
         finally:
             eng.defer_dw = False
+            self._defer_uncast = False
 
     def _fused_forward_backward(self, task_key: str, images, texts, target: torch.Tensor, ewc=None, dropout_keep=None, grad_weight: float = 1.0):
         host = self._host
@@ -624,7 +631,7 @@ class ViltContinualLearner(ContinualLearner):
         eng.saved = None           # (also when the encoder is frozen and its backward never ran)
         eng.finish_scaled_backward()
         if host.ddp is not None:
-            host.ddp.finish()
+            host.ddp.finish(defer_uncast=bool(getattr(self, "_defer_uncast", False)))
         ewc_task, ewc_loss = None, None
         if ewc is not None and ewc.do_ewc():
             ewc_task, ewc_loss = ewc.add_penalty_gradient(self)

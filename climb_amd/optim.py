@@ -37,6 +37,7 @@ class FusedAdamW(torch.optim.Optimizer):
             self._seg_start = torch.from_numpy(starts).to(eng.device)
             self._seg_start_host = starts
             self._spans, self._nspans, self._nblocks = None, 0, 0
+            self._g16_ranges = ()
             self._seg_group = torch.full((len(segs),), -1, dtype=torch.int8, device=eng.device)
             self._seg_group_host = None
             by_id = {id(p): n for n, p in self._host._params.items()}
@@ -101,18 +102,29 @@ class FusedAdamW(torch.optim.Optimizer):
                     seg_group[idx[n]] = -1
             else:
                 eng.materialize_dw()
-        if self._seg_group_host is None or not np.array_equal(seg_group, self._seg_group_host):
-            self._seg_group.copy_(torch.from_numpy(seg_group))
-            self._seg_group_host = seg_group
-            # maximal runs of tensors the flat pass updates, as { first element, elements, first 1024-element block } (csrc/optim.hip::adamw_spans_kernel)
+        g16 = eng._g16                 # data parallel: averaged gradients still in the reducer's 16-bit payload buffer (parallel.finish(defer_uncast=True))
+        g16_ranges = tuple(g16["ranges"]) if g16 else ()
+        if self._seg_group_host is None or not np.array_equal(seg_group, self._seg_group_host) or g16_ranges != self._g16_ranges:
+            if self._seg_group_host is None or not np.array_equal(seg_group, self._seg_group_host):
+                self._seg_group.copy_(torch.from_numpy(seg_group))
+                self._seg_group_host = seg_group
+            self._g16_ranges = g16_ranges
+            # maximal runs of tensors the flat pass updates, as { first element, elements, first 1024-element block, gradient source } (csrc/optim.hip::
+            # adamw_spans_kernel); a run is cut where it crosses into / out of a range whose gradient lives in the 16-bit payload buffer (source 1)
             starts = self._seg_start_host
-            spans, nb = [], 0
+            runs = []
             for si in np.flatnonzero(seg_group >= 0):
                 a, b = int(starts[si]), int(starts[si + 1])
-                if spans and spans[-1][0] + spans[-1][1] == a:
-                    spans[-1][1] += b - a
+                if runs and runs[-1][1] == a:
+                    runs[-1][1] = b
                 else:
-                    spans.append([a, b - a, 0])
+                    runs.append([a, b])
+            spans, nb = [], 0
+            for a, b in runs:
+                cuts = sorted({a, b} | {x for lo, hi in g16_ranges for x in (lo, hi) if a < x < b})
+                for c0, c1 in zip(cuts[:-1], cuts[1:]):
+                    src = int(any(lo <= c0 and c1 <= hi for lo, hi in g16_ranges))
+                    spans.append([c0, c1 - c0, 0, src])
             for sp in spans:
                 sp[2] = nb
                 nb += (sp[1] + 1023) // 1024
@@ -133,7 +145,9 @@ class FusedAdamW(torch.optim.Optimizer):
                     break
         if self._nspans:
             _lib.call("climb_adamw_spans", eng.flat, eng.grad, self._m, self._v, shadow, self._spans, self._nspans, self._nblocks, self._seg_start,
-                      self._seg_group, len(self._seg_names), table.ctypes.data, len(combos), 1.0, 1 if clean else 0, torch.cuda.current_stream().cuda_stream)
+                      self._seg_group, len(self._seg_names), table.ctypes.data, len(combos), 1.0, 1 if clean else 0,
+                      g16["stage"] if g16 else None, g16["scale"] if g16 else 1.0, torch.cuda.current_stream().cuda_stream)
+        eng._g16 = None                # consumed
         eng._grad_clean = clean
         eng.params_updated(shadow_fresh=shadow is not None, t_fresh=fused)
         return loss

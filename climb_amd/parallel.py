@@ -44,6 +44,9 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+_DEFER_UNCAST = os.environ.get("CLIMB_AMD_DP_DEFER_UNCAST", "1") != "0"      # A/B knob: 0 = always cast the averaged payload back into the gradient buffer
+
+
 def _cast_to_bf16(dst: torch.Tensor, src: torch.Tensor):
     if src.is_cuda:
         _lib.call("climb_cast_bf16", src, dst, src.numel(), _stream())
@@ -241,10 +244,15 @@ class GradientAllReducer:
             if sum(b - a for a, b in self._small) >= self.min_bucket:
                 self._flush_small()
 
-    def finish(self):
-        """Block the compute stream on every outstanding collective (no host sync on RCCL) and put the averaged gradients back."""
+    def finish(self, defer_uncast: bool = False):
+        """Block the compute stream on every outstanding collective (no host sync on RCCL) and put the averaged gradients back.
+        `defer_uncast` (r04; the fused step passes it when the caller named its FusedAdamW as the next reader of the gradients and no EWC term has to
+        be added to them): contiguous ranges that went through the 16-bit staging buffer are NOT cast back -- the engine is told where the averaged
+        payload lives (`eng._g16`) and the optimizer's flat pass reads it from there with the scale folded in (`climb_adamw_spans`), so the un-cast
+        pass (6 B per parameter) and the fp32 re-read disappear.  Anything else that wants those gradients calls `eng.materialize_g16()` first."""
         if not self.enabled:
             return
+        pending16 = []
         self._in_finish = True
         try:
             for lo, hi in self._deferred:
@@ -271,9 +279,14 @@ class GradientAllReducer:
             else:
                 lo, hi = ranges[0]
                 if self.h16_payload:
-                    _uncast_scaled(self.eng.grad[lo:hi], self._stage[lo:hi], scale)
+                    if defer_uncast and self._stage.is_cuda and _DEFER_UNCAST:
+                        pending16.append((lo, hi))
+                    else:
+                        _uncast_scaled(self.eng.grad[lo:hi], self._stage[lo:hi], scale)
                 else:
                     _scale(self.eng.grad[lo:hi], scale)
+        if pending16:
+            self.eng._g16 = dict(stage=self._stage, scale=float(scale), ranges=sorted(pending16))
         self._works.clear()
         self._reserve(False)            # nothing of RCCL's is on the chip any more: the persistent grids take every CU again
         self._packs_used = 0            # every collective was waited for: the pack buffers are free (also on paths that never call begin())

@@ -135,10 +135,11 @@ int climb_cross_entropy(const float* logits, long ldl, const long* labels, float
  * {lr, wd, beta1, beta2, eps, 1-beta1^t, 1-beta2^t, 0}.  Optionally refreshes the bf16 weight shadow in the same pass. */
 int climb_adamw(float* p, const float* g, float* m, float* v, void* shadow_bf16, long n, const long* seg_start, const signed char* seg_group, int nseg, const float* groups, int ngroups, float gscale, void* stream);
 /* r04: the same update over the ACTIVE spans of the flat buffer only (tensors the grouped weight-gradient launch updated in its epilogue, frozen
- * or untouched tensors are not walked).  spans (device) = nspans x { first element, elements, first 1024-element block }, ascending; nblocks = blocks
- * of all spans; seg_start / seg_group / groups as above.  zero_grad != 0: every gradient element it consumes is cleared (the optimizer.zero_grad()
- * of REF/train/visionlanguage_tasks/train_vqa.py:168-172 folded into the pass). */
-int climb_adamw_spans(float* p, float* g, float* m, float* v, void* shadow_bf16, const long* spans, int nspans, long nblocks, const long* seg_start, const signed char* seg_group, int nseg, const float* groups, int ngroups, float gscale, int zero_grad, void* stream);
+ * or untouched tensors are not walked).  spans (device) = nspans x { first element, elements, first 1024-element block, source }, ascending; nblocks =
+ * blocks of all spans; seg_start / seg_group / groups as above.  zero_grad != 0: every gradient element it consumes is cleared (the
+ * optimizer.zero_grad() of REF/train/visionlanguage_tasks/train_vqa.py:168-172 folded into the pass).  A span with source != 0 reads its gradient
+ * from g16 (the data-parallel reducer's 16-bit payload buffer, laid out like g) times g16_scale instead of from g. */
+int climb_adamw_spans(float* p, float* g, float* m, float* v, void* shadow_bf16, const long* spans, int nspans, long nblocks, const long* seg_start, const signed char* seg_group, int nseg, const float* groups, int ngroups, float gscale, int zero_grad, const void* g16, float g16_scale, void* stream);
 /* REF/cl_algorithms/ewc.py:75-87: loss_out = lam*sum F (theta-theta*)^2; grad += gscale*2*lam*F*(theta-theta*) if grad != NULL */
 int climb_ewc_penalty(const float* theta, const float* star, const float* fisher, float* grad, long n, float lam, float gscale, float* partials, float* loss_out, void* stream);
 int climb_ewc_workspace_floats(void);

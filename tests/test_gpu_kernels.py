@@ -508,11 +508,13 @@ def test_layernorm_gelu_forward_of_the_head():
         assert _rel(gz, ref) < 3e-6
 
 
-@pytest.mark.parametrize("zero", [0, 1])
-def test_adamw_spans_equals_the_flat_pass(zero):
+@pytest.mark.parametrize("zero,from16", [(0, False), (1, False), (0, True)])
+def test_adamw_spans_equals_the_flat_pass(zero, from16):
     """r04: climb_adamw_spans walks only the maximal runs of tensors that have a group (spans in 1024-element blocks, ragged ends, a span of
     several tensors with different groups) and must update them bit for bit like climb_adamw; tensors outside the spans keep p, m, v AND g;
-    with zero_grad = 1 the consumed gradients are cleared, nothing else is."""
+    with zero_grad = 1 the consumed gradients are cleared, nothing else is.  from16: one span takes its gradient from a 16-bit payload buffer
+    times a scale (the data-parallel reducer's averaged payload) -- the same bits as casting that payload back with climb_uncast_bf16_scale and
+    running the flat pass."""
     from climb_amd import _lib
     dev = _dev()
     g = torch.Generator().manual_seed(5 + zero)
@@ -524,24 +526,35 @@ def test_adamw_spans_equals_the_flat_pass(zero):
     p0, g0 = torch.randn(n, generator=g), torch.randn(n, generator=g) * 0.1
     m0, v0 = torch.rand(n, generator=g) * 0.01, torch.rand(n, generator=g) * 0.001
     d_starts, d_groups = torch.from_numpy(starts).to(dev), torch.from_numpy(groups).to(dev)
-    ref = [t.to(dev).clone() for t in (p0, g0, m0, v0)]
-    sh_ref = torch.zeros(n, device=dev, dtype=_h16())
-    _lib.call("climb_adamw", ref[0], ref[1], ref[2], ref[3], sh_ref, n, d_starts, d_groups, len(sizes), table.ctypes.data, 2, 1.0, _st())
     spans, nb = [], 0
     for si in np.flatnonzero(groups >= 0):
         a, b = int(starts[si]), int(starts[si + 1])
         if spans and spans[-1][0] + spans[-1][1] == a:
             spans[-1][1] += b - a
         else:
-            spans.append([a, b - a, 0])
+            spans.append([a, b - a, 0, 0])
+    assert len(spans) == 3 and spans[1][1] == 64 * 18          # tensors 2 and 3 (different groups) form one span
+    stage, scale16 = None, 1.0
+    gref = g0.clone()
+    if from16:          # the middle span's gradient lives in the payload buffer: cut it in two (only the first part from there) to walk a source boundary
+        a, ln = spans[1][0], spans[1][1]
+        cut = a + 64 * 5
+        spans[1:2] = [[a, cut - a, 0, 1], [cut, a + ln - cut, 0, 0]]
+        stage = (torch.randn(n, generator=g) * 0.1).to(_h16()).to(dev)
+        scale16 = 0.5
+        tmp = torch.zeros(n, device=dev)
+        _lib.call("climb_uncast_bf16_scale", stage[a:cut], tmp[a:cut], cut - a, scale16, _st())
+        gref[a:cut] = tmp[a:cut].cpu()
     for sp in spans:
         sp[2] = nb
         nb += (sp[1] + 1023) // 1024
-    assert len(spans) == 3 and spans[1][1] == 64 * 18          # tensors 2 and 3 (different groups) form one span
+    ref = [t.to(dev).clone() for t in (p0, gref, m0, v0)]
+    sh_ref = torch.zeros(n, device=dev, dtype=_h16())
+    _lib.call("climb_adamw", ref[0], ref[1], ref[2], ref[3], sh_ref, n, d_starts, d_groups, len(sizes), table.ctypes.data, 2, 1.0, _st())
     out = [t.to(dev).clone() for t in (p0, g0, m0, v0)]
     sh = torch.zeros(n, device=dev, dtype=_h16())
     _lib.call("climb_adamw_spans", out[0], out[1], out[2], out[3], sh, torch.tensor(spans, dtype=torch.int64, device=dev).reshape(-1), len(spans), nb,
-              d_starts, d_groups, len(sizes), table.ctypes.data, 2, 1.0, zero, _st())
+              d_starts, d_groups, len(sizes), table.ctypes.data, 2, 1.0, zero, stage, scale16, _st())
     for a, b in ((out[0], ref[0]), (out[2], ref[2]), (out[3], ref[3]), (sh, sh_ref)):
         assert torch.equal(a, b)
     gexp = g0.clone()
@@ -550,7 +563,7 @@ def test_adamw_spans_equals_the_flat_pass(zero):
             gexp[int(starts[si]):int(starts[si + 1])] = 0
     assert torch.equal(out[1].cpu(), gexp)
     with pytest.raises(RuntimeError):          # no spans: an argument error, not a launch
-        _lib.call("climb_adamw_spans", out[0], out[1], out[2], out[3], None, None, 0, 0, d_starts, d_groups, len(sizes), table.ctypes.data, 2, 1.0, 0, _st())
+        _lib.call("climb_adamw_spans", out[0], out[1], out[2], out[3], None, None, 0, 0, d_starts, d_groups, len(sizes), table.ctypes.data, 2, 1.0, 0, None, 1.0, _st())
 
 
 def test_adamw_ewc_fisher_flat_kernels():

@@ -1223,7 +1223,7 @@ def test_hipgraph_replay_matches_eager():
 
 
 # ------------------------------------------------------------------------------------------------ data parallel, end to end
-def _dp_worker(rank, world, port, q, precision, gbatch=4):
+def _dp_worker(rank, world, port, q, precision, gbatch=4, promise=False):
     import os as _os
     _os.environ["MASTER_ADDR"], _os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     import torch.distributed as dist
@@ -1244,16 +1244,58 @@ def _dp_worker(rank, world, port, q, precision, gbatch=4):
         model.train()
         losses, grads = [], None
         for it in range(2):
-            loss, _, _, _ = model.fused_forward_backward("vqa", images, texts, tgt[sl], grad_weight=weight)
-            if it == 0 and rank == 0:          # the averaged gradients the optimizer is about to consume (numpy: pickled by value)
+            # promise: the trainers' call -- FusedAdamW.step() is the next reader of the gradients, so the averaged 16-bit payload stays in the
+            # reducer's buffer and the optimizer reads it there (no un-cast pass); `.grad` is then NOT the averaged gradient
+            loss, _, _, _ = model.fused_forward_backward("vqa", images, texts, tgt[sl], grad_weight=weight, optimizer=opt if promise else None)
+            if promise and it == 0 and rank == 0:
+                grads = bool(model._host.engine()._g16)          # something really was deferred
+            if not promise and it == 0 and rank == 0:          # the averaged gradients the optimizer is about to consume (numpy: pickled by value)
                 grads = {n: p.grad.detach().cpu().numpy() for n, p in model.named_parameters() if p.grad is not None}
             opt.step()
             opt.zero_grad()
             losses.append(float(loss))
         ok = ddp.replicas_in_sync()
-        q.put((rank, ok, losses, grads, ddp.bytes_reduced, weight / world))          # weight / world = examples of the shard / examples of the batch
+        flat = model._host.engine().flat.double()
+        q.put((rank, ok, losses, grads, ddp.bytes_reduced, weight / world, [float(flat.sum()), float(flat.abs().sum()), float((flat * flat).sum())]))
     finally:
         dist.destroy_process_group()
+
+
+def _run_two_ranks(precision, gbatch, promise):
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q, precision, gbatch, promise)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    res.sort(key=lambda r: r[0])
+    return res
+
+
+def test_data_parallel_optimizer_reads_the_averaged_payload_in_place():
+    """r04: with the trainers' promise (`fused_forward_backward(..., optimizer=opt)`) the reducer leaves the averaged 16-bit payload in its staging
+    buffer and FusedAdamW's flat pass reads it there with the averaging factor folded in (`climb_adamw_spans`, source 1) instead of an un-cast pass
+    into the gradient buffer followed by a re-read.  Same arithmetic: after two steps on two ranks the parameters are what the run WITHOUT the promise
+    produces (16-bit GEMM order noise aside: the two runs are separate processes), both replicas in sync."""
+    if H16 == "fp32":
+        pytest.skip("16-bit payload only")
+    a = _run_two_ranks(H16, 4, False)
+    b = _run_two_ranks(H16, 4, True)
+    assert all(r[1] for r in a) and all(r[1] for r in b), "replicas diverged"
+    assert b[0][3] is True, "nothing was deferred: the optimizer did not read the payload buffer"
+    for x, y in zip(a[0][6], b[0][6]):
+        assert abs(x - y) <= 2e-6 * abs(x), (a[0][6], b[0][6])
+    for la, lb in zip(a[0][2], b[0][2]):
+        assert abs(la - lb) <= 2e-3 * abs(la)
 
 
 @pytest.mark.parametrize("gbatch", [4, 3])
