@@ -341,6 +341,7 @@ void climb_ntsk_set_workspace(void* ptr, long bytes);
 void climb_skinny_set_probe(int v);
 int climb_nt256_get_grid();
 void climb_attn_set_1pp_grid(int v);
+void climb_ln_set_rpw(int v);
 // current value of a library option (only the ones a caller has to put back: 9 = persistent NT grid); -1 = not readable
 extern "C" int climb_get_option(int key) { return key == 9 ? climb_nt256_get_grid() : -1; }
 extern "C" int climb_set_option(int key, int value) {
@@ -362,6 +363,7 @@ extern "C" int climb_set_option(int key, int value) {
   if (key == 18 && value >= 0) { climb_nt4_set_probe(value); return CLIMB_OK; }
   if (key == 19 && value >= 0 && value <= 2) { climb_skinny_set_probe(value); return CLIMB_OK; }
   if (key == 20 && value >= 0) { climb_attn_set_1pp_grid(value); return CLIMB_OK; }
+  if (key == 21 && value >= 1 && value <= 3) { climb_ln_set_rpw(value); return CLIMB_OK; }
   if (key == 6 && (value == 4 || value == 8)) { g_tn_waves = value; return CLIMB_OK; }
   if (key == 3 && value > 0) { g_tn_target = value; return CLIMB_OK; }
   return CLIMB_EINVAL;

@@ -8,58 +8,77 @@
 // per layer with eps=1e-12; REF/modeling/vilt.py:192 head LN with eps=1e-5)
 // x is the fp32 residual stream; y has the GEMM operand type TO.  Optional `add` [C] is added after the affine
 // (text rows add the modality-type embedding, HF:208-210).
-template <typename TO, int NV>
+// RPW rows per wave (r04 measurement, climb_set_option 21; tools/ln_bench.py): with all RPW rows' loads issued before the first reduction a launch of
+// M = 12288 rows is 1536 (RPW = 2) or 1024 (3) instead of 3072 workgroups -- 0.75 / 0.5 instead of 1.5 rounds of the chip's workgroup slots.  Measured
+// at the step's shape: 11.8 us (4.8 TB/s) with one row per wave, 12.3 with two, 13.1 with three: the default stays 1 (more waves in flight beat fewer
+// rounds; the in-step 13.5 us are cold caches, not the launch shape)
+template <typename TO, int NV, int RPW>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, long ldx, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float eps, TO* __restrict__ y, long ldy,
                                                             float* __restrict__ mean_out, float* __restrict__ rstd_out, int M, int C) {
   const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= M) return;
-  const float* xr = x + (long)row * ldx;
-  float4 v[NV];
-  float s = 0.f;
+  const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW;
+  if (row0 >= M) return;
+  float4 v[RPW][NV];
 #pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    int c = (i * 64 + lane) * 4;
-    v[i] = (c < C) ? ld4(xr + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-    s += v[i].x + v[i].y + v[i].z + v[i].w;
-  }
-  const float mean = wave_sum(s) / (float)C;
-  float q = 0.f;
+  for (int r = 0; r < RPW; ++r) {
+    const int row = row0 + r < M ? row0 + r : M - 1;
+    const float* xr = x + (long)row * ldx;
 #pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    int c = (i * 64 + lane) * 4;
-    if (c < C) {
-      float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
-      q += a * a + b * b + cc * cc + d * d;
+    for (int i = 0; i < NV; ++i) {
+      int c = (i * 64 + lane) * 4;
+      v[r][i] = (c < C) ? ld4(xr + c) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
-  const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
-  if (lane == 0) {
-    if (mean_out) mean_out[row] = mean;
-    if (rstd_out) rstd_out[row] = rstd;
-  }
-  TO* yr = y + (long)row * ldy;
 #pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    int c = (i * 64 + lane) * 4;
-    if (c < C) {
-      float4 g = ld4(gamma + c), b = ld4(beta + c);
-      float4 o = make_float4((v[i].x - mean) * rstd * g.x + b.x, (v[i].y - mean) * rstd * g.y + b.y,
-                             (v[i].z - mean) * rstd * g.z + b.z, (v[i].w - mean) * rstd * g.w + b.w);
-      st4(yr + c, o);
+  for (int r = 0; r < RPW; ++r) {
+    const int row = row0 + r;
+    if (row >= M) break;
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) s += v[r][i].x + v[r][i].y + v[r][i].z + v[r][i].w;
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      int c = (i * 64 + lane) * 4;
+      if (c < C) {
+        float a = v[r][i].x - mean, b = v[r][i].y - mean, cc = v[r][i].z - mean, d = v[r][i].w - mean;
+        q += a * a + b * b + cc * cc + d * d;
+      }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+    if (lane == 0) {
+      if (mean_out) mean_out[row] = mean;
+      if (rstd_out) rstd_out[row] = rstd;
+    }
+    TO* yr = y + (long)row * ldy;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      int c = (i * 64 + lane) * 4;
+      if (c < C) {
+        float4 g = ld4(gamma + c), b = ld4(beta + c);
+        float4 o = make_float4((v[r][i].x - mean) * rstd * g.x + b.x, (v[r][i].y - mean) * rstd * g.y + b.y,
+                               (v[r][i].z - mean) * rstd * g.z + b.z, (v[r][i].w - mean) * rstd * g.w + b.w);
+        st4(yr + c, o);
+      }
     }
   }
 }
 
+static int g_ln_rpw = 1;
+void climb_ln_set_rpw(int v) { g_ln_rpw = v; }
 template <typename TO>
 static int layernorm_fwd_launch(const float* x, long ldx, const float* g, const float* b, float eps, TO* y, long ldy, float* mean,
                                 float* rstd, int M, int C, hipStream_t st) {
   if (C % 4 || M <= 0) return CLIMB_EINVAL;
-  dim3 grid((M + 3) / 4), blk(256);
-  if (C <= 768) hipLaunchKernelGGL((layernorm_fwd_kernel<TO, 3>), grid, blk, 0, st, x, ldx, g, b, eps, y, ldy, mean, rstd, M, C);
-  else if (C <= 1536) hipLaunchKernelGGL((layernorm_fwd_kernel<TO, 6>), grid, blk, 0, st, x, ldx, g, b, eps, y, ldy, mean, rstd, M, C);
+  const int rpw = (g_ln_rpw >= 2 && M >= 4096) ? g_ln_rpw : 1;          // the small launches (B rows of the pooler / heads) keep one row per wave
+  dim3 grid((M + 4 * rpw - 1) / (4 * rpw)), blk(256);
+#define LNF(NV_, R_) hipLaunchKernelGGL((layernorm_fwd_kernel<TO, NV_, R_>), grid, blk, 0, st, x, ldx, g, b, eps, y, ldy, mean, rstd, M, C)
+  if (C <= 768) { if (rpw == 2) LNF(3, 2); else if (rpw >= 3) LNF(3, 3); else LNF(3, 1); }
+  else if (C <= 1536) { if (rpw == 2) LNF(6, 2); else LNF(6, 1); }
   else return CLIMB_EUNSUPPORTED;
+#undef LNF
   LAUNCH_CHECK();
   return CLIMB_OK;
 }

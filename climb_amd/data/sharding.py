@@ -84,7 +84,9 @@ class ShardedBatchSampler(Sampler):
                 mine, w = shard_of(glob, self.rank, self.world, self.pad)
                 if not mine:
                     continue
-            self.weights.append(w)
+            # (w, examples of the global batch per rank): the second is what the half build's loss scale is chosen from under data parallelism --
+            # the same number on every rank, also on one that only repeats an example with weight 0 (engine.begin_scaled_backward)
+            self.weights.append((w, len(glob) / max(1, self.world) if not self.replicated else float(len(glob))))
             yield mine
 
 
@@ -99,9 +101,10 @@ class ShardedDataLoader(DataLoader):
     def __iter__(self):
         sampler = self.batch_sampler
         for batch in super().__iter__():
-            w = sampler.weights.popleft()
+            w, rows = sampler.weights.popleft()
             if isinstance(batch, dict):
                 batch["dp_weight"] = w
+                batch["dp_rows"] = rows
             yield batch
 
     @contextlib.contextmanager

@@ -580,7 +580,8 @@ class ViltContinualLearner(ContinualLearner):
 
     # --- fused training step: forward + loss + backward (+ EWC term) with no autograd graph.  This is what
     # climb_amd.train.*Trainer.train_step runs; semantics = REF/train/visionlanguage_tasks/train_vqa.py:135-166.
-    def fused_forward_backward(self, task_key: str, images, texts, target: torch.Tensor, ewc=None, dropout_keep=None, grad_weight: float = 1.0, optimizer=None):
+    def fused_forward_backward(self, task_key: str, images, texts, target: torch.Tensor, ewc=None, dropout_keep=None, grad_weight: float = 1.0, optimizer=None,
+                               dp_rows: Optional[float] = None):
         """`grad_weight` multiplies d(loss) (not the returned loss): a data-parallel rank's share of an uneven global batch,
         climb_amd/data/sharding.py.
         `optimizer`: the caller's promise that `optimizer.step()` (this model's FusedAdamW) is the next thing that happens to the gradients
@@ -596,12 +597,12 @@ class ViltContinualLearner(ContinualLearner):
         # (not when an EWC term has to be ADDED to the averaged gradients: that needs them in fp32)
         self._defer_uncast = bool(promised and host.ddp is not None and not (ewc is not None and ewc.do_ewc()))
         try:
-            return self._fused_forward_backward(task_key, images, texts, target, ewc, dropout_keep, grad_weight)
+            return self._fused_forward_backward(task_key, images, texts, target, ewc, dropout_keep, grad_weight, dp_rows)
         finally:
             eng.defer_dw = False
             self._defer_uncast = False
 
-    def _fused_forward_backward(self, task_key: str, images, texts, target: torch.Tensor, ewc=None, dropout_keep=None, grad_weight: float = 1.0):
+    def _fused_forward_backward(self, task_key: str, images, texts, target: torch.Tensor, ewc=None, dropout_keep=None, grad_weight: float = 1.0, dp_rows=None):
         host = self._host
         eng = host.engine()
         host.before_backward()
@@ -622,7 +623,12 @@ class ViltContinualLearner(ContinualLearner):
         if task_key == "vqa":
             target = target.float()
         # fp16 operands: d(logits) is produced already multiplied by the loss scale (every |d logit| of both losses is <= 1 / rows)
-        gs = eng.begin_scaled_backward(1.0 / max(1, logits.shape[0])) * float(grad_weight)
+        # Under data parallelism the scale must be THE SAME on every rank (the half payload is reduced still scaled and every rank divides the average by
+        # its own scale: r04 -- ranks with 2 and 1 examples of a 3-example batch used to pick 2^8 and 2^7 and diverged).  A rank's |d logit| is bounded by
+        # weight / rows = ranks / examples of the global batch, whatever its share; `dp_rows` (the sharded loader) carries that number to ranks of weight 0 too.
+        rows_l = max(1, logits.shape[0])
+        bound = (1.0 / float(dp_rows)) if dp_rows else ((float(grad_weight) / rows_l) if grad_weight > 0 else 1.0 / rows_l)
+        gs = eng.begin_scaled_backward(bound) * float(grad_weight)
         loss, dlogits = eng.loss_and_grad(task_key, logits, target, gscale=gs, hs=hs)
         dpool = eng.head_backward(hs, dlogits, dtanh_of=pooled_seq)
         first, emb = host.frozen_prefix()

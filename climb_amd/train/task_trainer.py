@@ -121,7 +121,7 @@ class VLTaskTrainer(TaskTrainer):
         target = batch[self.target_field]
         # (`optimizer`: step() below is the next reader of the gradients -- the encoder's weight-gradient launch may carry the update, engine.defer_dw)
         loss, output, ewc_task, ewc_loss = model.fused_forward_backward(self.task_key, inputs["images"], inputs["texts"], target, ewc,
-                                                                        grad_weight=batch.get("dp_weight", 1.0), optimizer=optimizer)
+                                                                        grad_weight=batch.get("dp_weight", 1.0), optimizer=optimizer, dp_rows=batch.get("dp_rows"))
         if optimizer is not None:
             optimizer.step()
             if scheduler is not None:

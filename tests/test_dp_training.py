@@ -48,10 +48,12 @@ def test_sharded_loaders_reassemble_the_single_process_batches(n, G, world):
         torch.manual_seed(123)
         ld = ShardedDataLoader(ds, G, True, _collate, rank=r, world=world, pad=True)
         assert len(ld) == len(want)                 # steps per epoch (the lr schedule's length) do not depend on the number of ranks
-        got.append([(b["idx"], b["dp_weight"]) for b in ld])
+        got.append([(b["idx"], b["dp_weight"], b["dp_rows"]) for b in ld])
     for k, glob in enumerate(want):
         shares = [got[r][k][0] for r in range(world)]
         weights = [got[r][k][1] for r in range(world)]
+        # examples of the global batch per rank: the SAME number on every rank, also on one of weight 0 (the half build picks its loss scale from it)
+        assert all(got[r][k][2] == len(glob) / world for r in range(world))
         real = [s if w > 0 else [] for s, w in zip(shares, weights)]
         assert sorted(x for s in real for x in s) == sorted(glob)
         for r in range(world):
@@ -63,7 +65,7 @@ def test_sharded_loaders_reassemble_the_single_process_batches(n, G, world):
         avg = sum(w * sum(f(i) for i in s) / len(s) for s, w in zip(shares, weights)) / world
         assert avg == pytest.approx(sum(f(i) for i in glob) / len(glob), rel=1e-12)
     if n % G == 0 and G % world == 0:
-        assert all(w == 1.0 for r in range(world) for _, w in got[r])
+        assert all(w == 1.0 for r in range(world) for _, w, _ in got[r])
 
 
 def test_evaluation_shards_are_exact_and_replicated_mode_sees_whole_batches():
