@@ -246,9 +246,11 @@ extern "C" int climb_layernorm_gelu_fwd(const float* x, long ldx, const float* g
 }
 
 // Rank-M weight-gradient updates of the pooler and the heads (M = batch rows): C[n, k] += sum_m dY[m, n] * X[m, k].  climb_gemm_f32 walks the
-// 64 rows in four 16-deep trips (load, LDS, barrier, MFMA: 29 us for the 3129 x 1536 update); here a 64 x 64 tile's operands go global -> registers
-// in ONE round trip (for a fixed m both operands are contiguous along the lanes: coalesced 128-byte loads, 32 + 32 dwords per lane for 64 rows) and
-// straight into v_mfma_f32_32x32x2_f32; the tile is then read-modified-written once.  Exact fp32, one fixed summation order.
+// 64 rows in four 16-deep trips (load, LDS, barrier, MFMA); here a 64 x 64 tile's operands go global -> registers in ONE round trip (for a fixed m
+// both operands are contiguous along the lanes: coalesced 128-byte loads, 32 + 32 dwords per lane for 64 rows) and straight into
+// v_mfma_f32_32x32x2_f32; the tile is then read-modified-written once.  Exact fp32, one fixed summation order.  Measured in the step
+// (tools/head_trace.sh): 28.9 / 15.0 / 11.8 us for the 3129 x 1536, 1536 x 768 and 768 x 768 updates against 28.7 / 18.0 / 15.5 -- the big one is
+// bound by its 38 MB read-modify-write at 1176 small workgroups, not by the trips.
 __global__ __launch_bounds__(256) void rank_update_f32_kernel(const float* __restrict__ dY, long lddy, const float* __restrict__ X, long ldx, float* __restrict__ C,
                                                                long ldc, int M, int N, int K) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, half = lane >> 5, l31 = lane & 31;
