@@ -165,8 +165,20 @@ class BertParams(nn.Module):
         cfg = self.cfg
         H, nh, L, keep = cfg["hidden"], cfg["heads"], cfg["layers"], 1.0 - cfg.get("dropout", 0.1)
 
+        # Under data parallelism every rank seeds the device generator alike (the loaders, the replay memory and EWC's task draw depend on it), so
+        # the ranks would draw IDENTICAL masks for their different shards -- dropout noise correlated across the global batch, unlike the single
+        # process's.  The masks therefore come from a generator of their own, offset by the rank; one rank: the device's default stream.
+        gen = None
+        from . import parallel
+        rank, world = parallel.rank_world()
+        if world > 1:
+            gen = getattr(self, "_dropout_gen", None)
+            if gen is None:
+                gen = self._dropout_gen = torch.Generator(device=dev)
+                gen.manual_seed((torch.initial_seed() + 7919 * (rank + 1)) % (2 ** 63))
+
         def draw(*shape):
-            return torch.rand(shape, device=dev) < keep
+            return torch.rand(shape, device=dev, generator=gen) < keep
         return {"emb": draw(B, T, H), "probs": [draw(B, nh, T, T) for _ in range(L)], "attn_out": [draw(B, T, H) for _ in range(L)],
                 "ffn_out": [draw(B, T, H) for _ in range(L)]}
 
