@@ -173,9 +173,13 @@ class BertParams(nn.Module):
         rank, world = parallel.rank_world()
         if world > 1:
             gen = getattr(self, "_dropout_gen", None)
-            if gen is None:
+            seed0 = torch.initial_seed()
+            if gen is None or getattr(self, "_dropout_seed0", None) != seed0:
+                # (re-)derived whenever the process seed changes: torch.manual_seed() between tasks or on resume moves the masks under data
+                # parallelism exactly as it moves the single process's default stream
                 gen = self._dropout_gen = torch.Generator(device=dev)
-                gen.manual_seed((torch.initial_seed() + 7919 * (rank + 1)) % (2 ** 63))
+                gen.manual_seed((seed0 + 7919 * (rank + 1)) % (2 ** 63))
+                self._dropout_seed0 = seed0
 
         def draw(*shape):
             return torch.rand(shape, device=dev, generator=gen) < keep

@@ -108,41 +108,44 @@ __device__ __forceinline__ float dgelu_f(float x) {
   return cdf + x * pdf;
 }
 
-// GELU pair for the bf16 GEMM epilogues, where the result is rounded to bf16 (2^-9 relative) anyway and, measured, the erf/exp
-// formulation's ~24 VALU slots per element made the GELU epilogues VALU-bound (33 us of a layer's 555).  Phi(x) - 1/2 and
-// gelu'(x) - 1/2 are odd: x * Q((x/c)^2) with degree-7 Q fitted on Chebyshev nodes (conditioned in t = (x/c)^2 in [0,1]),
-// argument clamped to [-c, c], exact 0 left of -c.  No transcendental, 11 full-rate operations that pair into v_pk_fma_f32.
-// |gelu_poly - gelu| <= 6.8e-4 absolute (3.3e-4 of it the clamp at |x| = 3.75), |dgelu_poly - gelu'| <= 6.2e-4.
-// The fp32 parity path keeps erff().  (Also invisible on the IEEE-half build: with erff() in its epilogues the bs = 64 step's pooled error
-// against the reference is 2.9e-3 instead of 3.0e-3.)
-__device__ __forceinline__ float gelu_cdf_poly(float x) {
-  const float xc = fminf(fmaxf(x, -3.75f), 3.75f);
-  const float t = (xc * xc) * (1.0f / 14.0625f);
-  float q = -2.990306294e-01f;
-  q = fmaf(q, t, 1.411524049e+00f);
-  q = fmaf(q, t, -2.948430485e+00f);
-  q = fmaf(q, t, 3.672470736e+00f);
-  q = fmaf(q, t, -3.120830459e+00f);
-  q = fmaf(q, t, 1.952923920e+00f);
-  q = fmaf(q, t, -9.342629426e-01f);
-  q = fmaf(q, t, 3.989392092e-01f);
-  const float cdf = fmaf(xc, q, 0.5f);
-  return x < -3.75f ? 0.f : cdf;
+// GELU pair for the bf16 GEMM epilogues (r05: sigmoid form; r01 - r04 used odd degree-15 polynomials of 11 - 14 VALU operations per element, |error|
+// <= 6.8e-4 / 6.2e-4, which made the GELU epilogues VALU-bound and was a visible deviation from the reference's erf GELU, HF/modeling_vilt.py:393).
+//   gelu(x) ~= x * sigma(x * P(t)),  t = min(x^2, 64),  P(t) = a + b t + c t^2      (the tanh approximation is the two-term member of this family)
+// fitted minimax on [-12, 12] against the erf form: |gelu_fast - gelu| <= 2.6e-5 absolute in fp32 arithmetic (27 x closer than the polynomial; below
+// the bf16 rounding of every value it is stored as, and below north_star's 1e-3 by itself), and the DERIVATIVE OF THE SAME EXPRESSION
+//   gelu'(x) ~= s + x s (1 - s) (a + 3 b t + 5 c t^2),  s = sigma(x P(t))
+// is within 1.1e-4 of the exact gelu'.  7 full-rate operations + v_exp_f32 + v_rcp_f32 for the value (the transcendentals cost ~2 extra cycles each
+// beside MFMAs: MI355X_MICROARCH.md, "price of one filler"), 5 more for the derivative of the same element.  The clamp of t keeps P positive
+// (c < 0: P would change sign at |x| = 11.1) and costs nothing in accuracy (|x| > 8: sigma is 0 or 1 to 1e-12).  Saturation is exact where it
+// matters: exp2 overflows to +inf -> rcp 0 -> x * 0 for very negative x, exp2 underflows to 0 -> x * 1 for very positive x.
+// The fp32 parity path keeps erff().
+#define GELU_SIG_A 1.5950158f
+#define GELU_SIG_B 7.4011292e-2f
+#define GELU_SIG_C (-7.0303358e-4f)
+#define GELU_SIG_NL2E_A (-2.3011212f)        // -log2(e) * {a, b, c}: the exponent is taken in base 2
+#define GELU_SIG_NL2E_B (-0.10677572f)
+#define GELU_SIG_NL2E_C 1.014263e-3f
+#define GELU_SIG_DA GELU_SIG_A               // a, 3 b, 5 c
+#define GELU_SIG_DB 0.22203387f
+#define GELU_SIG_DC (-3.5151679e-3f)
+__device__ __forceinline__ float gelu_sig_t(float x) { return fminf(x * x, 64.0f); }
+__device__ __forceinline__ float gelu_sig_s(float x, float t) {          // sigma(x P(t))
+  const float p = fmaf(fmaf(GELU_SIG_NL2E_C, t, GELU_SIG_NL2E_B), t, GELU_SIG_NL2E_A);
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * p));
 }
-__device__ __forceinline__ float gelu_fast(float x) { return x * gelu_cdf_poly(x); }
+__device__ __forceinline__ float gelu_sig_d(float x, float t, float s) {  // derivative, given s
+  const float q = fmaf(fmaf(GELU_SIG_DC, t, GELU_SIG_DB), t, GELU_SIG_DA);
+  return fmaf(x * q, fmaf(-s, s, s), s);
+}
+__device__ __forceinline__ float gelu_fast(float x) { return x * gelu_sig_s(x, gelu_sig_t(x)); }
 __device__ __forceinline__ float dgelu_fast(float x) {
-  const float xc = fminf(fmaxf(x, -4.0f), 4.0f);
-  const float t = (xc * xc) * (1.0f / 16.0f);
-  float q = -5.764975740e+00f;
-  q = fmaf(q, t, 2.542120392e+01f);
-  q = fmaf(q, t, -4.785218948e+01f);
-  q = fmaf(q, t, 5.075452353e+01f);
-  q = fmaf(q, t, -3.378359828e+01f);
-  q = fmaf(q, t, 1.478723046e+01f);
-  q = fmaf(q, t, -4.235025071e+00f);
-  q = fmaf(q, t, 7.978034103e-01f);
-  const float d = fmaf(xc, q, 0.5f);
-  return x < -4.0f ? 0.f : d;
+  const float t = gelu_sig_t(x);
+  return gelu_sig_d(x, t, gelu_sig_s(x, t));
+}
+__device__ __forceinline__ void gelu_fast_pair(float x, float& y, float& dy) {      // value and derivative of one element (shared sigma)
+  const float t = gelu_sig_t(x), s = gelu_sig_s(x, t);
+  y = x * s;
+  dy = gelu_sig_d(x, t, s);
 }
 
 // torch.optim.AdamW (decoupled decay), REF/modeling/vilt.py:205-215 -- ONE definition for the flat optimizer pass (optim.hip) and the fused epilogue of
@@ -166,6 +169,8 @@ __device__ __forceinline__ void adamw_update(float& p, float& m, float& v, float
 #define EPI_SILU 5    // aux_out = acc + bias ; C = silu(aux_out)                  (adapter down-projection)
 #define EPI_DSILU 6   // C = acc * silu'(aux)       (aux has C's dtype)             (adapter backward)
 #define EPI_RESID2 7  // C = acc + bias + aux (f32) + aux2 (C's operand dtype)     (adapter up-projection + both residuals)
+#define EPI_GELUD 8   // aux_out = gelu'(acc + bias) ; C = gelu(acc + bias)        (r05: the backward multiplies by the SAVED derivative, 16-bit outputs only)
+#define EPI_MUL 9     // C = acc * aux               (aux has C's dtype: the derivative EPI_GELUD saved)
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 __device__ __forceinline__ float dsilu_f(float x) {

@@ -388,7 +388,7 @@ static int nt_dispatch(const bf16_t* A, long lda, const bf16_t* B, long ldb, TO*
   // epilogue-heavy kernels lose the second resident workgroup that computes while the first one stores, and come out 5-12 % slower
   const bool use192 = glds && g_nt_192 == 1 && (N % N192_T) == 0 && K >= 2 * GB_BK && nwg192 >= 160 && nwg192 <= 256;
   // persistent 256 x {256, 192} tiles (gemm_bf16_ntp.hip): the tile width whose last round of 256 workgroups wastes less
-  const bool epi256 = epi == EPI_NONE || epi == EPI_GELU || epi == EPI_RESID || epi == EPI_DGELU;
+  const bool epi256 = epi == EPI_NONE || epi == EPI_GELU || epi == EPI_RESID || epi == EPI_DGELU || epi == EPI_GELUD || epi == EPI_MUL;
   if (glds && epi256 && g_nt_256 == 1) {      // (forcing one of the 8-wave tile shapes through option 7 also keeps this kernel out)
     int rc = climb_nt4_launch(A, lda, B, ldb, C, ldc, sizeof(TO) == 4 ? CLIMB_DT_F32 : CLIMB_DT_BF16, M, N, K, bias, epi, aux, ldaux, aux_out, ldauxo, st);
     if (rc == CLIMB_OK) { LAUNCH_CHECK(); return CLIMB_OK; }
@@ -438,6 +438,10 @@ static int nt_dispatch(const bf16_t* A, long lda, const bf16_t* B, long ldb, TO*
     case EPI_SILU: NT_LAUNCH(EPI_SILU); break;
     case EPI_DSILU: NT_LAUNCH(EPI_DSILU); break;
     case EPI_RESID2: NT_LAUNCH(EPI_RESID2); break;
+    case EPI_GELUD:          // (16-bit outputs only: the saved derivative and the activation are GEMM operands of the backward)
+      if constexpr (sizeof(TO) == 2) { NT_LAUNCH(EPI_GELUD); break; } else return CLIMB_EINVAL;
+    case EPI_MUL:
+      if constexpr (sizeof(TO) == 2) { NT_LAUNCH(EPI_MUL); break; } else return CLIMB_EINVAL;
     default: return CLIMB_EINVAL;
   }
 #undef NT_LAUNCH
@@ -450,13 +454,15 @@ static inline bool al16p(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 // C (c_dtype: 0 fp32 / 1 bf16) [M,N] = epi(A[M,K] B[N,K]^T + bias).  A, B bf16 with K contiguous; K % 8 == 0, N % 4 == 0.
 // epi 1/5 (GELU/SiLU): aux_out (bf16 [M,N]) receives the pre-activation.  epi 2: aux = fp32 residual [M,N].  epi 3/6: aux = bf16
-// pre-activation (x gelu'/silu').  epi 7: aux = fp32 residual and aux2 = bf16 second residual.
+// pre-activation (x gelu'/silu').  epi 7: aux = fp32 residual and aux2 = bf16 second residual.  epi 8 (16-bit C only): aux_out receives
+// gelu'(pre-activation) instead of the pre-activation; epi 9 (16-bit C only): C = acc * aux, aux = what epi 8 saved.
 extern "C" int climb_gemm_bf16_nt(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int c_dtype, int M, int N, int K,
                                   const float* bias, int epi, const void* aux, long ldaux, void* aux_out, long ldauxo, const void* aux2, long ldaux2,
                                   void* stream) {
   if (M <= 0 || N <= 0 || K <= 0 || (K % 8) || (N % 4) || (lda % 8) || (ldb % 8) || (ldc % 4) || !al16p(A) || !al16p(B) || !al16p(C)) return CLIMB_EINVAL;
-  if ((epi == EPI_RESID || epi == EPI_DGELU || epi == EPI_DSILU || epi == EPI_RESID2) && !aux) return CLIMB_EINVAL;
-  if ((epi == EPI_GELU || epi == EPI_SILU) && !aux_out) return CLIMB_EINVAL;
+  if ((epi == EPI_RESID || epi == EPI_DGELU || epi == EPI_DSILU || epi == EPI_RESID2 || epi == EPI_MUL) && !aux) return CLIMB_EINVAL;
+  if ((epi == EPI_GELU || epi == EPI_SILU || epi == EPI_GELUD) && !aux_out) return CLIMB_EINVAL;
+  if ((epi == EPI_GELUD || epi == EPI_MUL) && c_dtype != CLIMB_DT_BF16) return CLIMB_EINVAL;
   if (epi == EPI_RESID2 && !aux2) return CLIMB_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   if (c_dtype == CLIMB_DT_F32)

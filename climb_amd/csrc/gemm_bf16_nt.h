@@ -66,7 +66,7 @@ __device__ __forceinline__ void nt_aux_prefetch_l(AuxRegs<EPI, NI * 4 * MJ>& ax,
       const int q = p * 64 + lane, r = q / CPR, c = q % CPR;
       const int m = min(mw + j * 32 + r, M - 1), n = min(nw + c * 4, N - 4);       // clamped: out-of-range results are never used
       if (EPI == EPI_RESID || EPI == EPI_RESID2) ax.r[j * NI * 4 + p] = ld4(reinterpret_cast<const float*>(aux) + (long)m * ldaux + n);
-      if (EPI == EPI_DGELU || EPI == EPI_DSILU) ax.h[j * NI * 4 + p] = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(aux) + (long)m * ldaux + n);
+      if (EPI == EPI_DGELU || EPI == EPI_DSILU || EPI == EPI_MUL) ax.h[j * NI * 4 + p] = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(aux) + (long)m * ldaux + n);
       if (EPI == EPI_RESID2) ax.h[j * NI * 4 + p] = *reinterpret_cast<const uint2*>(aux2 + (long)m * ldaux2 + n);
     }
 }
@@ -82,7 +82,7 @@ __device__ __forceinline__ void nt_aux_touch(AuxRegs<EPI, CNT>& ax) {
 #pragma unroll
   for (int i = 0; i < CNT; ++i) {
     if (EPI == EPI_RESID || EPI == EPI_RESID2) asm volatile("" : "+v"(ax.r[i].x), "+v"(ax.r[i].y), "+v"(ax.r[i].z), "+v"(ax.r[i].w));
-    if (EPI == EPI_DGELU || EPI == EPI_DSILU || EPI == EPI_RESID2) asm volatile("" : "+v"(ax.h[i].x), "+v"(ax.h[i].y));
+    if (EPI == EPI_DGELU || EPI == EPI_DSILU || EPI == EPI_RESID2 || EPI == EPI_MUL) asm volatile("" : "+v"(ax.h[i].x), "+v"(ax.h[i].y));
   }
 }
 __device__ __forceinline__ float4 bf16x4_to_f32(uint2 r) {
@@ -147,6 +147,13 @@ __device__ __forceinline__ void nt_epi_drain(const AX& ax, const NtBias<NI>& bb,
     } else if (EPI == EPI_DGELU) {
       const float4 uv = bf16x4_to_f32(ax.h[AXJ + p]);
       v.x *= dgelu_fast(uv.x); v.y *= dgelu_fast(uv.y); v.z *= dgelu_fast(uv.z); v.w *= dgelu_fast(uv.w);
+    } else if (EPI == EPI_GELUD) {
+      float4 d;
+      gelu_fast_pair(v.x, v.x, d.x); gelu_fast_pair(v.y, v.y, d.y); gelu_fast_pair(v.z, v.z, d.z); gelu_fast_pair(v.w, v.w, d.w);
+      st4(aux_out + (long)m * ldauxo + n, d);
+    } else if (EPI == EPI_MUL) {
+      const float4 uv = bf16x4_to_f32(ax.h[AXJ + p]);
+      v.x *= uv.x; v.y *= uv.y; v.z *= uv.z; v.w *= uv.w;
     } else if (EPI == EPI_SILU) {
       st4(aux_out + (long)m * ldauxo + n, v);
       v = make_float4(silu_f(v.x), silu_f(v.y), silu_f(v.z), silu_f(v.w));

@@ -79,6 +79,7 @@ __device__ __forceinline__ bf16x8 ntp_frag_(const unsigned char* p) { return as_
 template <int EPI> struct Nt4Aux { };
 template <> struct Nt4Aux<EPI_RESID> { f32x4 v[4]; };
 template <> struct Nt4Aux<EPI_DGELU> { u32x2 v[4]; };
+template <> struct Nt4Aux<EPI_MUL> { u32x2 v[4]; };
 
 // ---------------------------------------------------------------------------------------------------- loads the compiler does not count
 // (a register load hipcc can see is waited for with vmcnt(0) as soon as stores are pending: DESIGN.md section 5, "a load behind a store")
@@ -95,12 +96,16 @@ template <> __device__ __forceinline__ void nt4_aux_load<EPI_RESID>(Nt4Aux<EPI_R
 template <> __device__ __forceinline__ void nt4_aux_load<EPI_DGELU>(Nt4Aux<EPI_DGELU>& a, int p, const Nt4Uni& u, const Nt4Lane& l, unsigned soff) {
   nt4_ld64(a.v[p], u.rx, l.vx, soff);
 }
+template <> __device__ __forceinline__ void nt4_aux_load<EPI_MUL>(Nt4Aux<EPI_MUL>& a, int p, const Nt4Uni& u, const Nt4Lane& l, unsigned soff) {
+  nt4_ld64(a.v[p], u.rx, l.vx, soff);
+}
 template <int EPI> __device__ __forceinline__ u32x2 nt4_auxw(const Nt4Aux<EPI>&, int) { return (u32x2){0u, 0u}; }
 template <> __device__ __forceinline__ u32x2 nt4_auxw<EPI_DGELU>(const Nt4Aux<EPI_DGELU>& a, int p) { return a.v[p]; }
 // pins the registers of asm loads behind a wait (the compiler must not touch them between load and wait)
 template <int EPI> __device__ __forceinline__ void nt4_pin(Nt4Aux<EPI>&) {}
 template <> __device__ __forceinline__ void nt4_pin<EPI_RESID>(Nt4Aux<EPI_RESID>& a) { asm volatile("" : "+v"(a.v[0]), "+v"(a.v[1]), "+v"(a.v[2]), "+v"(a.v[3])::"memory"); }
 template <> __device__ __forceinline__ void nt4_pin<EPI_DGELU>(Nt4Aux<EPI_DGELU>& a) { asm volatile("" : "+v"(a.v[0]), "+v"(a.v[1]), "+v"(a.v[2]), "+v"(a.v[3])::"memory"); }
+template <> __device__ __forceinline__ void nt4_pin<EPI_MUL>(Nt4Aux<EPI_MUL>& a) { asm volatile("" : "+v"(a.v[0]), "+v"(a.v[1]), "+v"(a.v[2]), "+v"(a.v[3])::"memory"); }
 
 // ---------------------------------------------------------------------------------------------------- DMA
 constexpr int nt4_dma_piece(int q) {      // slot -> piece (0..5: A, 6..11: B) or -1
@@ -142,51 +147,50 @@ __device__ __forceinline__ void nt4_stage_write(const f32x16& acc, const Nt4Lane
   f32x4 v = {acc[4 * G], acc[4 * G + 1], acc[4 * G + 2], acc[4 * G + 3]};
   asm volatile("ds_write_b128 %0, %1" ::"v"(l.wr0 ^ (unsigned)(G << 5)), "v"(v) : "memory");
 }
-// The GELU kinds inside the k-loop.  gelu_fast / dgelu_fast (common.h) are Horner chains of 8 dependent FMAs per element: one element per MFMA
-// slot issues at the chain's latency (measured: the windows that carry them took 3 x the MFMA time).  Instead ONE stage of the chain runs per slot
-// for EIGHT elements (two readback pieces), so the eight chains interleave.  The arithmetic per element is exactly that of common.h (same
-// operations in the same order: bit-identical results).
-struct Nt4Act { float xc[8], t[8], q[8], u[8]; };
+// The GELU kinds inside the k-loop.  gelu_fast / dgelu_fast / gelu_fast_pair (common.h, the sigmoid form) are chains of dependent operations: one
+// element per MFMA slot would issue at the chain's latency (measured with the r04 polynomials: the windows that carried them took 3 x the MFMA time).
+// Instead ONE stage of the chain runs per slot for EIGHT elements (two readback pieces), so the eight chains interleave, and the second, independent
+// chain of the derivative (q) rides in the stages whose first chain is a transcendental.  The arithmetic per element is exactly that of common.h
+// (same operations in the same order: bit-identical to the 8-wave kernels' epilogues).  Stages: GELU 0..7, GELUD 0..8, DGELU 0..10.
+struct Nt4Act { float u[8], t[8], p[8], q[8]; };
+template <int EPI> struct Nt4ActN { static constexpr int STAGES = EPI == EPI_GELU ? 8 : EPI == EPI_GELUD ? 9 : 11; };
 template <int EPI, int STAGE>
 __device__ __forceinline__ void nt4_act_stage(Nt4Act& a, f32x4& v0, f32x4& v1, const u32x2& w0, const u32x2& w1) {
-  constexpr bool G = EPI == EPI_GELU;
-  constexpr float C = G ? 3.75f : 4.0f, S = G ? (1.0f / 14.0625f) : (1.0f / 16.0f);
-  constexpr float K0 = G ? -2.990306294e-01f : -5.764975740e+00f, K1 = G ? 1.411524049e+00f : 2.542120392e+01f, K2 = G ? -2.948430485e+00f : -4.785218948e+01f,
-                  K3 = G ? 3.672470736e+00f : 5.075452353e+01f, K4 = G ? -3.120830459e+00f : -3.378359828e+01f, K5 = G ? 1.952923920e+00f : 1.478723046e+01f,
-                  K6 = G ? -9.342629426e-01f : -4.235025071e+00f, K7 = G ? 3.989392092e-01f : 7.978034103e-01f;
-  if constexpr (STAGE == 0) {
-    if constexpr (G) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) { a.u[k] = v0[k]; a.u[4 + k] = v1[k]; }
-    } else {
-      a.u[0] = h16lo_to_f32(w0[0]); a.u[1] = h16hi_to_f32(w0[0]); a.u[2] = h16lo_to_f32(w0[1]); a.u[3] = h16hi_to_f32(w0[1]);
-      a.u[4] = h16lo_to_f32(w1[0]); a.u[5] = h16hi_to_f32(w1[0]); a.u[6] = h16lo_to_f32(w1[1]); a.u[7] = h16hi_to_f32(w1[1]);
-    }
-#pragma unroll
-    for (int k = 0; k < 8; ++k) a.xc[k] = fminf(fmaxf(a.u[k], -C), C);
+  constexpr bool D = EPI == EPI_DGELU;          // pre-activation comes packed (w0, w1) and v is multiplied by the derivative at the end
+  constexpr int S = D ? STAGE - 1 : STAGE;      // position in the common chain
+#define NT4_ALL _Pragma("unroll") for (int k = 0; k < 8; ++k)
+  if constexpr (D && STAGE == 0) {
+    a.u[0] = h16lo_to_f32(w0[0]); a.u[1] = h16hi_to_f32(w0[0]); a.u[2] = h16lo_to_f32(w0[1]); a.u[3] = h16hi_to_f32(w0[1]);
+    a.u[4] = h16lo_to_f32(w1[0]); a.u[5] = h16hi_to_f32(w1[0]); a.u[6] = h16lo_to_f32(w1[1]); a.u[7] = h16hi_to_f32(w1[1]);
   }
-  if constexpr (STAGE == 1) {
-#pragma unroll
-    for (int k = 0; k < 8; ++k) a.t[k] = (a.xc[k] * a.xc[k]) * S;
+  if constexpr (S == 0) {
+    if constexpr (!D) { NT4_ALL a.u[k] = k < 4 ? v0[k & 3] : v1[k & 3]; }
+    NT4_ALL a.t[k] = gelu_sig_t(a.u[k]);
   }
-#define NT4_H(ST, KK, FIRST)                                                     \
-  if constexpr (STAGE == ST) {                                                   \
-    _Pragma("unroll") for (int k = 0; k < 8; ++k) a.q[k] = fmaf(FIRST ? K0 : a.q[k], a.t[k], KK); \
+  if constexpr (S == 1) { NT4_ALL a.p[k] = fmaf(GELU_SIG_NL2E_C, a.t[k], GELU_SIG_NL2E_B); }
+  if constexpr (S == 2) { NT4_ALL a.p[k] = fmaf(a.p[k], a.t[k], GELU_SIG_NL2E_A); }
+  if constexpr (S == 3) { NT4_ALL a.p[k] = a.u[k] * a.p[k]; }
+  if constexpr (S == 4) {
+    NT4_ALL a.p[k] = __builtin_amdgcn_exp2f(a.p[k]);
+    if constexpr (EPI != EPI_GELU) { NT4_ALL a.q[k] = fmaf(GELU_SIG_DC, a.t[k], GELU_SIG_DB); }
   }
-  NT4_H(2, K1, true) NT4_H(3, K2, false) NT4_H(4, K3, false) NT4_H(5, K4, false) NT4_H(6, K5, false) NT4_H(7, K6, false) NT4_H(8, K7, false)
-#undef NT4_H
-  if constexpr (STAGE == 9) {
-#pragma unroll
-    for (int k = 0; k < 8; ++k) a.q[k] = fmaf(a.xc[k], a.q[k], 0.5f);
+  if constexpr (S == 5) {
+    NT4_ALL a.p[k] = 1.0f + a.p[k];
+    if constexpr (EPI != EPI_GELU) { NT4_ALL a.q[k] = fmaf(a.q[k], a.t[k], GELU_SIG_DA); }
   }
-  if constexpr (STAGE == 10) {
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const float r = a.u[k] < -C ? 0.f : a.q[k];
-      if (k < 4) v0[k] = v0[k] * r; else v1[k - 4] = v1[k - 4] * r;
-    }
+  if constexpr (S == 6) {
+    NT4_ALL a.p[k] = __builtin_amdgcn_rcpf(a.p[k]);          // s
+    if constexpr (EPI != EPI_GELU) { NT4_ALL a.q[k] = a.u[k] * a.q[k]; }
   }
+  if constexpr (S == 7) {
+    if constexpr (!D) { NT4_ALL { if (k < 4) v0[k & 3] = a.u[k] * a.p[k]; else v1[k & 3] = a.u[k] * a.p[k]; } }
+    if constexpr (EPI != EPI_GELU) { NT4_ALL a.t[k] = fmaf(-a.p[k], a.p[k], a.p[k]); }          // s - s^2 (t is dead)
+  }
+  if constexpr (S == 8 && EPI != EPI_GELU) { NT4_ALL a.q[k] = fmaf(a.q[k], a.t[k], a.p[k]); }   // the derivative
+  if constexpr (D && S == 9) { NT4_ALL { if (k < 4) v0[k & 3] = v0[k & 3] * a.q[k]; else v1[k & 3] = v1[k & 3] * a.q[k]; } }
+#undef NT4_ALL
 }
+__device__ __forceinline__ u32x2 nt4_pack4(float a, float b, float c, float d) { return (u32x2){pack_bf16x2(a, b), pack_bf16x2(c, d)}; }
 
 // one row-major float4 (readback p of block (bi, bj) of the finished tile): bias, epilogue, store(s).  SUB: -1 = everything at once.  Inside the
 // k-loop the GELU kinds spread their arithmetic over MFMA slots and HOLD the packed result for the next window (stores issued late in a window are
@@ -203,17 +207,32 @@ __device__ __forceinline__ void nt4_unit(f32x4& v, u32x2& hold, const f32x4& bia
     v += bias;
     v += ax.v[p];
     nt4_store<TO>(v, u.rc, l.vc, csoff);
+  } else if constexpr (EPI == EPI_MUL) {
+    const u32x2 w = ax.v[p];
+    v[0] *= h16lo_to_f32(w[0]); v[1] *= h16hi_to_f32(w[0]); v[2] *= h16lo_to_f32(w[1]); v[3] *= h16hi_to_f32(w[1]);
+    nt4_store<TO>(v, u.rc, l.vc, csoff);
   } else {
-    static_assert(EPI == EPI_GELU || EPI == EPI_DGELU, "epilogue");
+    static_assert(EPI == EPI_GELU || EPI == EPI_DGELU || EPI == EPI_GELUD, "epilogue");
     static_assert(sizeof(TO) == 2, "the GELU kinds have 16-bit outputs");
+    const unsigned osoff = u.obase + rowoff * u.ldo_b + (unsigned)(bj * 64);
     if constexpr (SUB <= 0) {
       v += bias;
-      if constexpr (EPI == EPI_GELU) nt4_store<bf16_t>(v, u.ro, l.vo2, u.obase + rowoff * u.ldo_b + (unsigned)(bj * 64));
+      if constexpr (EPI == EPI_GELU) nt4_store<bf16_t>(v, u.ro, l.vo2, osoff);
     }
     if constexpr (SUB < 0) {
       if constexpr (EPI == EPI_GELU) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) v[k] = gelu_fast(v[k]);
+      } else if constexpr (EPI == EPI_GELUD) {
+        f32x4 d;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          float y_, d_;
+          gelu_fast_pair(v[k], y_, d_);
+          v[k] = y_;
+          d[k] = d_;
+        }
+        nt4_store<bf16_t>(d, u.ro, l.vo2, osoff);
       } else {
         const u32x2 w = ax.v[p];
         v[0] *= dgelu_fast(h16lo_to_f32(w[0])); v[1] *= dgelu_fast(h16hi_to_f32(w[0]));
@@ -221,22 +240,15 @@ __device__ __forceinline__ void nt4_unit(f32x4& v, u32x2& hold, const f32x4& bia
       }
       nt4_store<TO>(v, u.rc, l.vc, csoff);
     }
-    if constexpr (SUB >= 1 && SUB <= 4) {
-      if constexpr (EPI == EPI_GELU) v[SUB - 1] = gelu_fast(v[SUB - 1]);
-      else {
-        const unsigned w = ax.v[p][(SUB - 1) >> 1];
-        v[SUB - 1] *= dgelu_fast(((SUB - 1) & 1) ? h16hi_to_f32(w) : h16lo_to_f32(w));
-      }
-      if constexpr (SUB == 4) hold = (u32x2){pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)};
-    }
     if constexpr (SUB == 5) __builtin_amdgcn_raw_buffer_store_b64(hold, u.rc, l.vc, csoff, 0);
+    if constexpr (SUB == 6) __builtin_amdgcn_raw_buffer_store_b64(hold, u.ro, l.vo2, osoff, 0);          // GELUD: the held derivative
   }
 }
 // operand loads of block B of the finished tile, piece p
 template <int EPI>
 __device__ __forceinline__ void nt4_aux_issue(Nt4Aux<EPI>& ax, int p, int bi, int bj, const Nt4Uni& u, const Nt4Lane& l) {
   if constexpr (EPI == EPI_RESID) nt4_aux_load<EPI>(ax, p, u, l, u.xbase + (unsigned)(bi * 32 + 8 * p) * u.ldx_b + (unsigned)(bj * 128));
-  if constexpr (EPI == EPI_DGELU) nt4_aux_load<EPI>(ax, p, u, l, u.xbase + (unsigned)(bi * 32 + 8 * p) * u.ldx_b + (unsigned)(bj * 64));
+  if constexpr (EPI == EPI_DGELU || EPI == EPI_MUL) nt4_aux_load<EPI>(ax, p, u, l, u.xbase + (unsigned)(bi * 32 + 8 * p) * u.ldx_b + (unsigned)(bj * 64));
 }
 __device__ __forceinline__ void nt4_bias_issue(f32x4 (&bias)[3], int j, const Nt4Uni& u, const Nt4Lane& l) { nt4_ld128(bias[j], u.rbias, l.vb, u.bbase + (unsigned)(j * 128)); }
 // coordinates of the tile that has just been finished -> epilogue bases
@@ -262,7 +274,7 @@ template <int PR_, bool SW_, int EB_, int AB_, bool BL_, bool DMA_, bool RD_, in
   static constexpr int EB = (PR_ & 2) ? -1 : EB_, AB = (PR_ & 2) ? -1 : AB_, SB = (PR_ & 2) ? -1 : SB_;
 };
 template <typename TO, int EPI, class CFG, int Q>
-__device__ __forceinline__ void nt4_slot(f32x16 (&accC)[3][3], f32x16 (&accP)[3][3], bf16x8 (&fa)[2][3], bf16x8 (&fb)[2][3], f32x4 (&rbk)[4], u32x2 (&hold)[4], Nt4Act& act,
+__device__ __forceinline__ void nt4_slot(f32x16 (&accC)[3][3], f32x16 (&accP)[3][3], bf16x8 (&fa)[2][3], bf16x8 (&fb)[2][3], f32x4 (&rbk)[4], u32x2 (&hold)[8], Nt4Act& act,
                                          f32x4 (&bias)[3], Nt4Aux<EPI> (&aux)[2], const Nt4Uni& u, const Nt4Lane& l, unsigned char* smem) {
   constexpr int st = Q / 9, blk = Q % 9, bi = blk / 3, bj = blk % 3;
   constexpr int par = (st == 0) ? 1 : ((st - 1) & 1);
@@ -296,15 +308,24 @@ __device__ __forceinline__ void nt4_slot(f32x16 (&accC)[3][3], f32x16 (&accP)[3]
     if constexpr (Q == 2) nt4_stage_write<1>(accP[ei][ej], l);
     if constexpr (Q == 3) nt4_stage_write<2>(accP[ei][ej], l);
     if constexpr (Q == 5) nt4_stage_write<3>(accP[ei][ej], l);
-    if constexpr (EPI == EPI_GELU || EPI == EPI_DGELU) {
-      // readback p in slot 5 + p; bias (+ pre-activation store) of piece p in slot 8 + p; pieces 0, 1: one stage of the activation per slot in
-      // 12 .. 22, packed into `hold` in 23; pieces 2, 3: 24 .. 34, packed in 35.  NO result store in this window: held for the next one's first slots
+    if constexpr (EPI == EPI_GELU || EPI == EPI_DGELU || EPI == EPI_GELUD) {
+      // readback p in slot 5 + p; bias (+ pre-activation store, GELU) of piece p in slot 8 + p; pieces 0, 1: one stage of the activation per slot from
+      // 12 on (at most 11 stages), packed into `hold` in 23; pieces 2, 3: from 24 on, packed in 35.  NO result store in this window: held for the
+      // next one's first slots
+      constexpr int NS = Nt4ActN<EPI>::STAGES;
       if constexpr (Q >= 5 && Q < 9) rbk[Q - 5] = *reinterpret_cast<const f32x4*>(smem + NT4_TURN + u.wid * 4096 + l.rd + (Q - 5) * 1024);
       if constexpr (Q >= 8 && Q < 12) nt4_unit<TO, EPI, 0>(rbk[Q - 8], hold[Q - 8], bias[ej], aux[CFG::EB & 1], Q - 8, ei, ej, u, l);
-      if constexpr (Q >= 12 && Q < 23) nt4_act_stage<EPI, Q - 12>(act, rbk[0], rbk[1], nt4_auxw<EPI>(aux[CFG::EB & 1], 0), nt4_auxw<EPI>(aux[CFG::EB & 1], 1));
-      if constexpr (Q >= 24 && Q < 35) nt4_act_stage<EPI, Q - 24>(act, rbk[2], rbk[3], nt4_auxw<EPI>(aux[CFG::EB & 1], 2), nt4_auxw<EPI>(aux[CFG::EB & 1], 3));
-      if constexpr (Q == 23) { hold[0] = (u32x2){pack_bf16x2(rbk[0].x, rbk[0].y), pack_bf16x2(rbk[0].z, rbk[0].w)}; hold[1] = (u32x2){pack_bf16x2(rbk[1].x, rbk[1].y), pack_bf16x2(rbk[1].z, rbk[1].w)}; }
-      if constexpr (Q == 35) { hold[2] = (u32x2){pack_bf16x2(rbk[2].x, rbk[2].y), pack_bf16x2(rbk[2].z, rbk[2].w)}; hold[3] = (u32x2){pack_bf16x2(rbk[3].x, rbk[3].y), pack_bf16x2(rbk[3].z, rbk[3].w)}; }
+      if constexpr (Q >= 12 && Q < 12 + NS) nt4_act_stage<EPI, Q - 12>(act, rbk[0], rbk[1], nt4_auxw<EPI>(aux[CFG::EB & 1], 0), nt4_auxw<EPI>(aux[CFG::EB & 1], 1));
+      if constexpr (Q >= 24 && Q < 24 + NS) nt4_act_stage<EPI, Q - 24>(act, rbk[2], rbk[3], nt4_auxw<EPI>(aux[CFG::EB & 1], 2), nt4_auxw<EPI>(aux[CFG::EB & 1], 3));
+      if constexpr (Q == 23 || Q == 35) {
+        constexpr int h = Q == 23 ? 0 : 2;
+        hold[h] = nt4_pack4(rbk[h].x, rbk[h].y, rbk[h].z, rbk[h].w);
+        hold[h + 1] = nt4_pack4(rbk[h + 1].x, rbk[h + 1].y, rbk[h + 1].z, rbk[h + 1].w);
+        if constexpr (EPI == EPI_GELUD) {
+          hold[4 + h] = nt4_pack4(act.q[0], act.q[1], act.q[2], act.q[3]);
+          hold[5 + h] = nt4_pack4(act.q[4], act.q[5], act.q[6], act.q[7]);
+        }
+      }
     } else {
       // every store in the first half of the window: readback p in slot 6 + 2 p, bias / residual / store in slot 9 + 2 p
       constexpr int rp = Q == 6 ? 0 : Q == 8 ? 1 : Q == 10 ? 2 : Q == 12 ? 3 : -1;
@@ -314,10 +335,11 @@ __device__ __forceinline__ void nt4_slot(f32x16 (&accC)[3][3], f32x16 (&accP)[3]
     }
   }
   if constexpr (CFG::SB >= 0 && Q < 4) nt4_unit<TO, EPI, 5>(rbk[Q], hold[Q], bias[0], aux[0], Q, CFG::SB / 3, CFG::SB % 3, u, l);
+  if constexpr (EPI == EPI_GELUD && CFG::SB >= 0 && Q >= 4 && Q < 8) nt4_unit<TO, EPI, 6>(rbk[Q - 4], hold[Q], bias[0], aux[0], Q - 4, CFG::SB / 3, CFG::SB % 3, u, l);
   __builtin_amdgcn_sched_barrier(0);
 }
 template <typename TO, int EPI, class CFG, int Q, int QE>
-__device__ __forceinline__ void nt4_slots(f32x16 (&accC)[3][3], f32x16 (&accP)[3][3], bf16x8 (&fa)[2][3], bf16x8 (&fb)[2][3], f32x4 (&rbk)[4], u32x2 (&hold)[4], Nt4Act& act,
+__device__ __forceinline__ void nt4_slots(f32x16 (&accC)[3][3], f32x16 (&accP)[3][3], bf16x8 (&fa)[2][3], bf16x8 (&fb)[2][3], f32x4 (&rbk)[4], u32x2 (&hold)[8], Nt4Act& act,
                                           f32x4 (&bias)[3], Nt4Aux<EPI> (&aux)[2], const Nt4Uni& u, const Nt4Lane& l, unsigned char* smem) {
   if constexpr (Q < QE) {
     nt4_slot<TO, EPI, CFG, Q>(accC, accP, fa, fb, rbk, hold, act, bias, aux, u, l, smem);
@@ -347,7 +369,7 @@ __device__ __forceinline__ void nt4_window_end(Nt4Uni& u, Nt4Aux<EPI> (&aux)[2],
   nt4_set_rd(u, u.rd_off + NT4_STAGE == 3 * NT4_STAGE ? 0u : u.rd_off + NT4_STAGE);
 }
 template <typename TO, int EPI, class CFG>
-__device__ __forceinline__ void nt4_window(f32x16 (&accC)[3][3], f32x16 (&accP)[3][3], bf16x8 (&fa)[2][3], bf16x8 (&fb)[2][3], f32x4 (&rbk)[4], u32x2 (&hold)[4], Nt4Act& act,
+__device__ __forceinline__ void nt4_window(f32x16 (&accC)[3][3], f32x16 (&accP)[3][3], bf16x8 (&fa)[2][3], bf16x8 (&fb)[2][3], f32x4 (&rbk)[4], u32x2 (&hold)[8], Nt4Act& act,
                                            f32x4 (&bias)[3], Nt4Aux<EPI> (&aux)[2], Nt4Uni& u, const Nt4Lane& l, unsigned char* smem) {
   nt4_dma_advance(u);
   nt4_slots<TO, EPI, CFG, 0, 36>(accC, accP, fa, fb, rbk, hold, act, bias, aux, u, l, smem);
@@ -355,7 +377,7 @@ __device__ __forceinline__ void nt4_window(f32x16 (&accC)[3][3], f32x16 (&accP)[
 }
 
 template <typename TO, int EPI, int E0, int E1>
-__device__ __forceinline__ void nt4_final(f32x16 (&accP)[3][3], f32x4 (&rbk)[4], u32x2 (&hold)[4], f32x4 (&bias)[3], const Nt4Uni& u, const Nt4Lane& l, unsigned char* smem) {
+__device__ __forceinline__ void nt4_final(f32x16 (&accP)[3][3], f32x4 (&rbk)[4], u32x2 (&hold)[8], f32x4 (&bias)[3], const Nt4Uni& u, const Nt4Lane& l, unsigned char* smem) {
   Nt4Aux<EPI> ax[E1 - E0];
 #pragma unroll
   for (int e = E0; e < E1; ++e)
@@ -439,7 +461,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt4_kernel(const bf16_t* A, lon
   f32x16 accC[3][3], accP[3][3];
   bf16x8 fa[2][3], fb[2][3];
   f32x4 rbk[4], bias[3];
-  u32x2 hold[4];
+  u32x2 hold[8];          // packed results held for the next window: [0..3] C, [4..7] the derivative (GELUD)
   Nt4Act act;
   Nt4Aux<EPI> aux[2];
 #pragma unroll
@@ -467,7 +489,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt4_kernel(const bf16_t* A, lon
   nt4_window_end<0, EPI>(u, aux, bias);           // k-tiles 1 and 2 have landed
   u.dma_off = 0;                                  // the stage k-tile 0 leaves at the end of the next window's k-step 3 ... which IS where piece 0 is issued (slot 4 of k-step 3: after this barrier every wave holds its k-step-3 fragments)
   const int nk = u.nk;
-  constexpr bool HOLD = EPI == EPI_GELU || EPI == EPI_DGELU;      // results held one window (see nt4_unit)
+  constexpr bool HOLD = EPI == EPI_GELU || EPI == EPI_DGELU || EPI == EPI_GELUD;      // results held one window (see nt4_unit)
   for (int t = 0;; ++t) {
     int w0 = 0;
     if (t > 0) {
@@ -508,8 +530,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt4_kernel(const bf16_t* A, lon
 }
 
 #ifndef NT4_SLP_BUILD
-int g_nt4 = 1;             // climb_set_option 17: 0 = never; 1 (default) = every epilogue but GELU -- inside a step (cold operands) the 8-wave kernel is the
-                           // faster one there: 83.1 vs 89.5 us, the step 10.37 vs 10.43 ms; 3 = GELU too; 2 = GELU too, the build WITHOUT packed arithmetic (A/B)
+int g_nt4 = 1;             // climb_set_option 17: 0 = never; 1 (default) = every epilogue but GELU / GELUD -- inside a step (cold operands) the 8-wave kernel was the
+                           // faster one there with the r04 polynomial: 83.1 vs 89.5 us, the step 10.37 vs 10.43 ms; 3 = those too; 4 = GELUD but not GELU;
+                           // 2 = everything on the build WITHOUT packed arithmetic (A/B)
 int g_nt4_probe = 0;       // climb_set_option 18 (measurement)
 int g_nt4_grid = 256;      // follows climb_set_option 9 (CUs left to RCCL)
 void climb_nt4_set_probe(int v) { g_nt4_probe = v; }
@@ -536,7 +559,7 @@ static int nt4_launch_one(int nwg, hipStream_t st, const bf16_t* A, long lda, co
 
 int climb_nt4_launch(const bf16_t* A, long lda, const bf16_t* B, long ldb, void* C, long ldc, int c_dtype, int M, int N, int K, const float* bias, int epi,
                      const void* aux, long ldaux, bf16_t* aux_out, long ldauxo, hipStream_t st) {
-  if (g_nt4 == 0 || (g_nt4 == 1 && epi == EPI_GELU)) return CLIMB_EUNSUPPORTED;
+  if (g_nt4 == 0 || (g_nt4 == 1 && (epi == EPI_GELU || epi == EPI_GELUD)) || (g_nt4 == 4 && epi == EPI_GELU)) return CLIMB_EUNSUPPORTED;
 #ifndef NT4_SLP_BUILD
   if (g_nt4 == 2) return climb_nt4slp_launch(A, lda, B, ldb, C, ldc, c_dtype, M, N, K, bias, epi, aux, ldaux, aux_out, ldauxo, st);
 #endif
@@ -560,9 +583,11 @@ int climb_nt4_launch(const bf16_t* A, long lda, const bf16_t* B, long ldb, void*
 #undef L4P
 #endif
   if (c_dtype == CLIMB_DT_BF16 && epi == EPI_NONE) L4(bf16_t, EPI_NONE);
-  if ((epi == EPI_GELU || epi == EPI_DGELU) && K < 11 * GB_BK) return CLIMB_EUNSUPPORTED;      // one more k-tile: the held results of the ninth block
+  if (c_dtype == CLIMB_DT_BF16 && epi == EPI_MUL) L4(bf16_t, EPI_MUL);
+  if ((epi == EPI_GELU || epi == EPI_DGELU || epi == EPI_GELUD) && K < 11 * GB_BK) return CLIMB_EUNSUPPORTED;      // one more k-tile: the held results of the ninth block
   if (c_dtype == CLIMB_DT_BF16 && epi == EPI_GELU) L4(bf16_t, EPI_GELU);
   if (c_dtype == CLIMB_DT_BF16 && epi == EPI_DGELU) L4(bf16_t, EPI_DGELU);
+  if (c_dtype == CLIMB_DT_BF16 && epi == EPI_GELUD) L4(bf16_t, EPI_GELUD);
   if (c_dtype == CLIMB_DT_F32 && epi == EPI_RESID) L4(float, EPI_RESID);
   if (c_dtype == CLIMB_DT_F32 && epi == EPI_NONE) L4(float, EPI_NONE);
 #undef L4

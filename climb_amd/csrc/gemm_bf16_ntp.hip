@@ -586,7 +586,7 @@ int climb_nt256_launch(int bn, const bf16_t* A, long lda, const bf16_t* B, long 
   // 16 residual float4s per lane next to 128 accumulators spill (measured: 80 B/lane of scratch): the residual epilogue only exists
   // for the 192-wide tile, which is also the width the layer's residual GEMMs (N = 768) tile best with
   // (the x GELU' epilogue at 256 columns spills 64 - 72 B/lane as well -- its pre-activation operand next to 128 accumulators -- and goes the same way)
-  if (epi == EPI_RESID || epi == EPI_DGELU) bn = 192;
+  if (epi == EPI_RESID || epi == EPI_DGELU || epi == EPI_MUL) bn = 192;
   if (bn == 192) {
     const int rc = ntsk_try(A, lda, B, ldb, C, ldc, c_dtype, M, N, K, bias, epi, aux, ldaux, aux_out, ldauxo, st);
     if (rc != CLIMB_EUNSUPPORTED) return rc;
@@ -608,10 +608,15 @@ int climb_nt256_launch(int bn, const bf16_t* A, long lda, const bf16_t* B, long 
     default: break;                         \
   }
   if (c_dtype == CLIMB_DT_F32 && bn == 256) { LNTP_EPI256(float) }
-  if (c_dtype == CLIMB_DT_BF16 && bn == 256) { LNTP_EPI256(bf16_t) }
+  if (c_dtype == CLIMB_DT_BF16 && bn == 256) { LNTP_EPI256(bf16_t) if (epi == EPI_GELUD) LNTP(bf16_t, EPI_GELUD, 4); }
 #undef LNTP_EPI256
   if (c_dtype == CLIMB_DT_F32 && bn == 192) { LNTP_EPI(float, 3) if (epi == EPI_RESID) LNTP(float, EPI_RESID, 3); }
-  if (c_dtype == CLIMB_DT_BF16 && bn == 192) { LNTP_EPI(bf16_t, 3) if (epi == EPI_RESID) LNTP(bf16_t, EPI_RESID, 3); }
+  if (c_dtype == CLIMB_DT_BF16 && bn == 192) {
+    LNTP_EPI(bf16_t, 3)
+    if (epi == EPI_RESID) LNTP(bf16_t, EPI_RESID, 3);
+    if (epi == EPI_GELUD) LNTP(bf16_t, EPI_GELUD, 3);
+    if (epi == EPI_MUL) LNTP(bf16_t, EPI_MUL, 3);
+  }
 #undef LNTP_EPI
 #undef LNTP
   return CLIMB_EUNSUPPORTED;

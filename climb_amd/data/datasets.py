@@ -161,13 +161,22 @@ def _read_jsonl(path: str):
 
 
 def _load_or_build_cache(cache_file: str, build):
+    """The reference's parse caches (REF/data/visionlanguage_datasets/*: `pkl.load` if the file exists, else parse and `pkl.dump`).  Under N ranks
+    every process builds its datasets at the same moment: a cache file is therefore written to a temporary name and renamed into place (a reader
+    either sees no file or a whole one), and a file that cannot be unpickled -- somebody else's half-written one from before this rule, a
+    truncated copy -- is parsed again instead of failing the run (found by the two-rank driver test: rank 1 read the file rank 0 was writing)."""
     if os.path.exists(cache_file):
-        with open(cache_file, "rb") as f:
-            return pkl.load(f)
+        try:
+            with open(cache_file, "rb") as f:
+                return pkl.load(f)
+        except (EOFError, pkl.UnpicklingError):
+            pass
     data = build()
     if os.path.isdir(os.path.dirname(cache_file)):          # the reference's data trees ship these directories; never create them
-        with open(cache_file, "wb") as f:
+        tmp = f"{cache_file}.tmp.{os.getpid()}"
+        with open(tmp, "wb") as f:
             pkl.dump(data, f)
+        os.replace(tmp, cache_file)
     return data
 
 

@@ -25,9 +25,16 @@ _FUSED_ADAPTER = os.environ.get("CLIMB_AMD_FUSED_ADAPTER", "1") != "0"       # m
 # "0" = off (one split GEMM + reduce per weight, the r02 path); default: all layers in one launch, 4 per launch under a data-parallel hook
 # (ranges must become ready in a few chunks for the all-reduce to overlap the rest of the backward)
 _DW_GROUP = os.environ.get("CLIMB_AMD_DW_GROUP")
+_NT_GRID_BEFORE_RESERVE = 0        # library-wide persistent NT grid (option 9) in force before the first CU reserve
+_NT_RESERVING = set()              # engines that currently hold a reserve
 _RED_BATCH = os.environ.get("CLIMB_AMD_RED_BATCH", "1") != "0"          # measurement knob: 0 = one reduce launch per LayerNorm backward
 _UNSCALE_MODE = os.environ.get("CLIMB_AMD_FP16_UNSCALE", "end")      # measurement knob: "range" (per finished range), "end" (one pass), "none" (timing only)
-EPI_NONE, EPI_GELU, EPI_RESID, EPI_DGELU, EPI_TANH, EPI_SILU, EPI_DSILU, EPI_RESID2 = 0, 1, 2, 3, 4, 5, 6, 7
+EPI_NONE, EPI_GELU, EPI_RESID, EPI_DGELU, EPI_TANH, EPI_SILU, EPI_DSILU, EPI_RESID2, EPI_GELUD, EPI_MUL = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
+# r05: what the MLP's up-projection saves for the backward in the 16-bit modes.  "deriv" (default): gelu'(pre-activation), computed in the forward
+# epilogue from the sigmoid the activation needs anyway (5 more operations per element), so that the backward's epilogue is ONE multiply per element
+# (EPI_GELUD / EPI_MUL); "pre": the pre-activation itself, the derivative evaluated in the backward (EPI_GELU / EPI_DGELU; the r01 - r04 scheme and what
+# the fp32 parity mode does).  Same arithmetic up to the 16-bit rounding of the saved tensor.
+GELU_SAVE = os.environ.get("CLIMB_AMD_GELU_SAVE", "deriv")
 
 
 # r04: the pooler / task-head products on csrc/heads.hip (0 = the r01-r03 launches: split-K GEMMs with atomics + separate activations)
@@ -190,6 +197,9 @@ class ViltEngine:
             self.t16 = _lib.torch_h16()
         self.precision_name = precision
         precision = "fp32" if precision == "fp32" else "bf16"      # the two code paths; `h16` says which 16-bit type the second one runs on
+        # the GELU pair's epilogue codes (GELU_SAVE above): ws.u holds gelu'(pre-activation) under "deriv", the pre-activation otherwise
+        deriv = precision == "bf16" and GELU_SAVE == "deriv"
+        self.epi_gelu, self.epi_dgelu = (EPI_GELUD, EPI_MUL) if deriv else (EPI_GELU, EPI_DGELU)
         self.loss_scale = 1.0           # fp16 only: factor on d(logits) of the current backward, divided out of every range in _ready()
         self._grad_dirty = False        # the gradient buffer holds sums of earlier backwards (accumulation without zero_grad)
         # r04: the optimizer in the epilogue of the grouped weight-gradient launch.  `defer_dw` is armed by a caller that promises optimizer.step()
@@ -199,6 +209,7 @@ class ViltEngine:
         self._dw_deferred = []          # [(ws, plan)]
         self._grad_extra = False        # the weight matrices' gradient ranges hold something besides zeros (EWC penalty term, an earlier backward)
         self._grad_clean = False        # set by FusedAdamW.step() when it leaves the gradient buffer all zeros; any backward clears it (before_backward)
+        self._fused_consumed = False    # the last FusedAdamW.step() updated matrices inside the weight-gradient launch (their gradients were never stored)
         self._g16 = None                # data parallel: {stage, scale, ranges}: averaged gradients that still live in the reducer's 16-bit payload buffer
         self._unscale_pending = self._prescaled = False
         self.layout = layout
@@ -271,6 +282,7 @@ class ViltEngine:
         self._grad_dirty = False
         self._dw_deferred = []          # gradients nobody asked for are never computed
         self._grad_extra = False
+        self._fused_consumed = False
 
     def materialize_g16(self):
         """Cast averaged gradients the data-parallel reducer left in its 16-bit payload buffer (GradientAllReducer.finish(defer_uncast=True)) back into
@@ -537,7 +549,9 @@ class ViltEngine:
             e0.record()
             _lib.call(name, *args)
             e1.record()
-            prof["events"].append((e0, e1, flops))
+            # (bench.py's per-kind table) an NT GEMM launch is named by its output width, reduction depth, epilogue and output type
+            kind = f"N{args[8]}_K{args[9]}_epi{args[11]}_{'f32' if args[6] == F32 else 'h16'}" if name == "climb_gemm_bf16_nt" else name
+            prof["events"].append((e0, e1, flops, kind))
         else:
             _lib.call(name, *args)
 
@@ -589,6 +603,10 @@ class ViltEngine:
             if nseq is None or T + 1 + nseq > 288:
                 raise NotImplementedError(f"sequence of {T + 1 + (nseq or gh * gw)} tokens exceeds the 288 this build sizes its attention tiles for")
         ws = self.workspace(B, T, gh, gw, nseq)
+        if self._dw_deferred and any(w is ws for w, _ in self._dw_deferred):
+            # a held-back weight-gradient launch still points at this workspace's saved activations (a no-grad forward between backward and step,
+            # or a step that never came): run it now, as the plain launch, before they are overwritten
+            self.materialize_dw()
         if not save and self.saved is not None and self.saved["ws"] is ws:
             # a grad-enabled forward of this shape is still waiting for its backward (reference-style autograd path: an evaluation or a
             # teacher pass between `model(...)` and `loss.backward()`): its saved activations live in `ws`, so this pass gets its own
@@ -634,7 +652,7 @@ class ViltEngine:
                                  EPI_RESID, x, SH, out_f32=True)
                 _lib.call("climb_layernorm_fwd", ws.h1c, H, self.p(l + "layernorm_after.weight"), self.p(l + "layernorm_after.bias"), cfg["ln_eps"],
                           ws.hnc, H, adt, ws.mean2c, ws.rstd2c, B, H, st)
-                self._lin_fwd_ld(ws.hnc, H, l + "intermediate.dense.weight", l + "intermediate.dense.bias", ws.ac, Fd, B, Fd, H, EPI_GELU,
+                self._lin_fwd_ld(ws.hnc, H, l + "intermediate.dense.weight", l + "intermediate.dense.bias", ws.ac, Fd, B, Fd, H, self.epi_gelu,
                                  None, 0, ws.uc, Fd)
                 self._lin_fwd_ld(ws.ac, Fd, l + "output.dense.weight", l + "output.dense.bias", ws.xLc, H, B, H, Fd, EPI_RESID, ws.h1c, H, out_f32=True)
                 continue
@@ -646,7 +664,7 @@ class ViltEngine:
                 self.adapter_fwd(a_, ws.ya[i], x, ws.za[i], ws.sa[i], ws.h1[i], M, H, r)
             _lib.call("climb_layernorm_fwd", ws.h1[i], H, self.p(l + "layernorm_after.weight"), self.p(l + "layernorm_after.bias"), cfg["ln_eps"],
                       ws.hn[i], H, adt, ws.mean2[i], ws.rstd2[i], M, H, st)
-            self.linear_fwd(ws.hn[i], l + "intermediate.dense.weight", l + "intermediate.dense.bias", ws.a[i], M, Fd, H, EPI_GELU, None, ws.u[i])
+            self.linear_fwd(ws.hn[i], l + "intermediate.dense.weight", l + "intermediate.dense.bias", ws.a[i], M, Fd, H, self.epi_gelu, None, ws.u[i])
             if ad is None:
                 self.linear_fwd_resid(ws.a[i], l + "output.dense.weight", l + "output.dense.bias", ws.x[i + 1], M, H, Fd, ws.h1[i])
             else:
@@ -736,10 +754,20 @@ class ViltEngine:
         if self.precision == "bf16":
             # the persistent NT grid is a library-wide setting: remember what was in force before the FIRST reserve (the library default, or a grid
             # pinned through CLIMB_AMD_OPTIONS / tools) and put exactly that back with n = 0
-            if self._cu_reserve == 0:
-                self._nt_grid_before_reserve = int(_lib.query_arg("climb_get_option", 9))
-            base = self._nt_grid_before_reserve
-            _lib.call("climb_set_option", 9, base if n == 0 else max(8, (base - n) // 8 * 8))
+            #  the saved value lives at module level -- the setting is the library's, not this engine's: engines that reserve in turn must
+            # not restore each other's reduced grids -- and 0 ("uncapped") counts as every CU when the reduced grid is computed
+            global _NT_GRID_BEFORE_RESERVE, _NT_RESERVING
+            if not _NT_RESERVING:
+                _NT_GRID_BEFORE_RESERVE = int(_lib.query_arg("climb_get_option", 9))
+            base = _NT_GRID_BEFORE_RESERVE
+            if n == 0:
+                _NT_RESERVING.discard(id(self))
+                if not _NT_RESERVING:
+                    _lib.call("climb_set_option", 9, base)
+            else:
+                _NT_RESERVING.add(id(self))
+                full = base if base > 0 else torch.cuda.get_device_properties(self.device).multi_processor_count
+                _lib.call("climb_set_option", 9, max(8, (full - n) // 8 * 8))
         self._cu_reserve = n
 
     def _dw_defer(self, pending: list, dY, X, wname, M, N, K, bname=None, ws=None):
@@ -825,6 +853,8 @@ class ViltEngine:
             for cv, f in zip(cover, flags):
                 if f:
                     done.update(cv)
+        if done:
+            self._fused_consumed = True
         return done
 
     def _red_flush(self, ws: Workspace, pending: list):
@@ -970,7 +1000,7 @@ class ViltEngine:
                                                dxc(i + 1), ws.dz_l[2 * i + 1] if G else ws.dz, dw)
                     dw(dy, ws.a[i], l + "output.dense.weight", M, H, Fd, l + "output.dense.bias", ws)
                 du = du_(i)
-                self.linear_dx(dy, l + "output.dense.weight", du, M, H, Fd, EPI_DGELU, ws.u[i])
+                self.linear_dx(dy, l + "output.dense.weight", du, M, H, Fd, self.epi_dgelu, ws.u[i])
                 dw(du, ws.hn[i], l + "intermediate.dense.weight", M, Fd, H, l + "intermediate.dense.bias", ws)
                 self.linear_dx(du, l + "intermediate.dense.weight", ws.dhn, M, Fd, H)
                 self.join_side()          # LN backward overwrites d(residual) that dW2 is reading
@@ -1039,7 +1069,7 @@ class ViltEngine:
         dy, lddy = (ws.dres, SH) if f32 else (ws.dyc, H)
         # x_L = h1 + W2 gelu(u) + b2,  u = W1 hn + b1
         self._lin_dw_ld(dy, lddy, ws.ac, Fd, l + "output.dense.weight", B, H, Fd)
-        self._lin_dx_ld(dy, lddy, l + "output.dense.weight", ws.duc, Fd, B, H, Fd, EPI_DGELU, ws.uc, Fd)
+        self._lin_dx_ld(dy, lddy, l + "output.dense.weight", ws.duc, Fd, B, H, Fd, self.epi_dgelu, ws.uc, Fd)
         self._lin_dw_ld(ws.duc, Fd, ws.hnc, H, l + "intermediate.dense.weight", B, Fd, H, l + "intermediate.dense.bias", ws)
         self._lin_dx_ld(ws.duc, Fd, l + "intermediate.dense.weight", ws.dhnc, H, B, Fd, H)
         # hn = LN(h1): d(h1) = d(x_L) + LN'(d(hn)), in place in the [CLS] rows of the residual-gradient stream

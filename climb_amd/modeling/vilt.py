@@ -208,12 +208,26 @@ class _EngineHost:
         """If the caller dropped `.grad` (nn.Module.zero_grad / optimizer.zero_grad(set_to_none=True)) since our last
         backward, the flat gradient buffer is stale: clear it so that accumulation semantics match `.grad`."""
         eng = self._engine
+        # a weight-gradient launch that was held back for an optimizer step that never came (ADVICE r4): it reads the saved activations of its
+        # workspace through raw pointers, so it has to run BEFORE the next forward overwrites them, as the plain launch (C += dW)
+        if eng._dw_deferred:
+            eng.materialize_dw()
         if eng.touched:
             for n, p in self._params.items():
                 if p.requires_grad and eng.is_touched(n):
                     if p.grad is None:
                         eng.zero_grad()
                     break
+        if eng.touched:
+            # gradients of an earlier backward were kept (accumulation, torch's semantics when zero_grad() is not called): the matrices' ranges hold
+            # sums too, whichever launch wrote them (plain grouped, immediate, the non-fused problems of a fused launch) -- the optimizer-carrying
+            # epilogue must add what is there instead of assuming zeros
+            eng._grad_extra = True
+            if eng._fused_consumed:
+                import warnings
+                warnings.warn("climb_amd: backward on top of gradients that FusedAdamW.step() already consumed inside the weight-gradient launch "
+                              "(no zero_grad() since): those matrices' earlier gradients were never stored and are not part of the accumulated sum")
+        eng._fused_consumed = False
         eng._grad_clean = False          # gradients are about to be written
         if eng._g16 is not None:         # (a backward on top of averaged gradients nobody consumed: they belong in the buffer this one accumulates into)
             eng.materialize_g16()

@@ -350,6 +350,8 @@ def init_data_parallel(backend: Optional[str] = None):
 _real_torch_save = None
 _real_makedirs = None
 _real_json_dump = None
+COLLECTIVE_JSON = {"results.json", "eval_results.json", "lowshot_results.json"}      # a launcher may register more names
+IO_LOG_MAX = 4096    # entries kept (long runs: the log is for tests and post-mortems, not an unbounded record)
 io_log = []          # (kind, path, wrote) per collective file operation of this process: what tests assert "one writer per file" on
 
 
@@ -383,21 +385,26 @@ def rank0_only_io():
         if rank == 0 or not is_path:
             _real_torch_save(obj, f, *a, **kw)
         if is_path:
-            io_log.append(("torch.save", os.fspath(f), rank == 0))
+            if len(io_log) < IO_LOG_MAX:
+                io_log.append(("torch.save", os.fspath(f), rank == 0))
             dist.barrier()
     torch.save = save
 
     def dump(obj, fp, *a, **kw):
         path = getattr(fp, "name", None)
-        if not (isinstance(path, str) and "w" in getattr(fp, "mode", "") and os.path.isfile(path)):
-            return _real_json_dump(obj, fp, *a, **kw)          # not a file on disk opened for writing: nobody else's business
+        # only the drivers' own results files are written collectively (REF/train/train_upstream_continual_learning.py:277,327,
+        # train_lowshot_multimodal.py:183,233): any other json.dump -- run metadata, a library's or one rank's own log file -- need not be called by
+        # every rank the same number of times, and a barrier inside it would dead-lock or mis-pair
+        if not (isinstance(path, str) and "w" in getattr(fp, "mode", "") and os.path.isfile(path) and os.path.basename(path) in COLLECTIVE_JSON):
+            return _real_json_dump(obj, fp, *a, **kw)
         dist.barrier()                                          # every rank is past its open(path, "w")
         if rank == 0:
             tmp = f"{path}.tmp.{os.getpid()}"
             with open(tmp, "w") as t:
                 _real_json_dump(obj, t, *a, **kw)
             os.replace(tmp, path)
-        io_log.append(("json.dump", path, rank == 0))
+        if len(io_log) < IO_LOG_MAX:
+            io_log.append(("json.dump", path, rank == 0))
         dist.barrier()
     json.dump = dump
 

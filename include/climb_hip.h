@@ -158,7 +158,9 @@ int climb_transpose_bf16_batched(const void* src, void* dst, const long* table, 
 /* nn.Linear forward and input-gradient GEMMs (HF:325-327, :366-369, :397-400, :410-414):
  * C[M,N] (c_dtype) = epi(A[M,K] B[N,K]^T + bias); A,B bf16, K contiguous.  epi 1: aux_out (bf16) = pre-activation;
  * epi 2: aux = fp32 residual [M,N]; epi 3: aux = bf16 pre-activation (multiplies by gelu'); epi 5/6: SiLU / silu' likewise;
- * epi 7: aux = fp32 residual, aux2 = bf16 residual (Houlsby adapter up-projection: out = up(s) + sublayer_out + x). */
+ * epi 7: aux = fp32 residual, aux2 = bf16 residual (Houlsby adapter up-projection: out = up(s) + sublayer_out + x).
+ * r05, 16-bit C only: epi 8 = GELU whose aux_out receives gelu'(pre-activation) instead of the pre-activation (HF/modeling_vilt.py:393, 397-414: the
+ * intermediate activation and what its backward needs); epi 9: C = (A B^T) * aux, aux = the 16-bit tensor epi 8 saved. */
 int climb_gemm_bf16_nt(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int c_dtype, int M, int N, int K, const float* bias, int epi, const void* aux, long ldaux, void* aux_out, long ldauxo, const void* aux2, long ldaux2, void* stream);
 /* Houlsby bottleneck adapter forward in one launch (16-bit mode; replaces the two skinny NT GEMMs of engine.py's adapter branch, which follow
  * the GLAMOR fork's arithmetic as restated in climb_amd/cl_algorithms/adapters.py): z = y wd^T + bd; s = silu(z); out = resid + y + s wu^T + bu.

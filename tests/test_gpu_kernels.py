@@ -645,6 +645,28 @@ def test_gemm_bf16_nt(M, N, K):
     ur = Uin.cpu().double().requires_grad_(True)
     gelu(ur).backward(A.double() @ W.double().t())
     assert _rel(C16.float(), ur.grad) < 5e-3
+    _check_saved_derivative_pair(Ad, Wd, bd, Uin, ref, A.double() @ W.double().t(), M, N, K)
+
+
+def _check_saved_derivative_pair(Ad, Wd, bd, Uin, ref, ref_nobias, M, N, K):
+    """r05, epilogue codes 8 / 9: the forward saves gelu'(pre-activation) next to gelu(pre-activation), the backward multiplies by what was saved."""
+    from climb_amd import _lib
+    dev = Ad.device
+    C16 = torch.empty(M, N, device=dev, dtype=_h16())
+    D = torch.empty(M, N, device=dev, dtype=_h16())
+    _lib.call("climb_gemm_bf16_nt", Ad, K, Wd, K, C16, N, 1, M, N, K, bd, 8, None, 0, D, N, None, 0, _st())
+    pre = ref.clone().requires_grad_(True)
+    gelu(pre).sum().backward()
+    assert _rel(C16.float(), gelu(ref)) < 5e-3
+    assert float((D.float().cpu().double() - pre.grad).abs().max()) < 5e-3          # gelu' is O(1): 16-bit rounding of the stored value + 1.1e-4 of the sigmoid form
+    _lib.call("climb_gemm_bf16_nt", Ad, K, Wd, K, C16, N, 1, M, N, K, None, 9, Uin, N, None, 0, None, 0, _st())
+    assert _rel(C16.float(), ref_nobias * Uin.cpu().double()) < 5e-3
+    # no fp32 outputs for these codes, and the operands they need are checked
+    C32 = torch.empty(M, N, device=dev)
+    with pytest.raises(RuntimeError, match="climb_gemm_bf16_nt"):
+        _lib.call("climb_gemm_bf16_nt", Ad, K, Wd, K, C32, N, 0, M, N, K, None, 8, None, 0, D, N, None, 0, _st())
+    with pytest.raises(RuntimeError, match="climb_gemm_bf16_nt"):
+        _lib.call("climb_gemm_bf16_nt", Ad, K, Wd, K, C16, N, 1, M, N, K, None, 9, None, 0, None, 0, None, 0, _st())
 
 
 @pytest.mark.parametrize("force", [2, 3, 4])
@@ -677,6 +699,8 @@ def test_gemm_bf16_nt_256_tiles(M, N, K, force):
         ur = Uin.cpu().double().requires_grad_(True)
         gelu(ur).backward(A.double() @ W.double().t())
         assert _rel(C16.float(), ur.grad) < 5e-3
+        if force != 4:          # (the two-workgroup variant behind option 7 = 4 does not implement the r05 codes: they fall through to the default kernels)
+            _check_saved_derivative_pair(Ad, Wd, bd, Uin, ref, A.double() @ W.double().t(), M, N, K)
     finally:
         _lib.call("climb_set_option", 7, 1)
 
@@ -737,14 +761,15 @@ def test_gemm_bf16_nt4_two_accumulator_sets_bit_identical(M, N, K):
 
     def run(cdt, epi, aux, b):
         C = torch.full((M, N), float("nan"), device=dev, dtype=_h16() if cdt else torch.float32)
-        U = torch.full((M, N), float("nan"), device=dev, dtype=_h16()) if epi == 1 else None
+        U = torch.full((M, N), float("nan"), device=dev, dtype=_h16()) if epi in (1, 8) else None
         _lib.call("climb_gemm_bf16_nt", A, K, W, K, C, N, cdt, M, N, K, b, epi, aux, N, U, N, None, 0, _st())
         return [C] + ([U] if U is not None else [])
     try:
         rows = torch.arange(0, M, 61, device=dev)
         r64 = A[rows].double() @ W.double().t() + bias.double()
         for name, cdt, epi, aux, b in [("f32", 0, 0, None, bias), ("h16", 1, 0, None, bias), ("h16 no bias", 1, 0, None, None), ("gelu", 1, 1, None, bias),
-                                       ("resid", 0, 2, R, bias), ("dgelu", 1, 3, Uin, None)]:
+                                       ("resid", 0, 2, R, bias), ("dgelu", 1, 3, Uin, None), ("gelu + saved derivative", 1, 8, None, bias),
+                                       ("x saved derivative", 1, 9, Uin, None)]:
             _lib.call("climb_set_option", 17, 0)
             ref = run(cdt, epi, aux, b)
             if name == "f32":

@@ -1006,6 +1006,40 @@ def test_optimizer_in_the_weight_gradient_epilogue_is_the_same_training_step(con
         assert abs(a - b) <= 5e-3 * abs(a), (res[False], res[True])
 
 
+def test_held_back_weight_gradients_of_a_step_that_never_came_use_their_own_activations():
+    """a weight-gradient launch held back for `optimizer.step()` points at the saved activations of its workspace; when a second
+    backward (accumulation) or a no-grad forward of the same shape comes first, it has to run BEFORE that forward overwrites them.  Compared here
+    as GRADIENTS (a loss curve at lr 2e-5 cannot see it): two backwards on different batches with the promise, no step -> the accumulated `.grad`
+    of every tensor equals the same two backwards without the promise; and a no-grad forward between backward and step changes nothing either."""
+    if H16 != "bf16":
+        pytest.skip("the held-back launch is the bf16 build's")
+    dev = _dev()
+    G = {}
+    for promise in (False, True):
+        model, _ = make_model(["vqa"], 42, precision=H16)
+        model.train()
+        opt = model.create_optimizer({"lr": 2e-5, "weight_decay": 1e-2, "adam_epsilon": 1e-8})
+        opt.zero_grad()
+        eng = model._host.engine()
+        for seed in (900, 950):
+            pixels, texts, target = _rand_batch(8, seed, dev)
+            model.fused_forward_backward("vqa", pixels, texts, target, optimizer=opt if promise else None)
+        if promise:
+            assert eng._dw_deferred, "nothing was held back: the test does not exercise the path"
+            with torch.no_grad():          # an evaluation pass of the same shape between backward and step
+                model(task_key="vqa", images=_rand_batch(8, 970, dev)[0], texts=texts)
+            assert not eng._dw_deferred, "the held-back launch survived a forward that overwrote its operands"
+        eng.materialize_dw()
+        torch.cuda.synchronize()
+        G[promise] = {n: p.grad.detach().float().cpu().clone() for n, p in model.named_parameters() if p.grad is not None}
+        del model, opt
+    assert set(G[False]) == set(G[True])
+    for n, g in G[False].items():
+        scale = float(g.abs().max())
+        if scale > 0:
+            assert float((G[True][n] - g).abs().max()) <= 2e-2 * scale, n          # run-to-run 16-bit noise (atomics) only; stale operands give O(1)
+
+
 def test_full_size_batch_permutation_and_mode_agreement():
     """BASELINE.json configs[1] size (64 sequences x 185 tokens), where the CPU oracle would take minutes: size-independent
     properties instead.  (1) samples are independent: permuting the batch permutes pooled/logits and leaves the loss and every
@@ -1223,11 +1257,32 @@ def test_hipgraph_replay_matches_eager():
 
 
 # ------------------------------------------------------------------------------------------------ data parallel, end to end
-def _dp_worker(rank, world, port, q, precision, gbatch=4, promise=False):
+def dp_join(rank, world, port, backend):
+    """Join a `world`-rank job from a spawned test process.  "gloo": every rank on the test box's one GPU (collectives on device tensors through the
+    host).  "nccl" (= RCCL; needs >= `world` GPUs): rank r sees ONLY GPU r -- as cuda:0, which is what every helper of this file uses -- the
+    one-process-per-GPU layout of the product (climb_amd/parallel.py::init_data_parallel).  Must run before the process touches the device."""
     import os as _os
     _os.environ["MASTER_ADDR"], _os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     import torch.distributed as dist
-    dist.init_process_group("gloo", rank=rank, world_size=world)          # both ranks share the one GPU of the test box
+    if backend == "nccl":
+        _os.environ["HIP_VISIBLE_DEVICES"] = str(rank)
+        _os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda:0"))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    return dist
+
+
+def need_backend(backend, world=2):
+    if backend == "nccl" and torch.cuda.device_count() < world:
+        pytest.skip(f"RCCL with {world} ranks needs {world} GPUs (this box has {torch.cuda.device_count()}); the gloo variant covers the host logic")
+
+
+BACKENDS = ["gloo", "nccl"]
+
+
+def _dp_worker(rank, world, port, q, precision, gbatch=4, promise=False, backend="gloo"):
+    dist = dp_join(rank, world, port, backend)
     try:
         from climb_amd.parallel import GradientAllReducer
         torch.manual_seed(1000 + rank)                                     # replicas start DIFFERENT: the broadcast must fix that
@@ -1261,7 +1316,7 @@ def _dp_worker(rank, world, port, q, precision, gbatch=4, promise=False):
         dist.destroy_process_group()
 
 
-def _run_two_ranks(precision, gbatch, promise):
+def _run_two_ranks(precision, gbatch, promise, backend="gloo"):
     import socket
     import torch.multiprocessing as mp
     s = socket.socket()
@@ -1270,10 +1325,27 @@ def _run_two_ranks(precision, gbatch, promise):
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q, precision, gbatch, promise)) for r in range(2)]
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q, precision, gbatch, promise, backend)) for r in range(2)]
+    return collect_ranks(procs, q)
+
+
+def collect_ranks(procs, q, timeout=600):
+    """start the rank processes, gather one queue item per rank; a rank that dies fails the test at once (not after the queue's timeout)"""
+    import queue as _queue
+    import time as _time
     for p in procs:
         p.start()
-    res = [q.get(timeout=600) for _ in procs]
+    res, t0 = [], _time.time()
+    while len(res) < len(procs):
+        try:
+            res.append(q.get(timeout=2))
+        except _queue.Empty:
+            dead = [(i, p.exitcode) for i, p in enumerate(procs) if p.exitcode not in (None, 0)]
+            if dead or _time.time() - t0 > timeout:
+                for p in procs:
+                    if p.is_alive():
+                        p.kill()
+                raise AssertionError(f"rank processes died (rank, exit code) {dead}" if dead else f"no result after {timeout} s")
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
@@ -1281,15 +1353,17 @@ def _run_two_ranks(precision, gbatch, promise):
     return res
 
 
-def test_data_parallel_optimizer_reads_the_averaged_payload_in_place():
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_data_parallel_optimizer_reads_the_averaged_payload_in_place(backend):
     """r04: with the trainers' promise (`fused_forward_backward(..., optimizer=opt)`) the reducer leaves the averaged 16-bit payload in its staging
     buffer and FusedAdamW's flat pass reads it there with the averaging factor folded in (`climb_adamw_spans`, source 1) instead of an un-cast pass
     into the gradient buffer followed by a re-read.  Same arithmetic: after two steps on two ranks the parameters are what the run WITHOUT the promise
     produces (16-bit GEMM order noise aside: the two runs are separate processes), both replicas in sync."""
     if H16 == "fp32":
         pytest.skip("16-bit payload only")
-    a = _run_two_ranks(H16, 4, False)
-    b = _run_two_ranks(H16, 4, True)
+    need_backend(backend)
+    a = _run_two_ranks(H16, 4, False, backend)
+    b = _run_two_ranks(H16, 4, True, backend)
     assert all(r[1] for r in a) and all(r[1] for r in b), "replicas diverged"
     assert b[0][3] is True, "nothing was deferred: the optimizer did not read the payload buffer"
     # (sum, sum |.|, sum of squares) of all 116 M parameters after the two steps.  The two runs are separate processes and a 16-bit step is not
@@ -1301,29 +1375,16 @@ def test_data_parallel_optimizer_reads_the_averaged_payload_in_place():
         assert abs(la - lb) <= 2e-3 * abs(la)
 
 
+@pytest.mark.parametrize("backend", BACKENDS)
 @pytest.mark.parametrize("gbatch", [4, 3])
 @pytest.mark.parametrize("precision,tol", [("fp32", 1e-4), (H16, 4e-2)])      # bf16: payload rounding 2^-9 + bf16 GEMM order noise
-def test_data_parallel_two_ranks_equals_single_process_on_the_global_batch(precision, tol, gbatch):
+def test_data_parallel_two_ranks_equals_single_process_on_the_global_batch(precision, tol, gbatch, backend):
     """Two processes (gloo collectives on device tensors, both on the test box's single GPU) train on halves of a batch of 4 through the
     real engine hooks: weights broadcast from rank 0, per-range gradient all-reduce during the backward, finish() before AdamW.
     The averaged gradients equal (fp32 summation order aside) those of ONE process on the whole batch -- the loss is a batch mean,
     so the average of the shard gradients is the global gradient -- and after two optimizer steps the replicas are bit-identical."""
-    import socket
-    import torch.multiprocessing as mp
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q, precision, gbatch)) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = [q.get(timeout=600) for _ in procs]
-    for p in procs:
-        p.join(timeout=120)
-        assert p.exitcode == 0
-    res.sort(key=lambda r: r[0])
+    need_backend(backend)
+    res = _run_two_ranks(precision, gbatch, False, backend)
     assert all(r[1] for r in res), "replicas diverged"
     assert res[0][4] > 0 and res[0][4] == res[1][4]
     # single process, global batch: its gradient is what the ranks' averaged gradient must be
