@@ -359,11 +359,12 @@ extern "C" int climb_set_option(int key, int value) {
   if (key == 15 && (value == 0 || value == 1)) { climb_ntp_set_sw(value); return CLIMB_OK; }
   if (key == 16 && value >= 0 && value < 4000) { climb_ntp_set_dephase(value); return CLIMB_OK; }
   if (key == 9 && value >= 0) { climb_nt256_set_grid(value); climb_nt4_set_grid(value); return CLIMB_OK; }
-  if (key == 17 && value >= 0 && value <= 3) { climb_nt4_set(value); return CLIMB_OK; }
+  if (key == 17 && value >= 0 && value <= 5) { climb_nt4_set(value); return CLIMB_OK; }
   if (key == 18 && value >= 0) { climb_nt4_set_probe(value); return CLIMB_OK; }
   if (key == 19 && value >= 0 && value <= 2) { climb_skinny_set_probe(value); return CLIMB_OK; }
   if (key == 20 && value >= 0) { climb_attn_set_1pp_grid(value); return CLIMB_OK; }
   if (key == 21 && value >= 1 && value <= 3) { climb_ln_set_rpw(value); return CLIMB_OK; }
+  if (key == 22 && value >= 0 && value <= 116) { climb_tn_set_stagger(value); return CLIMB_OK; }
   if (key == 6 && (value == 4 || value == 8)) { g_tn_waves = value; return CLIMB_OK; }
   if (key == 3 && value > 0) { g_tn_target = value; return CLIMB_OK; }
   return CLIMB_EINVAL;

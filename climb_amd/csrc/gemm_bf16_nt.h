@@ -230,6 +230,7 @@ void climb_nt256_set_grid(int v);       // workgroups launched at most (0 = one 
 // shapes it does not take (the caller then uses the 128 x 128 kernel)
 int climb_tnp_launch(const bf16_t* A, long lda, const bf16_t* B, long ldb, float* C, long ldc, int M, int N, int K, float* dbias, hipStream_t st);
 void climb_tnp_set_workspace(void* ptr, long bytes);
+void climb_tn_set_stagger(int groups);      // climb_set_option 22: phase groups of the grouped launch's plan (staggered epilogues; 0 / 1 = off)
 // gemm_bf16_nt2p.hip: 128 x 192 tiles, TWO persistent 4-wave workgroups per CU (the epilogue of one runs under the k-loop of the other)
 int climb_nt2_launch(const bf16_t* A, long lda, const bf16_t* B, long ldb, void* C, long ldc, int c_dtype, int M, int N, int K, const float* bias, int epi,
                      const void* aux, long ldaux, bf16_t* aux_out, long ldauxo, hipStream_t st);

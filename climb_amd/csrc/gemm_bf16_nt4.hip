@@ -29,11 +29,15 @@
 //
 // Takes: M % 192 == 0, N % 192 == 0, (M / 192) % 8 == 0, K % 64 == 0, K >= 640, epilogues NONE / GELU / RESID / DGELU.
 #include "gemm_bf16_nt.h"
-// A/B aid (r04): the file is compiled twice -- as is (the product: hipcc packs the GELU polynomials of two elements into v_pk_fma_f32), and with
-// -DNT4_SLP_BUILD -fno-slp-vectorize under other names for climb_set_option(17, 2) (measured: equal or 2 - 5 % slower on the GELU kinds)
+// A/B aid: the file is compiled twice -- as is (the product), and with -DNT4_SLP_BUILD under other names for climb_set_option(17, 2 | 5).  r04 used the
+// second build for the epilogue arithmetic without SLP packing (measured equal or 2 - 5 % slower on the GELU kinds); r05: the second build is the r04
+// WINDOW BOUNDARY (tile-walk bookkeeping with its branches between the barrier and the window's first MFMA), the product hides it (see nt4_dma_next).
 #ifdef NT4_SLP_BUILD
 #define gemm_bf16_nt4_kernel gemm_bf16_nt4slp_kernel
 #define climb_nt4_launch climb_nt4slp_launch
+#define NT4_OLD_BOUNDARY 1
+#else
+#define NT4_OLD_BOUNDARY 0
 #endif
 
 #define NT4_T 192
@@ -53,7 +57,17 @@ struct Nt4Lane {            // per-lane constants
 };
 struct Nt4Walk {            // tile walk of one stream (wave-uniform): tile = (xcd * gm + tml, tn)
   int tml, tn, gm, step, xcd;
-  __device__ __forceinline__ void advance() { tml += step; while (tml >= gm) { tml -= gm; ++tn; } }
+  int dm, dn;               // step = dn * gm + dm: the walk's increment without a loop (r05)
+  __device__ __forceinline__ void advance() {
+#if NT4_OLD_BOUNDARY
+    tml += step; while (tml >= gm) { tml -= gm; ++tn; }
+#else
+    const int t1 = tml + dm;
+    const bool c = t1 >= gm;
+    tml = c ? t1 - gm : t1;
+    tn += dn + (c ? 1 : 0);
+#endif
+  }
   __device__ __forceinline__ int m0() const { return (xcd * gm + tml) * NT4_T; }
   __device__ __forceinline__ int n0() const { return tn * NT4_T; }
 };
@@ -68,6 +82,7 @@ struct Nt4Uni {             // wave-uniform state
   Nt4Walk dw;
   int dkt, dleft, nk;
   unsigned curA, curB;           // byte offset of the stream's k-tile: tile rows + k
+  unsigned nxtA, nxtB;           // the NEXT window's (computed under this window's MFMAs, committed before its barrier)
   unsigned dma_off, rd_off;      // stage offsets: DMA destination / fragment reads of this window
   unsigned rda, rdb;             // rd_off + this wave's row base inside the A / B image
   // finished ("previous") tile: epilogue addressing
@@ -122,8 +137,26 @@ __device__ __forceinline__ void nt4_dma(const Nt4Uni& u, const Nt4Lane& l, unsig
     __builtin_amdgcn_raw_ptr_buffer_load_lds(u.rb, (lds_void_t*)(smem + u.dma_off + NT4_OP + (u.wid * 6 + (J - 6)) * 1024), 16, l.vo[2 + (J & 1)],
                                              u.curB + u.pb[J - 6], 0, 0);
 }
-// next k-tile of the DMA stream; past the workgroup's last k-tile it stays there (the same bytes again, into a stage nobody reads any more)
+// next k-tile of the DMA stream; past the workgroup's last k-tile it stays there (the same bytes again, into a stage nobody reads any more).
+// r05: WHERE this runs matters more than what it costs.  With one wave per SIMD nothing covers the instructions between a window's barrier and its first
+// MFMA: the r04 kernel ran this bookkeeping there, a dozen scalar instructions and four taken branches (k-tile wrap, last tile, the walk's while loop), and
+// the measurement builds of option 18 put the pure MFMA stream of a launch at 43 cycles per MFMA instead of 32.  Now it is branch-free (selects), computes
+// the NEXT window's offsets in a filler position of slot 20 (under the MFMAs), and nt4_window_end commits them BEFORE the barrier.
+__device__ __forceinline__ void nt4_dma_next(Nt4Uni& u) {
+  const int d1 = u.dkt + 1;
+  const bool wrap = d1 == u.nk, more = u.dleft > 1, adv = wrap && more;
+  u.dkt = wrap ? (more ? 0 : u.nk - 1) : d1;
+  u.dleft -= adv ? 1 : 0;
+  Nt4Walk w = u.dw;
+  w.advance();
+  u.dw.tml = adv ? w.tml : u.dw.tml;
+  u.dw.tn = adv ? w.tn : u.dw.tn;
+  u.nxtA = (unsigned)u.dw.m0() * u.lda2 + (unsigned)u.dkt * 128u;
+  u.nxtB = (unsigned)u.dw.n0() * u.ldb2 + (unsigned)u.dkt * 128u;
+}
+__device__ __forceinline__ void nt4_dma_commit(Nt4Uni& u) { u.curA = u.nxtA; u.curB = u.nxtB; }
 __device__ __forceinline__ void nt4_dma_advance(Nt4Uni& u) {
+#if NT4_OLD_BOUNDARY
   ++u.dkt;
   if (u.dkt == u.nk) {
     if (u.dleft > 1) { --u.dleft; u.dkt = 0; u.dw.advance(); }
@@ -131,6 +164,10 @@ __device__ __forceinline__ void nt4_dma_advance(Nt4Uni& u) {
   }
   u.curA = (unsigned)u.dw.m0() * u.lda2 + (unsigned)u.dkt * 128u;
   u.curB = (unsigned)u.dw.n0() * u.ldb2 + (unsigned)u.dkt * 128u;
+#else
+  nt4_dma_next(u);
+  nt4_dma_commit(u);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------- epilogue pieces of one 32 x 32 block
@@ -196,13 +233,23 @@ __device__ __forceinline__ u32x2 nt4_pack4(float a, float b, float c, float d) {
 // k-loop the GELU kinds spread their arithmetic over MFMA slots and HOLD the packed result for the next window (stores issued late in a window are
 // still unacknowledged at its end, and the window's counted wait then waits for them -- measured with cold operands: +27 us on the up-projection):
 // 0 = bias (+ the pre-activation store), 1..4 = element SUB - 1 (4 also packs into `hold`), 5 = store `hold`
+// r05: which kinds hold their packed results for the next window's first slots.  r04: the GELU kinds only (their stores would otherwise sit late in the
+// window).  The measurement builds say the same of every 16-bit kind: stores of slots 9 - 15 can still be unacknowledged at the window's end, and its
+// counted wait, vmcnt(12), cannot tell them from the DMA pieces it is about (loads and stores share the counter and complete out of order relative to
+// each other, so it must assume the stores are the ones still pending): +7 us on the QKV product with the drain in the windows against 37 without.
+template <typename TO, int EPI> constexpr bool nt4_holds() {
+  return EPI == EPI_GELU || EPI == EPI_DGELU || EPI == EPI_GELUD || (!NT4_OLD_BOUNDARY && sizeof(TO) == 2 && (EPI == EPI_NONE || EPI == EPI_MUL));
+}
 template <typename TO, int EPI, int SUB>
 __device__ __forceinline__ void nt4_unit(f32x4& v, u32x2& hold, const f32x4& bias, const Nt4Aux<EPI>& ax, int p, int bi, int bj, const Nt4Uni& u, const Nt4Lane& l) {
   const unsigned rowoff = (unsigned)(bi * 32 + 8 * p);
   const unsigned csoff = u.cbase + rowoff * u.ldc_b + (unsigned)(bj * 32 * (int)sizeof(TO));
-  if constexpr (EPI == EPI_NONE) {
+  if constexpr (SUB == 5) {                  // the held 16-bit result of an earlier window
+    __builtin_amdgcn_raw_buffer_store_b64(hold, u.rc, l.vc, csoff, 0);
+  } else if constexpr (EPI == EPI_NONE) {
     v += bias;
-    nt4_store<TO>(v, u.rc, l.vc, csoff);
+    if constexpr (SUB == 7) hold = nt4_pack4(v.x, v.y, v.z, v.w);
+    else nt4_store<TO>(v, u.rc, l.vc, csoff);
   } else if constexpr (EPI == EPI_RESID) {
     v += bias;
     v += ax.v[p];
@@ -210,7 +257,8 @@ __device__ __forceinline__ void nt4_unit(f32x4& v, u32x2& hold, const f32x4& bia
   } else if constexpr (EPI == EPI_MUL) {
     const u32x2 w = ax.v[p];
     v[0] *= h16lo_to_f32(w[0]); v[1] *= h16hi_to_f32(w[0]); v[2] *= h16lo_to_f32(w[1]); v[3] *= h16hi_to_f32(w[1]);
-    nt4_store<TO>(v, u.rc, l.vc, csoff);
+    if constexpr (SUB == 7) hold = nt4_pack4(v.x, v.y, v.z, v.w);
+    else nt4_store<TO>(v, u.rc, l.vc, csoff);
   } else {
     static_assert(EPI == EPI_GELU || EPI == EPI_DGELU || EPI == EPI_GELUD, "epilogue");
     static_assert(sizeof(TO) == 2, "the GELU kinds have 16-bit outputs");
@@ -240,7 +288,6 @@ __device__ __forceinline__ void nt4_unit(f32x4& v, u32x2& hold, const f32x4& bia
       }
       nt4_store<TO>(v, u.rc, l.vc, csoff);
     }
-    if constexpr (SUB == 5) __builtin_amdgcn_raw_buffer_store_b64(hold, u.rc, l.vc, csoff, 0);
     if constexpr (SUB == 6) __builtin_amdgcn_raw_buffer_store_b64(hold, u.ro, l.vo2, osoff, 0);          // GELUD: the held derivative
   }
 }
@@ -268,14 +315,15 @@ __device__ __forceinline__ void nt4_set_prev(Nt4Uni& u, int m0, int n0) {
 //      DMA  the 12 pieces of k-tile T + 3;  RD: fragment reads (off in the workgroup's very last k-step)
 //      SB   (GELU kinds) block whose results, held in packed form since the previous window, are stored in the first slots of this one
 //      PR   measurement builds (climb_set_option 18, 16-bit NONE kernel only; results are WRONG with bits 1 / 2): 1 = no DMA inside the windows,
-//           2 = no epilogue inside the windows, 4 = the 12 DMA pieces in slots 4 .. 15 (issued as early as the stage is free)
+//           2 = no epilogue inside the windows, 4 = the 12 DMA pieces in slots 4 .. 15 (issued as early as the stage is free),
+//           8 = no workgroup barrier at the end of a window, 16 = no fragment reads (r05: with 1 | 2 these leave the bare MFMA stream)
 template <int PR_, bool SW_, int EB_, int AB_, bool BL_, bool DMA_, bool RD_, int SB_ = -1> struct Nt4Cfg {
-  static constexpr bool SW = SW_, BL = BL_ && !(PR_ & 2), DMA = DMA_ && !(PR_ & 1), RD = RD_, STAG = (PR_ & 4) != 0;
+  static constexpr bool SW = SW_, BL = BL_ && !(PR_ & 2), DMA = DMA_ && !(PR_ & 1), RD = RD_ && !(PR_ & 16), STAG = (PR_ & 4) != 0, NOBAR = (PR_ & 8) != 0;
   static constexpr int EB = (PR_ & 2) ? -1 : EB_, AB = (PR_ & 2) ? -1 : AB_, SB = (PR_ & 2) ? -1 : SB_;
 };
 template <typename TO, int EPI, class CFG, int Q>
 __device__ __forceinline__ void nt4_slot(f32x16 (&accC)[3][3], f32x16 (&accP)[3][3], bf16x8 (&fa)[2][3], bf16x8 (&fb)[2][3], f32x4 (&rbk)[4], u32x2 (&hold)[8], Nt4Act& act,
-                                         f32x4 (&bias)[3], Nt4Aux<EPI> (&aux)[2], const Nt4Uni& u, const Nt4Lane& l, unsigned char* smem) {
+                                         f32x4 (&bias)[3], Nt4Aux<EPI> (&aux)[2], Nt4Uni& u, const Nt4Lane& l, unsigned char* smem) {
   constexpr int st = Q / 9, blk = Q % 9, bi = blk / 3, bj = blk % 3;
   constexpr int par = (st == 0) ? 1 : ((st - 1) & 1);
   if constexpr (CFG::SW && st == 0) accP[bi][bj] = CLIMB_MFMA_H16(fb[par][bj], fa[par][bi], accC[bi][bj], 0, 0, 0);
@@ -301,6 +349,9 @@ __device__ __forceinline__ void nt4_slot(f32x16 (&accC)[3][3], f32x16 (&accP)[3]
   if constexpr (Q < 3 && CFG::BL) nt4_bias_issue(bias, Q, u, l);
   if constexpr (CFG::DMA && !CFG::STAG && nt4_dma_piece(Q) >= 0) nt4_dma<(nt4_dma_piece(Q) < 0 ? 0 : nt4_dma_piece(Q))>(u, l, smem);
   if constexpr (CFG::DMA && CFG::STAG && Q >= 4 && Q < 16) nt4_dma<(Q >= 4 && Q < 16 ? Q - 4 : 0)>(u, l, smem);      // every piece early in the window
+#if !NT4_OLD_BOUNDARY
+  if constexpr (CFG::DMA && Q == 20) nt4_dma_next(u);          // the next window's stream position (scalar selects, under this slot's MFMA)
+#endif
   if constexpr (CFG::EB >= 0) {
     constexpr int ei = CFG::EB / 3, ej = CFG::EB % 3;
     // turn: 4 writes, then 4 row-major reads (LDS operations of one wave execute in order: no wait in between)
@@ -331,7 +382,7 @@ __device__ __forceinline__ void nt4_slot(f32x16 (&accC)[3][3], f32x16 (&accP)[3]
       constexpr int rp = Q == 6 ? 0 : Q == 8 ? 1 : Q == 10 ? 2 : Q == 12 ? 3 : -1;
       constexpr int p = Q == 9 ? 0 : Q == 11 ? 1 : Q == 13 ? 2 : Q == 15 ? 3 : -1;
       if constexpr (rp >= 0) rbk[rp] = *reinterpret_cast<const f32x4*>(smem + NT4_TURN + u.wid * 4096 + l.rd + rp * 1024);
-      if constexpr (p >= 0) nt4_unit<TO, EPI, -1>(rbk[p], hold[p], bias[ej], aux[CFG::EB & 1], p, ei, ej, u, l);
+      if constexpr (p >= 0) nt4_unit<TO, EPI, (nt4_holds<TO, EPI>() ? 7 : -1)>(rbk[p], hold[p], bias[ej], aux[CFG::EB & 1], p, ei, ej, u, l);
     }
   }
   if constexpr (CFG::SB >= 0 && Q < 4) nt4_unit<TO, EPI, 5>(rbk[Q], hold[Q], bias[0], aux[0], Q, CFG::SB / 3, CFG::SB % 3, u, l);
@@ -340,7 +391,7 @@ __device__ __forceinline__ void nt4_slot(f32x16 (&accC)[3][3], f32x16 (&accP)[3]
 }
 template <typename TO, int EPI, class CFG, int Q, int QE>
 __device__ __forceinline__ void nt4_slots(f32x16 (&accC)[3][3], f32x16 (&accP)[3][3], bf16x8 (&fa)[2][3], bf16x8 (&fb)[2][3], f32x4 (&rbk)[4], u32x2 (&hold)[8], Nt4Act& act,
-                                          f32x4 (&bias)[3], Nt4Aux<EPI> (&aux)[2], const Nt4Uni& u, const Nt4Lane& l, unsigned char* smem) {
+                                          f32x4 (&bias)[3], Nt4Aux<EPI> (&aux)[2], Nt4Uni& u, const Nt4Lane& l, unsigned char* smem) {
   if constexpr (Q < QE) {
     nt4_slot<TO, EPI, CFG, Q>(accC, accP, fa, fb, rbk, hold, act, bias, aux, u, l, smem);
     nt4_slots<TO, EPI, CFG, Q + 1, QE>(accC, accP, fa, fb, rbk, hold, act, bias, aux, u, l, smem);
@@ -353,27 +404,38 @@ __device__ __forceinline__ void nt4_set_rd(Nt4Uni& u, unsigned off) {
   u.rda = off + (u.wid >> 1) * (96u * 128u);
   u.rdb = off + NT4_OP + (u.wid & 1) * (96u * 128u);
 }
-template <int VM, int EPI>
+template <int VM, int EPI, bool NOBAR = false>
 __device__ __forceinline__ void nt4_window_end(Nt4Uni& u, Nt4Aux<EPI> (&aux)[2], f32x4 (&bias)[3]) {
   __builtin_amdgcn_sched_barrier(0);
+#if !NT4_OLD_BOUNDARY
+  // everything the next window's first slots need, BEFORE the waits and the barrier (nothing of this window uses these any more: the last DMA piece
+  // went out in slot 35, the last fragment read in slot 32); a wave that arrives early does this while it would wait anyway
+  nt4_dma_commit(u);
+  u.dma_off = u.rd_off;
+  nt4_set_rd(u, u.rd_off + NT4_STAGE == 3 * NT4_STAGE ? 0u : u.rd_off + NT4_STAGE);
+  asm volatile("" : "+s"(u.curA), "+s"(u.curB), "+s"(u.dma_off), "+s"(u.rda), "+s"(u.rdb));          // materialised here, not after the barrier
+  __builtin_amdgcn_sched_barrier(0);
+#endif
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  if (VM == 0 || u.probe == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM) : "memory");
-  else if (u.probe == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM + 4) : "memory");        // MEASUREMENT ONLY (climb_set_option 18): results may be wrong
-  else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM + 8) : "memory");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM) : "memory");
   nt4_pin<EPI>(aux[0]);
   nt4_pin<EPI>(aux[1]);
   asm volatile("" : "+v"(bias[0]), "+v"(bias[1]), "+v"(bias[2])::"memory");
-  __builtin_amdgcn_s_barrier();
+  if constexpr (!NOBAR) __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
+#if NT4_OLD_BOUNDARY
   u.dma_off = u.rd_off;
   nt4_set_rd(u, u.rd_off + NT4_STAGE == 3 * NT4_STAGE ? 0u : u.rd_off + NT4_STAGE);
+#endif
 }
 template <typename TO, int EPI, class CFG>
 __device__ __forceinline__ void nt4_window(f32x16 (&accC)[3][3], f32x16 (&accP)[3][3], bf16x8 (&fa)[2][3], bf16x8 (&fb)[2][3], f32x4 (&rbk)[4], u32x2 (&hold)[8], Nt4Act& act,
                                            f32x4 (&bias)[3], Nt4Aux<EPI> (&aux)[2], Nt4Uni& u, const Nt4Lane& l, unsigned char* smem) {
+#if NT4_OLD_BOUNDARY
   nt4_dma_advance(u);
+#endif
   nt4_slots<TO, EPI, CFG, 0, 36>(accC, accP, fa, fb, rbk, hold, act, bias, aux, u, l, smem);
-  nt4_window_end<12, EPI>(u, aux, bias);
+  nt4_window_end<12, EPI, CFG::NOBAR>(u, aux, bias);
 }
 
 template <typename TO, int EPI, int E0, int E1>
@@ -410,7 +472,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt4_kernel(const bf16_t* A, lon
   const int nbm = M / NT4_T, nbn = N / NT4_T, nwg = nbm * nbn, G = gridDim.x;
   const int ntw = (nwg - (int)blockIdx.x + G - 1) / G;          // tiles of this workgroup (>= 1)
   u.nk = K / GB_BK;
-  u.probe = probe;
+  u.probe = probe;          // (r04's run-time vmcnt experiments are gone; the compile-time measurement builds remain)
   u.stag = u.wid % 3u;
   // resources: raw buffers (stride 0), range = 2 GB (the launcher checks sizes); a missing bias reads as zeros through an empty range
   u.ra = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, 0x7fffffff, 0x00020000);
@@ -451,6 +513,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt4_kernel(const bf16_t* A, lon
   Nt4Walk cw;
   cw.gm = nbm / 8;
   cw.step = G / 8;
+  cw.dn = cw.step / cw.gm;
+  cw.dm = cw.step - cw.dn * cw.gm;
   cw.xcd = blockIdx.x & 7;
   cw.tn = (blockIdx.x >> 3) / cw.gm;
   cw.tml = (blockIdx.x >> 3) - cw.tn * cw.gm;
@@ -474,6 +538,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt4_kernel(const bf16_t* A, lon
     nt4_dma<0>(u, l, smem); nt4_dma<1>(u, l, smem); nt4_dma<2>(u, l, smem); nt4_dma<3>(u, l, smem); nt4_dma<4>(u, l, smem); nt4_dma<5>(u, l, smem);
     nt4_dma<6>(u, l, smem); nt4_dma<7>(u, l, smem); nt4_dma<8>(u, l, smem); nt4_dma<9>(u, l, smem); nt4_dma<10>(u, l, smem); nt4_dma<11>(u, l, smem);
   }
+#if !NT4_OLD_BOUNDARY
+  nt4_dma_next(u);                                            // the first full window's k-tile (committed by the half window's end below)
+#endif
   asm volatile("s_waitcnt vmcnt(24)" ::: "memory");          // k-tile 0 is all this half window reads
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
@@ -489,7 +556,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt4_kernel(const bf16_t* A, lon
   nt4_window_end<0, EPI>(u, aux, bias);           // k-tiles 1 and 2 have landed
   u.dma_off = 0;                                  // the stage k-tile 0 leaves at the end of the next window's k-step 3 ... which IS where piece 0 is issued (slot 4 of k-step 3: after this barrier every wave holds its k-step-3 fragments)
   const int nk = u.nk;
-  constexpr bool HOLD = EPI == EPI_GELU || EPI == EPI_DGELU || EPI == EPI_GELUD;      // results held one window (see nt4_unit)
+  constexpr bool HOLD = nt4_holds<TO, EPI>();      // results held one window (see nt4_unit)
   for (int t = 0;; ++t) {
     int w0 = 0;
     if (t > 0) {
@@ -532,7 +599,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt4_kernel(const bf16_t* A, lon
 #ifndef NT4_SLP_BUILD
 int g_nt4 = 1;             // climb_set_option 17: 0 = never; 1 (default) = every epilogue but GELU / GELUD -- inside a step (cold operands) the 8-wave kernel was the
                            // faster one there with the r04 polynomial: 83.1 vs 89.5 us, the step 10.37 vs 10.43 ms; 3 = those too; 4 = GELUD but not GELU;
-                           // 2 = everything on the build WITHOUT packed arithmetic (A/B)
+                           // 2 = everything on the second build (A/B: the r04 window boundary), 5 = like 1 on the second build
 int g_nt4_probe = 0;       // climb_set_option 18 (measurement)
 int g_nt4_grid = 256;      // follows climb_set_option 9 (CUs left to RCCL)
 void climb_nt4_set_probe(int v) { g_nt4_probe = v; }
@@ -559,9 +626,9 @@ static int nt4_launch_one(int nwg, hipStream_t st, const bf16_t* A, long lda, co
 
 int climb_nt4_launch(const bf16_t* A, long lda, const bf16_t* B, long ldb, void* C, long ldc, int c_dtype, int M, int N, int K, const float* bias, int epi,
                      const void* aux, long ldaux, bf16_t* aux_out, long ldauxo, hipStream_t st) {
-  if (g_nt4 == 0 || (g_nt4 == 1 && (epi == EPI_GELU || epi == EPI_GELUD)) || (g_nt4 == 4 && epi == EPI_GELU)) return CLIMB_EUNSUPPORTED;
+  if (g_nt4 == 0 || ((g_nt4 == 1 || g_nt4 == 5) && (epi == EPI_GELU || epi == EPI_GELUD)) || (g_nt4 == 4 && epi == EPI_GELU)) return CLIMB_EUNSUPPORTED;
 #ifndef NT4_SLP_BUILD
-  if (g_nt4 == 2) return climb_nt4slp_launch(A, lda, B, ldb, C, ldc, c_dtype, M, N, K, bias, epi, aux, ldaux, aux_out, ldauxo, st);
+  if (g_nt4 == 2 || g_nt4 == 5) return climb_nt4slp_launch(A, lda, B, ldb, C, ldc, c_dtype, M, N, K, bias, epi, aux, ldaux, aux_out, ldauxo, st);
 #endif
   if ((M % NT4_T) || (N % NT4_T) || ((M / NT4_T) % 8) || (K % GB_BK) || K < 10 * GB_BK) return CLIMB_EUNSUPPORTED;
   const long lim = 1L << 31;
@@ -574,22 +641,25 @@ int climb_nt4_launch(const bf16_t* A, long lda, const bf16_t* B, long ldb, void*
 #define L4(TO, E) return nt4_launch_one<TO, E>(nwg, st, A, lda, B, ldb, (TO*)C, ldc, M, N, K, bias, aux, ldaux, aux_out, ldauxo)
 #ifndef NT4_SLP_BUILD
 #define L4P(P) return nt4_launch_one<bf16_t, EPI_NONE, P>(nwg, st, A, lda, B, ldb, (bf16_t*)C, ldc, M, N, K, bias, aux, ldaux, aux_out, ldauxo)
-  if (c_dtype == CLIMB_DT_BF16 && epi == EPI_NONE && g_nt4_probe >= 101 && g_nt4_probe <= 104) {      // measurement builds (option 18 = 100 + bits)
+  if (c_dtype == CLIMB_DT_BF16 && epi == EPI_NONE && g_nt4_probe >= 101 && g_nt4_probe <= 131) {      // measurement builds (option 18 = 100 + bits)
     if (g_nt4_probe == 101) L4P(1);
     if (g_nt4_probe == 102) L4P(2);
     if (g_nt4_probe == 103) L4P(3);
     if (g_nt4_probe == 104) L4P(4);
+    if (g_nt4_probe == 111) L4P(11);
+    if (g_nt4_probe == 119) L4P(19);
+    if (g_nt4_probe == 127) L4P(27);
   }
 #undef L4P
 #endif
+  if (c_dtype == CLIMB_DT_F32 && epi == EPI_RESID) L4(float, EPI_RESID);
+  if (c_dtype == CLIMB_DT_F32 && epi == EPI_NONE) L4(float, EPI_NONE);
+  if (K < 11 * GB_BK) return CLIMB_EUNSUPPORTED;      // the 16-bit kinds hold their results one window: one more k-tile for those of the ninth block
   if (c_dtype == CLIMB_DT_BF16 && epi == EPI_NONE) L4(bf16_t, EPI_NONE);
   if (c_dtype == CLIMB_DT_BF16 && epi == EPI_MUL) L4(bf16_t, EPI_MUL);
-  if ((epi == EPI_GELU || epi == EPI_DGELU || epi == EPI_GELUD) && K < 11 * GB_BK) return CLIMB_EUNSUPPORTED;      // one more k-tile: the held results of the ninth block
   if (c_dtype == CLIMB_DT_BF16 && epi == EPI_GELU) L4(bf16_t, EPI_GELU);
   if (c_dtype == CLIMB_DT_BF16 && epi == EPI_DGELU) L4(bf16_t, EPI_DGELU);
   if (c_dtype == CLIMB_DT_BF16 && epi == EPI_GELUD) L4(bf16_t, EPI_GELUD);
-  if (c_dtype == CLIMB_DT_F32 && epi == EPI_RESID) L4(float, EPI_RESID);
-  if (c_dtype == CLIMB_DT_F32 && epi == EPI_NONE) L4(float, EPI_NONE);
 #undef L4
   return CLIMB_EUNSUPPORTED;
 }

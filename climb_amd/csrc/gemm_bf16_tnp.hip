@@ -18,6 +18,7 @@
 // The bias gradient db[n] = sum_m A[m][n] rides along on the VALU: the A fragments a lane holds ARE 8 tokens of one column n, so the
 // lanes of wave column 0 add them up during the reduction tiles dealt to their workgroup (round-robin over the k-tiles of an n-row
 // of tiles, so every workgroup carries the same small share).
+#include <vector>
 #include "gemm_bf16_phase.h"
 
 __device__ __forceinline__ int tnp_aswz(int row) { return (row & 3) << 2; }
@@ -576,18 +577,29 @@ __global__ __launch_bounds__(512) void gemm_bf16_tn_grouped_kernel(const TnGroup
 // stream-K tail leaves >= 2 tiles on both sides), N[p] % 8 == 0, K[p] % 8 == 0 (anything that is not a multiple of 256 needs the launch's
 // `ragged` flag).  Workgroup b of `nwg` (a multiple of 8: XCD = b % 8)
 // gets items first[b] .. first[b + 1] - 1.  Returns the number of items written, CLIMB_EINVAL for shapes outside the contract, or
-// CLIMB_EUNSUPPORTED when `cap` items do not suffice (at most tiles + nwg + 1 are ever needed).
+// CLIMB_EUNSUPPORTED when `cap` items do not suffice (at most tiles + 2 nwg + 1 are ever needed; with room for tiles + nwg + 1 only, the plan is
+// made without the staggered epilogues of option 22).
+// r05, staggered epilogues (climb_set_option 22 = G phase groups, 0 / 1 = off).  Every workgroup owns `rounds` whole tiles plus an equal share of the
+// stream-K tail, so all 256 of them reach the optimizer-carrying epilogue of a whole tile at the same moment: 256 x 1.8 MB of p / m / v / shadow
+// traffic arrive as one burst (~85 us at the HBM roof), five times per launch, with every matrix pipe idle -- the +0.39 ms the fused AdamW cost over
+// the plain launch (r04).  The tail share (~0.2 tile of reduction work per workgroup) is the only freedom the equal-work plan has: phase group
+// g = idx % G of an XCD runs the fraction g / (G - 1) of ITS share BEFORE its whole tiles and the rest after them, so the groups reach every epilogue
+// ~60 us / (G - 1) apart and each burst is 256 / G workgroups wide, under the other groups' k-loops.  Same items, same sums (the stream-K shares still
+// meet through atomics; a share cut in two at an even reduction tile adds one partial item).
+static int g_tn_stagger = 0;          // measured r05 (profiles/r05_dw_stagger_ab.txt): the step is 0.03 - 0.13 ms SLOWER with any grouping (inside an XCD the phase groups stop sharing panels in L2; by XCD nothing is gained): off
+void climb_tn_set_stagger(int v) { g_tn_stagger = v; }
 extern "C" int climb_tn_grouped_plan(int nprob, const int* M, const int* N, const int* K, int nwg, int* items_out, int cap, int* first_out) {
   if (nprob <= 0 || nwg <= 0 || (nwg % 8) || !M || !N || !K || !items_out || !first_out) return CLIMB_EINVAL;
   struct Tile { int prob, tn, tk, nkt; };
+  struct Piece { Tile x; int kt0, kt1; };
   long ntiles = 0;
   for (int p = 0; p < nprob; ++p) {
     if (M[p] < 128 || (M[p] % 128) || N[p] < 8 || (N[p] % 8) || K[p] < 8 || (K[p] % 8)) return CLIMB_EINVAL;
     ntiles += (long)((N[p] + 255) / 256) * ((K[p] + 255) / 256);
   }
   if (ntiles + nwg + 1 > cap) return CLIMB_EUNSUPPORTED;
-  Tile* tiles = new Tile[ntiles];
-  long t = 0;
+  std::vector<Tile> tiles;
+  tiles.reserve(ntiles);
   for (int p = 0; p < nprob; ++p) {
     const int nbn = (N[p] + 255) / 256, nbk = (K[p] + 255) / 256;
     for (int i = 0; i < nbn * nbk; ++i) {
@@ -597,58 +609,73 @@ extern "C" int climb_tn_grouped_plan(int nprob, const int* M, const int* N, cons
       x.tn = nbn > nbk ? i / nbk : i % nbn;
       x.tk = nbn > nbk ? i % nbk : i / nbn;
       x.nkt = M[p] / 64;
-      tiles[t++] = x;
+      tiles.push_back(x);
     }
   }
   const int per_xcd = nwg / 8;
   // per-workgroup item lists, indexed by RANK r = xcd * per_xcd + idx (consecutive ranks share an XCD); blockIdx b <-> rank (b % 8) * per_xcd + b / 8
-  int* count = new int[nwg]();
   const long rounds = ntiles / nwg, tail0 = rounds * nwg;
   long units = 0;
   for (long i = tail0; i < ntiles; ++i) units += tiles[i].nkt;
   long q = (units + nwg - 1) / nwg;
   q += q & 1;                                              // even share: cuts fall on even reduction-tile indices
-  // pass 1 counts, pass 2 writes (first[] needs the counts of all lower block indices)
-  int* rank_first = new int[nwg + 1];
-  for (int pass = 0; pass < 2; ++pass) {
-    if (pass == 1) {
-      int at = 0;
-      for (int b = 0; b < nwg; ++b) {
-        const int r = (b % 8) * per_xcd + b / 8;
-        first_out[b] = at;
-        rank_first[r] = at;
-        at += count[r];
-      }
-      first_out[nwg] = at;
-      for (int r = 0; r < nwg; ++r) count[r] = 0;
-    }
-    auto emit = [&](int r, const Tile& x, int kt0, int kt1) {
-      if (pass == 1) {
-        int* o = items_out + 8L * (rank_first[r] + count[r]);
-        o[0] = x.prob; o[1] = x.tn; o[2] = x.tk; o[3] = kt0; o[4] = kt1; o[5] = (kt0 != 0 || kt1 != x.nkt) ? 1 : 0; o[6] = o[7] = 0;
-      }
-      ++count[r];
-    };
-    for (long j = 0; j < rounds; ++j)
-      for (int r = 0; r < nwg; ++r) emit(r, tiles[j * nwg + r], 0, tiles[j * nwg + r].nkt);
+  // the stream-K shares of the tail, per rank
+  std::vector<std::vector<Piece>> share(nwg);
+  {
     int r = 0;
     long rem = q;
     for (long i = tail0; i < ntiles; ++i) {
       int pos = 0;
       while (pos < tiles[i].nkt) {
         const int take = (int)((tiles[i].nkt - pos) < rem ? (tiles[i].nkt - pos) : rem);
-        emit(r, tiles[i], pos, pos + take);
+        share[r].push_back(Piece{tiles[i], pos, pos + take});
         pos += take;
         rem -= take;
         if (rem == 0) { ++r; rem = q; }
       }
     }
   }
-  const int total = first_out[nwg];
-  delete[] tiles;
-  delete[] count;
-  delete[] rank_first;
-  return total;
+  // (a caller that sized its table for the unstaggered plan, tiles + nwg + 1 items, gets that plan: a cut share needs up to nwg more)
+  const bool by_xcd = g_tn_stagger >= 100;          // 100 + G: whole XCDs form the phase groups (their 32 workgroups stay in lock step and keep sharing panels in L2)
+  const int gs = by_xcd ? g_tn_stagger - 100 : g_tn_stagger;
+  const int G = (gs >= 2 && rounds >= 1 && ntiles + 2L * nwg + 1 <= cap) ? gs : 1;
+  std::vector<std::vector<Piece>> list(nwg);
+  for (int r = 0; r < nwg; ++r) {
+    std::vector<Piece> before, after;
+    long len = 0;
+    for (const Piece& pc : share[r]) len += pc.kt1 - pc.kt0;
+    const int g = by_xcd ? (r / per_xcd) % G : (r % per_xcd) % G;
+    long want = G > 1 ? (len * g / (G - 1)) & ~1L : 0;     // reduction tiles of the share that run before the whole tiles (even)
+    for (const Piece& pc : share[r]) {
+      const int n = pc.kt1 - pc.kt0;
+      if (want >= n) { before.push_back(pc); want -= n; }
+      else if (want >= 2 && n - want >= 2) {               // cut inside this piece: both parts keep >= 2 reduction tiles, even cut point
+        before.push_back(Piece{pc.x, pc.kt0, pc.kt0 + (int)want});
+        after.push_back(Piece{pc.x, pc.kt0 + (int)want, pc.kt1});
+        want = 0;
+      } else { after.push_back(pc); want = 0; }
+    }
+    for (const Piece& pc : before) list[r].push_back(pc);
+    for (long j = 0; j < rounds; ++j) list[r].push_back(Piece{tiles[j * nwg + r], 0, tiles[j * nwg + r].nkt});
+    for (const Piece& pc : after) list[r].push_back(pc);
+  }
+  int at = 0;
+  std::vector<int> rank_first(nwg + 1);
+  for (int b = 0; b < nwg; ++b) {
+    const int r = (b % 8) * per_xcd + b / 8;
+    first_out[b] = at;
+    rank_first[r] = at;
+    at += (int)list[r].size();
+  }
+  first_out[nwg] = at;
+  if (at > cap) return CLIMB_EUNSUPPORTED;
+  for (int r = 0; r < nwg; ++r)
+    for (size_t k = 0; k < list[r].size(); ++k) {
+      const Piece& pc = list[r][k];
+      int* o = items_out + 8L * (rank_first[r] + (long)k);
+      o[0] = pc.x.prob; o[1] = pc.x.tn; o[2] = pc.x.tk; o[3] = pc.kt0; o[4] = pc.kt1; o[5] = (pc.kt0 != 0 || pc.kt1 != pc.x.nkt) ? 1 : 0; o[6] = o[7] = 0;
+    }
+  return at;
 }
 
 // probs: TnGroupProblem[...] in device memory, items / first: the planner's tables copied to device memory (ints).  nwg workgroups

@@ -792,7 +792,7 @@ class ViltEngine:
                 r["A"], r["B"], r["C"], r["dbias"] = dY.data_ptr(), X.data_ptr(), self.g(w), (self.g(b) if b is not None else 0)
                 r["lda"], r["ldb"], r["ldc"], r["M"], r["N"], r["K"] = N, K, K, M, N, K
             Ms, Ns, Ks = (np.ascontiguousarray(rec[f], dtype=np.int32) for f in ("M", "N", "K"))
-            cap = int(sum(((n + 255) // 256) * ((k + 255) // 256) for n, k in zip(Ns, Ks))) + nwg + 1
+            cap = int(sum(((n + 255) // 256) * ((k + 255) // 256) for n, k in zip(Ns, Ks))) + 2 * nwg + 1
             items = np.zeros((cap, 8), dtype=np.int32)
             first = np.zeros(nwg + 1, dtype=np.int32)
             n_items = _lib.load().climb_tn_grouped_plan(len(pending), Ms.ctypes.data, Ns.ctypes.data, Ks.ctypes.data, nwg, items.ctypes.data, cap, first.ctypes.data)

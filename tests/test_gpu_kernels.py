@@ -251,7 +251,7 @@ def test_gemm_bf16_tn_grouped_launch(nwg, ragged):
             r["A"], r["B"], r["C"], r["dbias"] = dY.data_ptr(), X.data_ptr(), C.data_ptr(), (db.data_ptr() if db is not None else 0)
             r["lda"], r["ldb"], r["ldc"], r["M"], r["N"], r["K"] = N, K, K, M, N, K
         Ms, Ns, Ks = (np.ascontiguousarray(rec[f], dtype=np.int32) for f in ("M", "N", "K"))
-        cap = int(sum(((n + 255) // 256) * ((k + 255) // 256) for n, k in zip(Ns, Ks))) + nwg + 1
+        cap = int(sum(((n + 255) // 256) * ((k + 255) // 256) for n, k in zip(Ns, Ks))) + 2 * nwg + 1
         items, first = np.zeros((cap, 8), dtype=np.int32), np.zeros(nwg + 1, dtype=np.int32)
         n = _lib.load().climb_tn_grouped_plan(len(shapes), Ms.ctypes.data, Ns.ctypes.data, Ks.ctypes.data, nwg, items.ctypes.data, cap, first.ctypes.data)
         assert n > 0
@@ -296,7 +296,7 @@ def test_gemm_bf16_tn_grouped_with_adamw_in_the_epilogue_equals_launch_then_flat
     dYs = [torch.randn(M, n, device=dev, generator=g).to(torch.bfloat16) for n, k in shapes]
     Xs = [torch.randn(M, k, device=dev, generator=g).to(torch.bfloat16) for n, k in shapes]
     Ms, Ns, Ks = (np.array(v, dtype=np.int32) for v in ([M] * len(shapes), [n for n, _ in shapes], [k for _, k in shapes]))
-    cap = int(sum((n // 256) * (k // 256) for n, k in shapes)) + nwg + 1
+    cap = int(sum((n // 256) * (k // 256) for n, k in shapes)) + 2 * nwg + 1
     items, first = np.zeros((cap, 8), dtype=np.int32), np.zeros(nwg + 1, dtype=np.int32)
     n_items = _lib.load().climb_tn_grouped_plan(len(shapes), Ms.ctypes.data, Ns.ctypes.data, Ks.ctypes.data, nwg, items.ctypes.data, cap, first.ctypes.data)
     assert n_items > 0

@@ -59,7 +59,7 @@ def make_model(tasks, wseed=42, precision="fp32"):
     from climb_amd.configs.task_configs import task_configs
     from climb_amd.configs.model_configs import model_configs
     dev = _dev()
-    model = create_continual_learner_map["vilt"](model_name_or_path="random-init:0", ordered_cl_tasks=list(tasks),
+    model = create_continual_learner_map["vilt"](model_name_or_path="random-init:empty", ordered_cl_tasks=list(tasks),      # every parameter is loaded below (strict)
                                                  model_config=model_configs["vilt"], task_configs=task_configs, device=dev, precision=precision)
     P = _seeded_params(tasks, wseed)
     missing, unexpected = model.load_state_dict({k: v for k, v in P.items()}, strict=True)

@@ -298,3 +298,59 @@ def test_nt4_tile_walk_is_a_bijection():
     for nbm, nbn, G in [(64, 4, 256), (64, 12, 256), (64, 16, 256), (64, 16, 224), (96, 16, 256), (8, 1, 256), (16, 3, 256), (48, 4, 256), (64, 12, 64)]:
         seen = walk(nbm, nbn, G)
         assert len(seen) == nbm * nbn and set(seen) == {(m, n) for m in range(nbm) for n in range(nbn)}, (nbm, nbn, G)
+
+
+@pytest.mark.parametrize("stagger", [0, 2, 4, 8])
+def test_grouped_weight_gradient_plan_covers_every_tile_once_with_staggered_epilogues(stagger):
+    """climb_tn_grouped_plan is host code (no device needed): for the benchmark's 49 weight-gradient problems on 256 workgroups -- and a small case where
+    everything is stream-K tail -- every output tile's reduction range [0, tokens / 64) is covered exactly once by its items, cut points are even with
+    >= 2 reduction tiles per item, every workgroup gets the same number of whole tiles and the same share of the tail (to one cut), and with
+    climb_set_option(22, G) phase group g = idx % G of an XCD runs g / (G - 1) of its tail share BEFORE its whole tiles (r05: the optimizer-carrying
+    epilogues of the 256 workgroups no longer arrive as one burst)."""
+    import numpy as np
+    from climb_amd import _lib
+    lib = _lib.load()
+    assert lib.climb_set_option(22, stagger) == 0
+    try:
+        layer = [(12288, 768, 3072), (12288, 3072, 768), (12288, 768, 768), (12288, 2304, 768)]
+        for probs, nwg in [(layer * 12 + [(9216, 768, 3072)], 256), (layer, 256), (layer * 3, 64)]:
+            Ms, Ns, Ks = (np.ascontiguousarray([p[i] for p in probs], dtype=np.int32) for i in range(3))
+            ntiles = int(sum(((n + 255) // 256) * ((k + 255) // 256) for _, n, k in probs))
+            cap = ntiles + 2 * nwg + 1
+            items, first = np.zeros((cap, 8), dtype=np.int32), np.zeros(nwg + 1, dtype=np.int32)
+            n = lib.climb_tn_grouped_plan(len(probs), Ms.ctypes.data, Ns.ctypes.data, Ks.ctypes.data, nwg, items.ctypes.data, cap, first.ctypes.data)
+            assert n > 0 and first[nwg] == n and first[0] == 0 and (np.diff(first) >= 0).all()
+            items = items[:n]
+            cover = {}
+            for prob, tn, tk, k0, k1, partial, _, _ in items:
+                nkt = probs[prob][0] // 64
+                assert 0 <= k0 < k1 <= nkt and k1 - k0 >= 2 and k0 % 2 == 0 and k1 % 2 == 0
+                assert partial == int(k0 != 0 or k1 != nkt)
+                assert tn < (probs[prob][1] + 255) // 256 and tk < (probs[prob][2] + 255) // 256
+                cover.setdefault((prob, tn, tk), []).append((k0, k1))
+            assert len(cover) == ntiles
+            for (prob, tn, tk), rs in cover.items():
+                rs.sort()
+                assert rs[0][0] == 0 and rs[-1][1] == probs[prob][0] // 64 and all(a[1] == b[0] for a, b in zip(rs[:-1], rs[1:])), (prob, tn, tk, rs)
+            rounds = ntiles // nwg
+            per_xcd = nwg // 8
+            G = stagger if stagger >= 2 and rounds >= 1 else 1
+            tails = []
+            for b in range(nwg):
+                mine = items[first[b]:first[b + 1]]
+                whole = [i for i, it in enumerate(mine) if it[5] == 0]
+                assert len(whole) >= rounds
+                units = int(sum(it[4] - it[3] for it in mine if it[5] == 1))
+                tails.append(units)
+                if G > 1 and rounds >= 1 and units:
+                    rank = (b % 8) * per_xcd + b // 8
+                    g = (rank % per_xcd) % G
+                    before = int(sum(it[4] - it[3] for it in mine[:whole[0]] if it[5] == 1)) if whole else units
+                    # (a share whose pieces cannot be cut at the wanted place keeps them whole: within one piece of the target)
+                    assert abs(before - units * g / (G - 1)) <= max(2, max(it[4] - it[3] for it in mine if it[5] == 1)), (b, g, before, units)
+            if G > 1 and rounds >= 1 and max(tails) >= 8:
+                befores = [int(sum(it[4] - it[3] for it in items[first[b]:first[b + 1]][:next((i for i, it in enumerate(items[first[b]:first[b + 1]]) if it[5] == 0), 0)]))
+                           for b in range(nwg)]
+                assert len(set(befores)) >= 2, "no stagger: every workgroup runs the same amount of tail work before its whole tiles"
+    finally:
+        lib.climb_set_option(22, 0)

@@ -87,7 +87,7 @@ if __name__ == "__main__":
             r["A"], r["B"], r["C"], r["lda"], r["ldb"], r["ldc"], r["M"], r["N"], r["K"] = dY.data_ptr(), X.data_ptr(), C.data_ptr(), dY.shape[1], X.shape[1], X.shape[1], M, dY.shape[1], X.shape[1]
         nwg = int(os.environ.get("NWG", 256))
         Ms, Ns, Ks = (np.ascontiguousarray(rec[f], dtype=np.int32) for f in ("M", "N", "K"))
-        cap = int(sum((n // 256) * (k // 256) for n, k in zip(Ns, Ks))) + nwg + 1
+        cap = int(sum((n // 256) * (k // 256) for n, k in zip(Ns, Ks))) + 2 * nwg + 1
         items, first = np.zeros((cap, 8), dtype=np.int32), np.zeros(nwg + 1, dtype=np.int32)
         n = _lib.load().climb_tn_grouped_plan(len(flat), Ms.ctypes.data, Ns.ctypes.data, Ks.ctypes.data, nwg, items.ctypes.data, cap, first.ctypes.data)
         d = [torch.from_numpy(rec.view(np.uint8).copy()).to(dev), torch.from_numpy(items[:n].copy()).to(dev), torch.from_numpy(first).to(dev)]

@@ -171,6 +171,9 @@ if __name__ == "__main__":
         for cold in (False, True):
             bench(rotate=6, passes=3, settings=((17, 0, 18, 0), (17, 3, 18, 0), (17, 3, 18, 101), (17, 3, 18, 102), (17, 3, 18, 103), (17, 3, 18, 104)), cold=cold,
                   only=("qkv fwd", "dhn", "dctx"))
+    if "--anatomy2" in sys.argv:
+        print("== r05: the bare window (103 = no DMA, no epilogue) minus its barrier (111), minus its fragment reads (119), minus both (127: MFMAs only)")
+        bench(rotate=6, passes=3, settings=((17, 3, 18, 0), (17, 3, 18, 103), (17, 3, 18, 111), (17, 3, 18, 119), (17, 3, 18, 127)), only=("qkv fwd", "dhn"))
     if "--zeros" in sys.argv:
         print("== zero operands (the matrix pipes toggle nothing: what the clock does when the power budget is not the limit)")
         bench(rotate=6, passes=3, settings=((17, 0), (17, 3)), zeros=True)
