@@ -147,5 +147,15 @@ class EWC:
         eng.touched.append((0, eng.layout.encoder_end))
         return ewc_task_key, loss
 
+    def park_penalty(self, model):
+        """r05: the fused step's form when the caller named its optimizer (`fused_forward_backward(..., optimizer=opt)`): nothing is launched here --
+        FusedAdamW.step() adds the term inside its own passes and fills the returned tensor with the penalty's value (engine.park_ewc).  Same task
+        draw as `add_penalty_gradient` (one call of Python's `random`, REF ewc.py:77)."""
+        ewc_task_key = random.choice(self.task_keys)
+        eng = model._host.engine()
+        loss = eng.park_ewc(self.param_flat[ewc_task_key], self.fisher_flat[ewc_task_key], self.ewc_loss_weight)
+        eng.touched.append((0, eng.layout.encoder_end))
+        return ewc_task_key, loss
+
     def do_ewc(self):
         return True if len(self.task_keys) > 0 else False

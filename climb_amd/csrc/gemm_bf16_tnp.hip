@@ -374,7 +374,11 @@ struct TnGroupOpt {          // 56 bytes, parallel to the problems; include/clim
   long ldt;
   int fused, pad;
 };
-struct TnAdam { AdamGroup g; float gscale; int grad_dirty; };
+// r05: the EWC term in the same epilogue (REF/cl_algorithms/ewc.py:75-87: loss += lam sum F (theta - theta*)^2, so d/dtheta = 2 lam F (theta - theta*)).
+// theta* and F are laid out like the encoder range of the flat parameter buffer: element e of p <-> star[e - flat], fisher[e - flat].  The term is
+// added to the tile sum in fp32 before the update, and lam F (theta - theta*)^2 of the elements this launch updates is added to *loss (atomics).
+struct TnEwc { const float* flat; const float* star; const float* fisher; float* loss; float lam; int pad; };
+struct TnAdam { AdamGroup g; float gscale; int grad_dirty; TnEwc ewc; };
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
 // 4 x 4 transpose inside every quad of lanes: register i of lane b <-> register b of lane i (two exchange steps through DPP quad permutes)
 __device__ __forceinline__ float tn_dpp_quad(float x, bool hi) {
@@ -392,7 +396,7 @@ __device__ __forceinline__ void tn_quad_transpose(float (&r)[4], int lane) {
 
 // RAGGED: N, K any multiples of 8 (the adapters' 768 x 48 / 48 x 768 gradients ride in the same launch as 256 x 256 tiles whose surplus
 // columns are computed on clamped addresses and never stored -- the FLOPs of those GEMMs are nothing, their launches and operand reads were).
-template <bool RAGGED, bool FUSED = false>
+template <bool RAGGED, bool FUSED = false, bool EWC = false>
 __global__ __launch_bounds__(512) void gemm_bf16_tn_grouped_kernel(const TnGroupProblem* __restrict__ probs, const TnGroupItem* __restrict__ items,
                                                                    const int* __restrict__ first, const TnGroupOpt* __restrict__ opts = nullptr, TnAdam ad = TnAdam()) {
   constexpr int NI = 4, BK_ = 256;
@@ -508,18 +512,54 @@ __global__ __launch_bounds__(512) void gemm_bf16_tn_grouped_kernel(const TnGroup
       const unsigned st0 = (unsigned)((k0 + wc * (32 * NI)) * (int)O.ldt + n0 + wr * 64) * 2u;
       const float isb2 = rsqrtf(ad.g.bc2), step = ad.g.lr / ad.g.bc1;
       const bool dirty = ad.grad_dirty != 0;
+      __amdgpu_buffer_rsrc_t rstar = rp, rfis = rp;
+      if constexpr (EWC) {
+        const long delta = O.p - ad.ewc.flat;          // this matrix inside the encoder range
+        rstar = __builtin_amdgcn_make_buffer_rsrc((void*)(ad.ewc.star + delta), 0, 0x7fffffff, 0x00020000);
+        rfis = __builtin_amdgcn_make_buffer_rsrc((void*)(ad.ewc.fisher + delta), 0, 0x7fffffff, 0x00020000);
+      }
+      const float two_lam = 2.f * ad.ewc.lam;
+      float ewc_sum = 0.f;
 #pragma unroll
       for (int p = 0; p < NI; ++p)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {          // one 32 x 32 block: every load before the first store (a load behind a store drains the store queue)
           f32x4 pv[4], mv[4], vv[4], gv[4];
+          if constexpr (EWC) {
+            // first p, theta*, F -> the term (and its share of the penalty's value); only then m, v: the working set stays that of the plain epilogue
+            // (all six operands at once spilled 1 KB per lane next to the 128 accumulators).  Every load still precedes the block's first store.
+            f32x4 sv[4], fv[4];
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const unsigned so = (se0 + (unsigned)((j * 32 + 8 * q) * (int)ldc + p * 32)) * 4u;
-            pv[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rp, le * 4u, so, 0));
-            mv[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rm, le * 4u, so, 0));
-            vv[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rv, le * 4u, so, 0));
-            gv[q] = dirty ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rg, le * 4u, so, 0)) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int q = 0; q < 4; ++q) {
+              const unsigned so = (se0 + (unsigned)((j * 32 + 8 * q) * (int)ldc + p * 32)) * 4u;
+              pv[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rp, le * 4u, so, 0));
+              sv[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rstar, le * 4u, so, 0));
+              fv[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rfis, le * 4u, so, 0));
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                const float d = pv[q][i] - sv[q][i], fd = fv[q][i] * d;
+                ewc_sum = fmaf(fd, d, ewc_sum);
+                gv[q][i] = two_lam * fd;          // the term, in the transposed-register layout the update runs in
+              }
+            __builtin_amdgcn_sched_barrier(0);          // (the scheduler otherwise hoists the loads below above the term: all six operands live at once)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const unsigned so = (se0 + (unsigned)((j * 32 + 8 * q) * (int)ldc + p * 32)) * 4u;
+              mv[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rm, le * 4u, so, 0));
+              vv[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rv, le * 4u, so, 0));
+            }
+          } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const unsigned so = (se0 + (unsigned)((j * 32 + 8 * q) * (int)ldc + p * 32)) * 4u;
+              pv[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rp, le * 4u, so, 0));
+              mv[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rm, le * 4u, so, 0));
+              vv[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rv, le * 4u, so, 0));
+              gv[q] = dirty ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rg, le * 4u, so, 0)) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
           }
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
@@ -546,6 +586,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_tn_grouped_kernel(const TnGroup
             __builtin_amdgcn_raw_buffer_store_b64(wt, rt, lt, st0 + (unsigned)((p * 32) * (int)O.ldt + j * 32 + 8 * q) * 2u, 0);
           }
         }
+      if constexpr (EWC) {
+        ewc_sum = wave_sum(ewc_sum);
+        if (lane == 0) atomicAdd(ad.ewc.loss, ad.ewc.lam * ewc_sum);
+      }
     } else {
       // whole tile: the only writer of these elements in this launch.  All 16 loads of a (p, j) block are issued before its first store
       // (a load behind a store drains the store queue on gfx9: one vmcnt for both kinds)
@@ -704,8 +748,22 @@ extern "C" int climb_gemm_bf16_tn_grouped(const void* probs, const void* items, 
 // The same launch with the optimizer in the epilogue of the problems whose TnGroupOpt says `fused` (see above).  opts: device array parallel to
 // probs; adam: HOST array of 8 floats { lr, weight decay, beta1, beta2, eps, 1 - beta1^t, 1 - beta2^t, gradient scale }; grad_dirty != 0: the
 // gradient buffer (the problems' C) is not zero and is added to the tile sums before the update (it is never written for fused problems).
+static int tn_grouped_adamw_launch(const void* probs, const void* items, const void* first, int nwg, int ragged, const void* opts, const float* adam, int grad_dirty,
+                                   const TnEwc* ewc, void* stream);
 extern "C" int climb_gemm_bf16_tn_grouped_adamw(const void* probs, const void* items, const void* first, int nwg, int ragged, const void* opts, const float* adam,
                                                 int grad_dirty, void* stream) {
+  return tn_grouped_adamw_launch(probs, items, first, nwg, ragged, opts, adam, grad_dirty, nullptr, stream);
+}
+// r05: ... and the EWC term (see TnEwc): `flat` = the fp32 parameter buffer the fused problems' p pointers point into, `star` / `fisher` = theta* / F laid
+// out like its encoder range (every fused problem must lie inside it), *loss += lam * sum F (theta - theta*)^2 over the updated elements.
+extern "C" int climb_gemm_bf16_tn_grouped_adamw_ewc(const void* probs, const void* items, const void* first, int nwg, int ragged, const void* opts, const float* adam,
+                                                    int grad_dirty, const float* flat, const float* star, const float* fisher, float lam, float* loss, void* stream) {
+  if (!flat || !star || !fisher || !loss) return CLIMB_EINVAL;
+  const TnEwc e{flat, star, fisher, loss, lam, 0};
+  return tn_grouped_adamw_launch(probs, items, first, nwg, ragged, opts, adam, grad_dirty, &e, stream);
+}
+static int tn_grouped_adamw_launch(const void* probs, const void* items, const void* first, int nwg, int ragged, const void* opts, const float* adam, int grad_dirty,
+                                   const TnEwc* ewc, void* stream) {
   if (!probs || !items || !first || nwg <= 0 || !opts || !adam) return CLIMB_EINVAL;
   constexpr int LDS = 2 * (NTP_A_BYTES + 4 * NTP_B_UNIT);
   static bool configured = false;
@@ -714,12 +772,22 @@ extern "C" int climb_gemm_bf16_tn_grouped_adamw(const void* probs, const void* i
     if (e != hipSuccess) return (int)e;
     e = hipFuncSetAttribute((const void*)gemm_bf16_tn_grouped_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute((const void*)gemm_bf16_tn_grouped_kernel<false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) return (int)e;
     configured = true;
   }
   TnAdam ad;
   ad.g = AdamGroup{adam[0], adam[1], adam[2], adam[3], adam[4], adam[5], adam[6], 0.f};
   ad.gscale = adam[7];
   ad.grad_dirty = grad_dirty;
+  ad.ewc = ewc ? *ewc : TnEwc{nullptr, nullptr, nullptr, nullptr, 0.f, 0};
+  if (ewc) {
+    if (ragged || grad_dirty) return CLIMB_EUNSUPPORTED;          // (the engine never defers a ragged plan, and folds the term only into a step whose gradient buffer is clean)
+    hipLaunchKernelGGL((gemm_bf16_tn_grouped_kernel<false, true, true>), dim3(nwg), dim3(512), LDS, (hipStream_t)stream, (const TnGroupProblem*)probs,
+                       (const TnGroupItem*)items, (const int*)first, (const TnGroupOpt*)opts, ad);
+    LAUNCH_CHECK();
+    return CLIMB_OK;
+  }
   if (ragged)
     hipLaunchKernelGGL((gemm_bf16_tn_grouped_kernel<true, true>), dim3(nwg), dim3(512), LDS, (hipStream_t)stream, (const TnGroupProblem*)probs,
                        (const TnGroupItem*)items, (const int*)first, (const TnGroupOpt*)opts, ad);

@@ -65,11 +65,16 @@ extern "C" int climb_adamw(float* p, const float* g, float* m, float* v, void* s
 // Data parallel (r04): a span flagged in spans[4 i + 3] takes its gradient from `g16` -- the reducer's 16-bit staging buffer, laid out like the
 // gradient buffer, holding the all-reduced payload -- times g16_scale (the averaging factor / loss scale the un-cast pass used to apply): that pass
 // (2 B read + 4 B written per parameter) and the 4 B read of its result disappear.  Same product, same rounding as un-cast followed by this kernel.
-template <bool SHADOW, bool ZERO>
+// r05: with EWC the term 2 lam F (theta - theta*) of REF/cl_algorithms/ewc.py:75-87 is added to the gradient of every element below `enc_n` (theta* / F
+// are laid out like that range) right here, and lam F (theta - theta*)^2 of those elements to *ewc_loss: the separate penalty pass (16 B per encoder
+// parameter) and the re-read of what it parked in the gradient buffer (4 B) become 8 B read in this pass.
+struct SpansEwc { const float* star; const float* fisher; float* loss; long enc_n; float lam; int pad; };
+template <bool SHADOW, bool ZERO, bool EWC = false>
 __global__ __launch_bounds__(256) void adamw_spans_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                                           bf16_t* __restrict__ shadow, const long* __restrict__ spans, int nspans, long nblocks,
                                                           const long* __restrict__ seg_start, const signed char* __restrict__ seg_group, int nseg,
-                                                          AdamGroups groups, float gscale, const bf16_t* __restrict__ g16, float g16_scale) {
+                                                          AdamGroups groups, float gscale, const bf16_t* __restrict__ g16, float g16_scale, SpansEwc ew = SpansEwc()) {
+  float ewc_sum = 0.f;
   for (long b = blockIdx.x; b < nblocks; b += gridDim.x) {
     int lo = 0, hi = nspans - 1;                     // last span whose first block is <= b
     while (lo < hi) {
@@ -91,18 +96,53 @@ __global__ __launch_bounds__(256) void adamw_spans_kernel(float* __restrict__ p,
     float pa[4] = {pp.x, pp.y, pp.z, pp.w}, ga[4] = {gg.x, gg.y, gg.z, gg.w}, ma[4] = {mm.x, mm.y, mm.z, mm.w}, va[4] = {vv.x, vv.y, vv.z, vv.w};
     const float isb2 = rsqrtf(G.bc2), step = G.lr / G.bc1;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) adamw_update(pa[j], ma[j], va[j], ga[j] * gscale, G, isb2, step);
+    for (int j = 0; j < 4; ++j) ga[j] *= gscale;
+    if constexpr (EWC) {
+      if (e < ew.enc_n) {          // (tensors are 64-element aligned: a float4 never straddles the end of the encoder range)
+        const float4 s4 = ld4(ew.star + e), f4 = ld4(ew.fisher + e);
+        const float sa[4] = {s4.x, s4.y, s4.z, s4.w}, fa[4] = {f4.x, f4.y, f4.z, f4.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float d = pa[j] - sa[j], fd = fa[j] * d;
+          ewc_sum = fmaf(fd, d, ewc_sum);
+          ga[j] += 2.f * ew.lam * fd;
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) adamw_update(pa[j], ma[j], va[j], ga[j], G, isb2, step);
     st4(p + e, make_float4(pa[0], pa[1], pa[2], pa[3]));
     st4(m + e, make_float4(ma[0], ma[1], ma[2], ma[3]));
     st4(v + e, make_float4(va[0], va[1], va[2], va[3]));
     if (SHADOW) st4(shadow + e, make_float4(pa[0], pa[1], pa[2], pa[3]));
     if (ZERO) st4(g + e, make_float4(0.f, 0.f, 0.f, 0.f));
   }
+  if constexpr (EWC) {
+    ewc_sum = wave_sum(ewc_sum);
+    if ((threadIdx.x & 63) == 0 && ewc_sum != 0.f) atomicAdd(ew.loss, ew.lam * ewc_sum);
+  }
 }
 
+static int adamw_spans_launch(float* p, float* g, float* m, float* v, void* shadow_bf16, const long* spans, int nspans, long nblocks, const long* seg_start,
+                              const signed char* seg_group, int nseg, const float* groups, int ngroups, float gscale, int zero_grad, const void* g16,
+                              float g16_scale, const SpansEwc* ew, void* stream);
 extern "C" int climb_adamw_spans(float* p, float* g, float* m, float* v, void* shadow_bf16, const long* spans, int nspans, long nblocks,
                                  const long* seg_start, const signed char* seg_group, int nseg, const float* groups, int ngroups, float gscale,
                                  int zero_grad, const void* g16, float g16_scale, void* stream) {
+  return adamw_spans_launch(p, g, m, v, shadow_bf16, spans, nspans, nblocks, seg_start, seg_group, nseg, groups, ngroups, gscale, zero_grad, g16, g16_scale, nullptr, stream);
+}
+// r05: the same pass with the EWC term for the elements below enc_n (see SpansEwc); *ewc_loss is ADDED to (the caller zeroes it once per step)
+extern "C" int climb_adamw_spans_ewc(float* p, float* g, float* m, float* v, void* shadow_bf16, const long* spans, int nspans, long nblocks,
+                                     const long* seg_start, const signed char* seg_group, int nseg, const float* groups, int ngroups, float gscale,
+                                     int zero_grad, const void* g16, float g16_scale, const float* star, const float* fisher, long enc_n, float lam,
+                                     float* ewc_loss, void* stream) {
+  if (!star || !fisher || !ewc_loss || enc_n <= 0 || (enc_n % 4)) return CLIMB_EINVAL;
+  const SpansEwc e{star, fisher, ewc_loss, enc_n, lam, 0};
+  return adamw_spans_launch(p, g, m, v, shadow_bf16, spans, nspans, nblocks, seg_start, seg_group, nseg, groups, ngroups, gscale, zero_grad, g16, g16_scale, &e, stream);
+}
+static int adamw_spans_launch(float* p, float* g, float* m, float* v, void* shadow_bf16, const long* spans, int nspans, long nblocks, const long* seg_start,
+                              const signed char* seg_group, int nseg, const float* groups, int ngroups, float gscale, int zero_grad, const void* g16,
+                              float g16_scale, const SpansEwc* ew, void* stream) {
   if (nspans <= 0 || nblocks <= 0 || nseg <= 0 || ngroups <= 0 || ngroups > 8 || !spans) return CLIMB_EINVAL;
   AdamGroups G;
   for (int i = 0; i < 8; ++i) {
@@ -110,6 +150,17 @@ extern "C" int climb_adamw_spans(float* p, float* g, float* m, float* v, void* s
     G.g[i] = AdamGroup{s[0], s[1], s[2], s[3], s[4], s[5], s[6], 0.f};
   }
   dim3 grid((unsigned)(nblocks < 16384 ? nblocks : 16384)), blk(256);
+  if (ew) {
+    if (!shadow_bf16) return CLIMB_EUNSUPPORTED;          // (the fold is the 16-bit training step's)
+    if (zero_grad)
+      hipLaunchKernelGGL((adamw_spans_kernel<true, true, true>), grid, blk, 0, (hipStream_t)stream, p, g, m, v, (bf16_t*)shadow_bf16, spans, nspans, nblocks, seg_start,
+                         seg_group, nseg, G, gscale, (const bf16_t*)g16, g16_scale, *ew);
+    else
+      hipLaunchKernelGGL((adamw_spans_kernel<true, false, true>), grid, blk, 0, (hipStream_t)stream, p, g, m, v, (bf16_t*)shadow_bf16, spans, nspans, nblocks, seg_start,
+                         seg_group, nseg, G, gscale, (const bf16_t*)g16, g16_scale, *ew);
+    LAUNCH_CHECK();
+    return CLIMB_OK;
+  }
 #define ADAMW_SPANS(S_, Z_)                                                                                                                          \
   hipLaunchKernelGGL((adamw_spans_kernel<S_, Z_>), grid, blk, 0, (hipStream_t)stream, p, g, m, v, (bf16_t*)shadow_bf16, spans, nspans, nblocks, seg_start, \
                      seg_group, nseg, G, gscale, (const bf16_t*)g16, g16_scale)

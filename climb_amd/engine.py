@@ -209,6 +209,7 @@ class ViltEngine:
         self._dw_deferred = []          # [(ws, plan)]
         self._grad_extra = False        # the weight matrices' gradient ranges hold something besides zeros (EWC penalty term, an earlier backward)
         self._grad_clean = False        # set by FusedAdamW.step() when it leaves the gradient buffer all zeros; any backward clears it (before_backward)
+        self._ewc_fold = None           # r05: {star, fisher, lam, loss}: an EWC term the next FusedAdamW.step() applies inside its passes (park_ewc)
         self._fused_consumed = False    # the last FusedAdamW.step() updated matrices inside the weight-gradient launch (their gradients were never stored)
         self._g16 = None                # data parallel: {stage, scale, ranges}: averaged gradients that still live in the reducer's 16-bit payload buffer
         self._unscale_pending = self._prescaled = False
@@ -281,6 +282,9 @@ class ViltEngine:
         self.touched = []
         self._grad_dirty = False
         self._dw_deferred = []          # gradients nobody asked for are never computed
+        if self._ewc_fold is not None:  # (its value was promised to the caller; the gradients are being dropped)
+            f, self._ewc_fold = self._ewc_fold, None
+            f["loss"].copy_(self.ewc_penalty(f["star"], f["fisher"], f["lam"], add_grad=False))
         self._grad_extra = False
         self._fused_consumed = False
 
@@ -292,8 +296,24 @@ class ViltEngine:
             for lo, hi in pend["ranges"]:
                 _lib.call("climb_uncast_bf16_scale", pend["stage"][lo:hi], self.grad[lo:hi], hi - lo, pend["scale"], _stream())
 
+    def park_ewc(self, star: torch.Tensor, fisher: torch.Tensor, lam: float) -> torch.Tensor:
+        """r05: the EWC term of a fused training step whose caller named its optimizer is not written by a pass of its own
+        (`ewc_penalty`: 16 B per encoder parameter, then 4 B more when the optimizer re-reads what was parked in the gradient buffer): FusedAdamW.step()
+        adds 2 lam F (theta - theta*) to the gradient inside its two passes -- the weight-gradient epilogue and the flat pass, 8 B per parameter -- and
+        accumulates the penalty's value.  Returns the tensor that RECEIVES the value when step() runs (REF/.../train_vqa.py:160-170 reads it after the
+        step); anything else that looks at the gradients first (`materialize_dw`) writes the term the old way."""
+        loss = torch.zeros((), dtype=torch.float32, device=self.device)
+        self._ewc_fold = dict(star=star, fisher=fisher, lam=float(lam), loss=loss)
+        return loss
+
+    def apply_parked_ewc(self):
+        f, self._ewc_fold = self._ewc_fold, None
+        if f is not None:
+            f["loss"].copy_(self.ewc_penalty(f["star"], f["fisher"], f["lam"], add_grad=True))
+
     def materialize_dw(self):
         """Run weight-gradient launches that were held back for the optimizer as the plain launches they replace (C += dW)."""
+        self.apply_parked_ewc()
         held, self._dw_deferred = self._dw_deferred, []
         for ws, plan in held:
             self._timed_call("gemm_bf16_tn", plan["flops"], "climb_gemm_bf16_tn_grouped", plan["probs"], plan["items"], plan["first"], plan["nwg"], plan["ragged"], _stream())
@@ -824,7 +844,7 @@ class ViltEngine:
             segs = self._segs = self.layout.segments()
         return [n for n, start, length in segs if lo <= start < lo + numel]
 
-    def fused_dw_adamw(self, opt_m: torch.Tensor, opt_v: torch.Tensor, eligible, adam_row) -> set:
+    def fused_dw_adamw(self, opt_m: torch.Tensor, opt_v: torch.Tensor, eligible, adam_row, ewc=None) -> set:
         """The held-back weight-gradient launches with AdamW in their epilogue (csrc/gemm_bf16_tnp.hip).  `eligible(name) -> bool`: tensors the
         optimizer updates THIS step with the constants `adam_row` (8 floats: lr, wd, beta1, beta2, eps, 1 - beta1^t, 1 - beta2^t, gradient scale).
         Returns the names that were updated here (the flat pass must skip them; their transposed shadows are fresh too)."""
@@ -848,8 +868,12 @@ class ViltEngine:
                 if len(plan["opts"]) >= 8:
                     plan["opts"].pop(next(iter(plan["opts"])))
                 plan["opts"][key] = opts
-            self._timed_call("gemm_bf16_tn", plan["flops"], "climb_gemm_bf16_tn_grouped_adamw", plan["probs"], plan["items"], plan["first"], plan["nwg"], plan["ragged"],
-                             opts, row.ctypes.data, 1 if self._grad_extra else 0, _stream())
+            if ewc is not None:          # (never with a non-zero gradient buffer or a ragged plan: FusedAdamW.step() / _dw_flush)
+                self._timed_call("gemm_bf16_tn", plan["flops"], "climb_gemm_bf16_tn_grouped_adamw_ewc", plan["probs"], plan["items"], plan["first"], plan["nwg"],
+                                 plan["ragged"], opts, row.ctypes.data, 0, self.flat, ewc["star"], ewc["fisher"], ewc["lam"], ewc["loss"], _stream())
+            else:
+                self._timed_call("gemm_bf16_tn", plan["flops"], "climb_gemm_bf16_tn_grouped_adamw", plan["probs"], plan["items"], plan["first"], plan["nwg"], plan["ragged"],
+                                 opts, row.ctypes.data, 1 if self._grad_extra else 0, _stream())
             for cv, f in zip(cover, flags):
                 if f:
                     done.update(cv)

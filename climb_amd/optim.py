@@ -87,6 +87,16 @@ class FusedAdamW(torch.optim.Optimizer):
             table[slot] = (g["lr"], g["weight_decay"], b1, b2, g["eps"], 1.0 - b1 ** t, 1.0 - b2 ** t, 0.0)
         fused = set()
         shadow = eng.shadow_ptr()
+        # r05: an EWC term parked by the fused training step (engine.park_ewc) is applied inside this step's two passes -- provided they reach EVERY
+        # encoder element (the term's value and gradient cover the whole encoder range, REF/cl_algorithms/ewc.py:75-87); else it is written the old way
+        fold = eng._ewc_fold
+        if fold is not None:
+            segs_enc = [si for si, st in enumerate(self._seg_start_host[:-1]) if st < eng.layout.encoder_end]
+            if shadow is None or eng._grad_extra or not all(seg_group[si] >= 0 for si in segs_enc):
+                eng.apply_parked_ewc()
+                fold = None
+            else:
+                eng._ewc_fold = None
         if eng._dw_deferred:
             # r04: weight-gradient launches held back for this step (the fused training step armed engine.defer_dw): run them with the update in
             # their epilogue for the tensors of the most common (group, step) combination; the flat pass below skips what was updated there
@@ -97,7 +107,7 @@ class FusedAdamW(torch.optim.Optimizer):
                 slot0 = max(set(sl for sl in slots if sl >= 0), key=slots.count)
                 row = table[slot0].copy()
                 row[7] = 1.0          # gradient scale
-                fused = eng.fused_dw_adamw(self._m, self._v, lambda n: int(seg_group[idx[n]]) == slot0, row)
+                fused = eng.fused_dw_adamw(self._m, self._v, lambda n: int(seg_group[idx[n]]) == slot0, row, ewc=fold)
                 for n in fused:
                     seg_group[idx[n]] = -1
             else:
@@ -144,9 +154,14 @@ class FusedAdamW(torch.optim.Optimizer):
                     clean = False
                     break
         if self._nspans:
-            _lib.call("climb_adamw_spans", eng.flat, eng.grad, self._m, self._v, shadow, self._spans, self._nspans, self._nblocks, self._seg_start,
-                      self._seg_group, len(self._seg_names), table.ctypes.data, len(combos), 1.0, 1 if clean else 0,
-                      g16["stage"] if g16 else None, g16["scale"] if g16 else 1.0, torch.cuda.current_stream().cuda_stream)
+            args = (eng.flat, eng.grad, self._m, self._v, shadow, self._spans, self._nspans, self._nblocks, self._seg_start,
+                    self._seg_group, len(self._seg_names), table.ctypes.data, len(combos), 1.0, 1 if clean else 0,
+                    g16["stage"] if g16 else None, g16["scale"] if g16 else 1.0)
+            if fold is not None:
+                _lib.call("climb_adamw_spans_ewc", *args, fold["star"], fold["fisher"], eng.layout.encoder_end, fold["lam"], fold["loss"],
+                          torch.cuda.current_stream().cuda_stream)
+            else:
+                _lib.call("climb_adamw_spans", *args, torch.cuda.current_stream().cuda_stream)
         eng._g16 = None                # consumed
         eng._grad_clean = clean
         eng.params_updated(shadow_fresh=shadow is not None, t_fresh=fused)

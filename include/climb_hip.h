@@ -140,6 +140,9 @@ int climb_adamw(float* p, const float* g, float* m, float* v, void* shadow_bf16,
  * optimizer.zero_grad() of REF/train/visionlanguage_tasks/train_vqa.py:168-172 folded into the pass).  A span with source != 0 reads its gradient
  * from g16 (the data-parallel reducer's 16-bit payload buffer, laid out like g) times g16_scale instead of from g. */
 int climb_adamw_spans(float* p, float* g, float* m, float* v, void* shadow_bf16, const long* spans, int nspans, long nblocks, const long* seg_start, const signed char* seg_group, int nseg, const float* groups, int ngroups, float gscale, int zero_grad, const void* g16, float g16_scale, void* stream);
+/* r05: the same pass with the EWC term (REF/cl_algorithms/ewc.py:75-87) folded in: elements below enc_n (the encoder range; star / fisher = theta* / F laid
+ * out like it) get 2 lam F (theta - theta*) added to their gradient, and lam F (theta - theta*)^2 is ADDED to *ewc_loss (zero it once per step). */
+int climb_adamw_spans_ewc(float* p, float* g, float* m, float* v, void* shadow_bf16, const long* spans, int nspans, long nblocks, const long* seg_start, const signed char* seg_group, int nseg, const float* groups, int ngroups, float gscale, int zero_grad, const void* g16, float g16_scale, const float* star, const float* fisher, long enc_n, float lam, float* ewc_loss, void* stream);
 /* REF/cl_algorithms/ewc.py:75-87: loss_out = lam*sum F (theta-theta*)^2; grad += gscale*2*lam*F*(theta-theta*) if grad != NULL */
 int climb_ewc_penalty(const float* theta, const float* star, const float* fisher, float* grad, long n, float lam, float gscale, float* partials, float* loss_out, void* stream);
 int climb_ewc_workspace_floats(void);
@@ -205,6 +208,9 @@ int climb_gemm_bf16_tn_grouped(const void* probs, const void* items, const void*
  * else behaves as climb_gemm_bf16_tn_grouped.  A problem may be fused only if none of its tiles is `partial` in the plan.  adam: HOST array of 8 floats
  * { lr, weight_decay, beta1, beta2, eps, 1 - beta1^t, 1 - beta2^t, gscale } (climb_adamw's group row + the gradient scale). */
 int climb_gemm_bf16_tn_grouped_adamw(const void* probs, const void* items, const void* first, int nwg, int ragged, const void* opts, const float* adam, int grad_dirty, void* stream);
+/* r05: ... and the EWC term in that epilogue: `flat` = the fp32 parameter buffer the fused problems' p pointers point into, star / fisher laid out like its
+ * encoder range; *loss += lam sum F (theta - theta*)^2 over the elements updated here.  Not for ragged plans or a non-zero gradient buffer (CLIMB_EUNSUPPORTED). */
+int climb_gemm_bf16_tn_grouped_adamw_ewc(const void* probs, const void* items, const void* first, int nwg, int ragged, const void* opts, const float* adam, int grad_dirty, const float* flat, const float* star, const float* fisher, float lam, float* loss, void* stream);
 /* HF:322-351 in bf16: same contract as the _f32 entry points, qkv/ctx/dctx/dqkv are bf16.  The backward takes the forward's ctx and
  * computes delta itself (its first phase); `delta` [B,heads,S_pad] is scratch it writes */
 int climb_attn_fwd_bf16(const void* qkv, const float* key_bias, void* ctx, float* lse, int B, int S_pad, int heads, int head_dim, void* stream);

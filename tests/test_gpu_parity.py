@@ -980,7 +980,8 @@ def test_optimizer_in_the_weight_gradient_epilogue_is_the_same_training_step(con
             loss, _, _, _ = model.fused_forward_backward("vqa", pixels, texts, target, ewc, optimizer=opt if fused else None)
             opt.step()
             # the flat pass clears what it consumes when that leaves the whole buffer zero (no EWC term parked in it): zero_grad() then skips its fill
-            expect_clean = fused and config != "ewc" and not (config == "accumulate" and step == 1)
+            # (r05: the EWC term no longer parks anything in the buffer either -- FusedAdamW.step() adds it inside its passes)
+            expect_clean = fused and not (config == "accumulate" and step == 1)
             assert eng._grad_clean == expect_clean, (config, fused, step)
             if expect_clean:
                 assert not bool(eng.grad.any()), "the step claimed a zero gradient buffer"
@@ -1004,6 +1005,79 @@ def test_optimizer_in_the_weight_gradient_epilogue_is_the_same_training_step(con
         torch.cuda.empty_cache()
     for a, b in zip(res[False], res[True]):
         assert abs(a - b) <= 5e-3 * abs(a), (res[False], res[True])
+
+
+def test_ewc_term_folded_into_the_optimizer_passes_is_the_same_update():
+    """r05: with the optimizer named, the EWC term (REF/cl_algorithms/ewc.py:75-87) is not written by a pass of its own: the
+    weight-gradient epilogue and the flat AdamW pass add 2 lam F (theta - theta*) to the gradient they consume and accumulate lam sum F (theta - theta*)^2.
+    Checked on one step from zero moments, where AdamW's first moment IS the gradient (m = (1 - beta1) g): (a) the penalty's value equals the float64
+    sum over the PRE-step parameters; (b) m of the folded step minus m of the same step without EWC equals the analytic term, tensor by tensor --
+    matrices (updated in the weight-gradient epilogue), vectors and embeddings (flat pass) alike; (c) the unfolded path (CLIMB_AMD_EWC_FOLD=0) gives the
+    same value and moments; (d) the step leaves the gradient buffer clean (nothing was parked in it)."""
+    if H16 != "bf16":
+        pytest.skip("the fused update is the bf16 build's")
+    from climb_amd.cl_algorithms import EWC
+    dev = _dev()
+    lam = 100.0
+    runs = {}
+    for mode in ("none", "fold", "unfold"):
+        model, P = make_model(["vqa", "nlvr2"], 42, precision=H16)
+        model.train()
+        ewc = None
+        if mode != "none":
+            ewc = EWC(types.SimpleNamespace(ewc_fisher_sample_percentage=0.01, ewc_loss_weight=lam))
+            fisher, star = _ewc_state(P, 5)
+            ewc.set_task_state("nlvr2", model, fisher, star)
+        opt = model.create_optimizer({"lr": 2e-5, "weight_decay": 1e-2, "adam_epsilon": 1e-8})
+        opt.zero_grad()
+        eng = model._host.engine()
+        pixels, texts, target = _rand_batch(8, 900, dev)
+        os.environ["CLIMB_AMD_EWC_FOLD"] = "0" if mode == "unfold" else "1"
+        try:
+            random.seed(0)
+            _, _, _, ewc_loss = model.fused_forward_backward("vqa", pixels, texts, target, ewc, optimizer=opt)
+            if mode == "fold":
+                assert eng._ewc_fold is not None, "the term was not parked for the optimizer"
+            opt.step()
+        finally:
+            os.environ.pop("CLIMB_AMD_EWC_FOLD", None)
+        assert eng._ewc_fold is None
+        if mode == "fold":
+            assert eng._grad_clean and not bool(eng.grad.any()), "the folded step left something in the gradient buffer"
+        torch.cuda.synchronize()
+        n_enc = eng.layout.encoder_end
+        runs[mode] = dict(m=opt._m[:n_enc].detach().double().cpu(), loss=None if ewc_loss is None else float(ewc_loss))
+        if mode == "fold":
+            F = ewc.fisher_flat["nlvr2"].double().cpu()
+            S = ewc.param_flat["nlvr2"].double().cpu()
+            runs["F"], runs["S"] = F, S
+            runs["segs"] = [(n, eng.layout.offset[n], eng.layout.numel(n)) for n in eng.layout.shapes if eng.layout.offset[n] < n_enc]
+            # the parameters BEFORE the step, in the engine's flat order (64-element aligned tensors: gaps are zero in theta, theta* and F alike)
+            flat0 = torch.zeros(n_enc, dtype=torch.float64)
+            for n, o, k in runs["segs"]:
+                flat0[o:o + k] = P[n].reshape(-1).double()          # (layout names are the state dict's)
+            runs["theta0"] = flat0
+        del model, opt
+        torch.cuda.empty_cache()
+    F, S, th = runs["F"], runs["S"], runs["theta0"]
+    value = lam * float((F * (th - S) ** 2).sum())
+    assert abs(runs["fold"]["loss"] - value) <= 2e-5 * value, (runs["fold"]["loss"], value)
+    assert abs(runs["unfold"]["loss"] - value) <= 2e-5 * value, (runs["unfold"]["loss"], value)
+    term = 2.0 * lam * F * (th - S)
+    got = (runs["fold"]["m"] - runs["none"]["m"]) / (1.0 - 0.9)
+    worst = 0.0
+    for n, o, k in runs["segs"]:
+        t, g = term[o:o + k], got[o:o + k]
+        scale = float(t.abs().max())
+        if scale == 0:
+            continue
+        # the two runs' task gradients differ by the 16-bit step's run-to-run noise (atomics); the term itself is exact fp32 arithmetic
+        tol = 2e-2 * float(runs["none"]["m"][o:o + k].abs().max()) / 0.1 + 1e-5 * scale
+        err = float((g - t).abs().max())
+        assert err <= tol + 1e-12, (n, err, tol, scale)
+        worst = max(worst, err / scale)
+    assert float((runs["fold"]["m"] - runs["unfold"]["m"]).abs().max()) <= 2e-2 * float(runs["unfold"]["m"].abs().max())
+    print(f"EWC fold: value {runs['fold']['loss']:.6f} (float64 {value:.6f}); worst term error {worst:.2e} of its tensor's largest element")
 
 
 def test_held_back_weight_gradients_of_a_step_that_never_came_use_their_own_activations():
