@@ -311,9 +311,10 @@ class ViltEngine:
         if f is not None:
             f["loss"].copy_(self.ewc_penalty(f["star"], f["fisher"], f["lam"], add_grad=True))
 
-    def materialize_dw(self):
+    def materialize_dw(self, keep_parked_ewc: bool = False):
         """Run weight-gradient launches that were held back for the optimizer as the plain launches they replace (C += dW)."""
-        self.apply_parked_ewc()
+        if not keep_parked_ewc:
+            self.apply_parked_ewc()
         held, self._dw_deferred = self._dw_deferred, []
         for ws, plan in held:
             self._timed_call("gemm_bf16_tn", plan["flops"], "climb_gemm_bf16_tn_grouped", plan["probs"], plan["items"], plan["first"], plan["nwg"], plan["ragged"], _stream())

@@ -656,7 +656,7 @@ class ViltContinualLearner(ContinualLearner):
         if ewc is not None and ewc.do_ewc():
             # (r05) with the optimizer named and a plain single-GPU bf16 step, the term rides in the optimizer's passes (EWC.park_penalty)
             fold = (eng.defer_dw and eng.loss_scale == 1.0 and not eng._grad_extra and eng.active_adapter is None and hasattr(ewc, "park_penalty")
-                    and os.environ.get("CLIMB_AMD_EWC_FOLD", "1") != "0")
+                    and os.environ.get("CLIMB_AMD_EWC_FOLD", "2") != "0")
             ewc_task, ewc_loss = ewc.park_penalty(self) if fold else ewc.add_penalty_gradient(self)
         host.after_backward()
         # `pooled`, `logits` and `loss` live in buffers the next step overwrites: hand the caller its own copies (a few hundred KB)

@@ -6,6 +6,8 @@ reference's `optimizer.step(); scheduler.step(); optimizer.zero_grad()` sequence
 with `transformers.get_polynomial_decay_schedule_with_warmup` (a LambdaLR over `param_groups`)."""
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 
@@ -90,6 +92,7 @@ class FusedAdamW(torch.optim.Optimizer):
         # r05: an EWC term parked by the fused training step (engine.park_ewc) is applied inside this step's two passes -- provided they reach EVERY
         # encoder element (the term's value and gradient cover the whole encoder range, REF/cl_algorithms/ewc.py:75-87); else it is written the old way
         fold = eng._ewc_fold
+        fold_flat = False
         if fold is not None:
             segs_enc = [si for si, st in enumerate(self._seg_start_host[:-1]) if st < eng.layout.encoder_end]
             if shadow is None or eng._grad_extra or not all(seg_group[si] >= 0 for si in segs_enc):
@@ -97,6 +100,12 @@ class FusedAdamW(torch.optim.Optimizer):
                 fold = None
             else:
                 eng._ewc_fold = None
+                fold_flat = os.environ.get("CLIMB_AMD_EWC_FOLD", "2") == "2"
+                if fold_flat:
+                    # the term rides in the FLAT pass for every encoder element: the weight gradients are written by the plain launch and the optimizer
+                    # is not carried in its epilogue this step (measured, tools/ewc_ab.py: the epilogue is exposed time -- two more operands there cost
+                    # more than the separate pass they replace)
+                    eng.materialize_dw(keep_parked_ewc=True)
         if eng._dw_deferred:
             # r04: weight-gradient launches held back for this step (the fused training step armed engine.defer_dw): run them with the update in
             # their epilogue for the tensors of the most common (group, step) combination; the flat pass below skips what was updated there
@@ -144,6 +153,8 @@ class FusedAdamW(torch.optim.Optimizer):
         # matrices updated in the weight-gradient epilogue were never written), nothing else is parked in the buffer (EWC term, accumulated sums)
         # and no reducer or loss scale is in play.  The optimizer.zero_grad() that follows (REF/.../train_vqa.py:170) then has nothing to fill.
         clean = bool(fused) and not eng._grad_extra and self._host.ddp is None and eng.loss_scale == 1.0 and not eng._dw_deferred
+        if fold is not None and fold_flat and self._host.ddp is None and eng.loss_scale == 1.0:
+            clean = True          # (the plain launch's sums are this step's gradients: the flat pass consumes -- and clears -- every range, checked below)
         if clean:
             consumed = seg_group >= 0
             consumed[[idx[n] for n in fused]] = True
