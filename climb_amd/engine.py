@@ -764,7 +764,15 @@ class ViltEngine:
         groups of 4 layers (or CLIMB_AMD_DW_GROUP) from the top down, whichever path computed them."""
         if self.grad_ready_hook is None:
             return 1
-        return int(_DW_GROUP) if (_DW_GROUP is not None and int(_DW_GROUP) > 0) else 4
+        if _DW_GROUP is not None and int(_DW_GROUP) > 0:
+            return int(_DW_GROUP)
+        # r05: a reducer that DEFERS its collectives to after the backward (GradientAllReducer.overlap False: the setting bench.py's warm-up trial, or
+        # CLIMB_AMD_DP_OVERLAP=0, chose for every rank alike) gains nothing from gradients that become final in chunks: one group = one grouped
+        # weight-gradient launch (three launches cost 0.3 ms more than one: three stream-K tails) and one collective
+        owner = getattr(self.grad_ready_hook, "__self__", None)
+        if owner is not None and getattr(owner, "overlap", True) is False:
+            return self.cfg["layers"]
+        return 4
 
     def set_cu_reserve(self, n: int):
         """Leave `n` CUs to somebody else (RCCL's collectives under the backward: parallel.GradientAllReducer.reserve_cus): the persistent GEMMs --
