@@ -354,3 +354,14 @@ def test_grouped_weight_gradient_plan_covers_every_tile_once_with_staggered_epil
                 assert len(set(befores)) >= 2, "no stagger: every workgroup runs the same amount of tail work before its whole tiles"
     finally:
         lib.climb_set_option(22, 0)
+
+
+def test_committed_traffic_figures_belong_to_this_tree():
+    """bench.py reports `roofline.traffic` / `roofline.hbm_bytes_per_step` from the latest profiles/rNN_traffic.json only when the file was measured on
+    THIS tree's kernel sources (it names their hashes); a kernel edit after the last PMC pass silently nulled the figure in the round-4 driver line.
+    This test is the guard: after editing anything under climb_amd/csrc, re-run tools/profile_step.sh + tools/summarize_profile.py and commit."""
+    import bench
+    tj = bench.latest_traffic()
+    assert tj["csrc_sha16"] == bench.csrc_hash(), "the NT GEMM sources changed since the committed PMC passes: roofline.traffic would be null"
+    assert tj.get("step_sha16") == bench.step_hash(), "a kernel source changed since the committed PMC passes: roofline.hbm_bytes_per_step would be null"
+    assert tj["gemm_bf16_nt"]["hbm_bytes_per_launch"] > 0 and tj["hbm_bytes_per_step"] > 0
