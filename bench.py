@@ -311,6 +311,11 @@ def main():
                 out["real_input"] = real_input_line(dev, args)
             if args.precision == "bf16":
                 out["fp32_parity_mode"] = fp32_parity_line(dev, args)
+                out["reference_stack_on_this_gpu"] = torch_stack_line(dev, args)
+                if isinstance(out["reference_stack_on_this_gpu"].get("fp32"), dict):
+                    rs = out["reference_stack_on_this_gpu"]
+                    rs["headline_over_fp32"] = round(value / rs["fp32"]["value"], 2)
+                    rs["headline_over_bf16_autocast"] = round(value / rs["bf16_autocast"]["value"], 2)
             out["cpu_baseline"] = cpu_baseline(args.cpu_steps)
         # the JSON line must be the LAST line on stdout: RCCL prints its version banner through C stdio, which is block-buffered on a pipe and would
         # otherwise come out at process exit, after this line (seen with the forced single-rank RCCL run).  Flush it now, print, then hand fd 1 to stderr.
@@ -389,6 +394,61 @@ def fp32_parity_line(dev, args):
                 "vs_ref": bf16_vs_reference(dev, "fp32"),
                 "note": "the parity mode (exact-fp32 MFMA, fp32 activations): the arithmetic that meets 1e-3 / argmax-exact against the reference; not the BASELINE dtype"}
     except Exception as e:      # the headline must not depend on the extra line
+        return {"error": repr(e)[:300]}
+
+
+def torch_stack_line(dev, args):
+    """Reported next to the headline, never as `value`: the step CLiMB itself would run on this GPU -- transformers' `ViltModel` (the module
+    REF/modeling/vilt.py:17 imports and delegates the encoder to), the reference's VQA head (REF/modeling/vilt.py:179-203), BCE-with-logits x 3129
+    (REF/train/visionlanguage_tasks/train_vqa.py:95,157) and torch.optim.AdamW, in plain PyTorch-ROCm on the same MI355X, same batch shape, random-init
+    weights: fp32 as the reference runs it (it has no autocast / half anywhere), and under bf16 autocast as the strongest setting that stack offers.
+    Third-party library code only (no file of /root/reference, no oracle); a failure here never touches the headline."""
+    import torch
+    try:
+        from transformers import ViltConfig, ViltModel
+        B, T = args.batch, 40
+        torch.manual_seed(0)
+        enc = ViltModel(ViltConfig()).to(dev)          # ViLT-B/32 defaults: 12 x 768, 384 x 384 / 32, 40 text positions
+        head = torch.nn.Sequential(torch.nn.Linear(768, 1536), torch.nn.LayerNorm(1536), torch.nn.GELU(), torch.nn.Linear(1536, 3129)).to(dev)
+        enc.train()
+        head.train()
+        params = list(enc.parameters()) + list(head.parameters())
+        g = torch.Generator().manual_seed(1)
+        ids = torch.randint(0, 30522, (B, T), generator=g).to(dev)
+        pixels = torch.randn(B, 3, 384, 384, generator=g).to(dev)
+        mask = torch.ones(B, 384, 384, dtype=torch.long, device=dev)
+        target = torch.zeros(B, 3129)
+        target[torch.arange(B), torch.randint(0, 3129, (B,), generator=g)] = 1.0
+        target = target.to(dev)
+        out = {}
+        for mode in ("fp32", "bf16_autocast"):
+            opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=1e-2, betas=(0.9, 0.98))
+
+            def step():
+                with torch.autocast("cuda", dtype=torch.bfloat16, enabled=(mode != "fp32")):
+                    pooled = enc(input_ids=ids, token_type_ids=torch.zeros_like(ids), attention_mask=torch.ones_like(ids), pixel_values=pixels, pixel_mask=mask).pooler_output
+                    logits = head(pooled)
+                loss = torch.nn.functional.binary_cross_entropy_with_logits(logits.float(), target) * target.shape[1]
+                loss.backward()
+                opt.step()
+                opt.zero_grad()
+            steps, warm = (6, 2) if mode == "fp32" else (10, 3)
+            for _ in range(warm):
+                step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / steps
+            out[mode] = {"value": round(B / dt, 1), "ms_per_step": round(dt * 1e3, 2)}
+        del enc, head, params
+        torch.cuda.empty_cache()
+        out["unit"] = "samples/s"
+        out["note"] = ("transformers ViltModel + CLiMB's VQA head + BCE + torch.optim.AdamW in plain PyTorch-ROCm on this GPU (what the reference's own code path "
+                       "would execute here): fp32 as the reference runs it, and under bf16 autocast; batch %d, 384x384 + 40 tokens, random-init" % B)
+        return out
+    except Exception as e:
         return {"error": repr(e)[:300]}
 
 
