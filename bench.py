@@ -58,11 +58,18 @@ def main():
         return spawn_check(world, rank)
     if rank != 0:
         os.dup2(2, 1)       # only rank 0 owns stdout: whatever another rank's libraries print (RCCL's banner sits in a C stdio buffer until exit) goes to stderr
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one process per GPU.  (CLIMB_AMD_DP_BACKEND=gloo is the test hook of tests/test_gpu_rccl.py: N ranks on whatever GPUs exist -- on the one-GPU test box
+    # all of them on cuda:0 -- with collectives through the host, so that everything this file does only under world > 1 runs before a multi-GPU lease does)
+    backend = os.environ.get("CLIMB_AMD_DP_BACKEND", "nccl")
+    local_dev = local_rank if backend == "nccl" else local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     if args.real_input_only:
         print(json.dumps({"real_input": real_input_line(dev, args)}), flush=True)

@@ -146,6 +146,24 @@ def test_cu_reserve_is_taken_under_the_backward_and_given_back(backend):
         assert after == (0, grid0), f"rank {rank}: reserve / grid not restored after finish(): {after} vs grid {grid0}"
 
 
+# ------------------------------------------------------------------------------------------------ bench.py --gpus 2 on ONE GPU (gloo): the N > 1 code of the bench itself
+def test_bench_two_ranks_on_one_gpu_through_gloo():
+    """Everything bench.py does only under world > 1 -- the launcher it becomes, rank-0-only stdout, the reducer, the warm-up trial that settles overlap /
+    CU reserve / deferred collectives with an all-reduced decision, the timed region's barriers and max-over-ranks time, the A/B leg, the data-parallel
+    fields of the JSON line -- with two ranks sharing the test box's GPU and collectives through the host (CLIMB_AMD_DP_BACKEND=gloo).  Not a
+    performance number (two replicas time-share one GPU); a small batch keeps it short."""
+    env = dict(os.environ, CLIMB_AMD_DP_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--batch", "8", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line on stdout (rank 0's)"
+    j = json.loads(lines[-1])
+    assert j["n_gpus"] == 2 and j["replicas_in_sync"] is True and j["config"]["global_batch"] == 16 and j["scaling"] == "weak"
+    assert j["allreduce_MB_per_step"] > 100 and j["value"] > 0 and j["dp_payload"] in ("bf16", "fp16")
+    assert set(j["dp_overlap_warmup_trial"]) >= {"overlap_ms", "deferred_ms", "chosen"} and "dp_overlap_ab" in j
+
+
 # ------------------------------------------------------------------------------------------------ bench.py --gpus 2 (RCCL only: its ranks bind one GPU each)
 def test_bench_two_gpus_smoke():
     """The driver's scaling command at N = 2, shortened: runs only where two GPUs exist (skipped on the 1-GPU test box)."""
