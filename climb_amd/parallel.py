@@ -17,8 +17,8 @@ Why it is shaped like this on MI355X
     (identical on every rank, so it must NOT be summed) and the fused AdamW enqueued.  The fused optimizer calls `finish()` itself
     as a backstop, so paths that never reach the encoder backward (frozen encoder on the reference-style autograd path) are reduced too.
   * ReduceOp.AVG on RCCL; SUM followed by a scale on backends without AVG (gloo, used by the CPU tests).
-  * Payload: fp32 (bit-faithful averaging, the parity default) or 16 bit (`compress="bf16"`, the default of the bf16 throughput
-    mode; SURVEY.md §8(e) "prefer bf16 payload"): the range is cast into a persistent bf16 staging buffer laid out like the
+  * Payload: fp32 (bit-faithful averaging, the parity default and -- r05 -- the default of the IEEE-half build, whose half payload can overflow:
+    see attach()) or 16 bit (`compress="bf16"`, the default of the bf16 throughput mode; SURVEY.md §8(e) "prefer bf16 payload"): the range is cast into a persistent bf16 staging buffer laid out like the
     gradient buffer (`climb_cast_bf16`), reduced there, and cast back with the averaging scale folded in
     (`climb_uncast_bf16_scale`).  Halves the bytes every xGMI link carries (480 -> 240 MB per step) for two extra streaming
     passes over the gradients; the rounding (2^-9 relative per element, once) is below the bf16 GEMM noise already in those
@@ -117,8 +117,13 @@ class GradientAllReducer:
         # 16-bit payload: "bf16" on the bf16 build; on the IEEE-half build the cast kernels produce half, whose range only holds the gradients
         # while they still carry the engine's loss scale -- "fp16": the engine hands ranges over BEFORE unscaling them (takes_scaled) and
         # finish() divides the scale out together with the averaging factor
+        # r05: the half payload is OPT-IN (CLIMB_AMD_DP_COMPRESS=fp16 / compress="fp16"), the half build defaults to the fp32 payload.  The engine's loss
+        # scale puts |d(logits)| near 2^7, but a weight gradient sums over a batch's tokens: bench.py's two-rank run on this build (8 sequences per rank,
+        # scale 2^10) carried 3.5e4 in the position-embedding gradient of ONE rank -- their sum left half's range (6.9e4 > 65504), the average came back
+        # inf and the replicas NaN (found by tests/test_gpu_rccl.py::test_bench_two_ranks_on_one_gpu_through_gloo on the half build).  bf16 has fp32's
+        # range: the bf16 build keeps its 16-bit payload.
         if mode is None:
-            mode = ("fp16" if fp16_lib else "bf16") if getattr(eng, "precision", "fp32") == "bf16" else "none"
+            mode = ("none" if fp16_lib else "bf16") if getattr(eng, "precision", "fp32") == "bf16" else "none"
         if mode not in ("none", "bf16", "fp16"):
             raise ValueError(f"unknown gradient compression {mode!r}")
         if (mode == "bf16" and fp16_lib) or (mode == "fp16" and not fp16_lib):

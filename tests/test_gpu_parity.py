@@ -1367,6 +1367,8 @@ BACKENDS = ["gloo", "nccl"]
 
 def _dp_worker(rank, world, port, q, precision, gbatch=4, promise=False, backend="gloo"):
     dist = dp_join(rank, world, port, backend)
+    if promise and precision == "fp16":
+        os.environ["CLIMB_AMD_DP_COMPRESS"] = "fp16"          # (the half payload is opt-in since r05; the deferred un-cast exists for 16-bit payloads)
     try:
         from climb_amd.parallel import GradientAllReducer
         torch.manual_seed(1000 + rank)                                     # replicas start DIFFERENT: the broadcast must fix that

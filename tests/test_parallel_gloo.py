@@ -156,12 +156,13 @@ def test_cu_reserve_is_held_only_while_collectives_run_under_the_backward(overla
 
 def test_payload_type_follows_the_librarys_16_bit_type():
     """On the IEEE-half build of the library the 16-bit cast kernels produce half, whose range holds the gradients only while they carry the
-    loss scale: the reducer's 16-bit payload is "fp16" there (scaled ranges, scale divided out in finish()) and an explicit bf16 one is
-    refused; on the bf16 build the throughput mode defaults to bf16."""
+    loss scale: the reducer's 16-bit payload is "fp16" there (scaled ranges, scale divided out in finish(); opt-in since r05) and an explicit bf16 one
+    is refused; on the bf16 build the throughput mode defaults to bf16."""
     from climb_amd.layout import FlatLayout, TASK_ARITH
     from climb_amd.parallel import GradientAllReducer
     lay = FlatLayout(["vqa"], TASK_ARITH)
-    for h16, precision, want in (("bf16", "bf16", "bf16"), ("fp16", "bf16", "fp16"), (None, "fp32", "none")):
+    # (r05: the half build DEFAULTS to the fp32 payload -- a scaled weight gradient can leave half's range when ranks are summed -- "fp16" is opt-in)
+    for h16, precision, want in (("bf16", "bf16", "bf16"), ("fp16", "bf16", "none"), (None, "fp32", "none")):
         eng = _FakeEngine(lay, 0)
         eng.h16, eng.precision = h16, precision
         r = GradientAllReducer()
