@@ -587,12 +587,18 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt4_kernel(const bf16_t* A, lon
     }
   }
   // the workgroup's last tile: nothing left to hide under.  Operands first (no store is pending that a load could queue behind), one wait,
-  // then the blocks; the fp32 residual (16 registers per block) in two rounds, the second behind the first round's stores
+  // then the blocks
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int j = 0; j < 3; ++j) nt4_bias_issue(bias, j, u, l);
+#if NT4_OLD_BOUNDARY
   nt4_final<TO, EPI, 0, (EPI == EPI_RESID ? 5 : 9)>(accP, rbk, hold, bias, u, l, smem);
   if constexpr (EPI == EPI_RESID) nt4_final<TO, EPI, 5, 9>(accP, rbk, hold, bias, u, l, smem);
+#else
+  // r05: ONE round for the fp32 residual too (144 operand registers: the k-loop's fragment and staging registers are dead here, the kernel's peak
+  // stays at 256 without scratch) -- the second round's loads used to queue behind the first round's stores (a vmcnt(0) drain in mid-epilogue)
+  nt4_final<TO, EPI, 0, 9>(accP, rbk, hold, bias, u, l, smem);
+#endif
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // no LDS-DMA may outlive the workgroup's LDS allocation
 }
 
