@@ -9,6 +9,7 @@
 
 #define CLIMB_DT_F32 0
 #define CLIMB_DT_BF16 1
+#define CLIMB_DT_SPLIT 2      // r06: a (hi, lo) PAIR of 16-bit planes: x ~= hi + lo, hi = rn16(x), lo = rn16(x - hi) (split.hip); the pointer names the hi plane
 
 // The 16-bit operand type of the throughput mode.  One source tree, two libraries: libclimb_hip.so (bf16: 8 significant bits, fp32's range;
 // BASELINE configs[1]) and libclimb_hip_f16.so (-DCLIMB_H16_F16: IEEE half, 11 significant bits -- 8x smaller operand rounding at the same
@@ -88,6 +89,23 @@ __device__ __forceinline__ void st4(bf16_t* p, float4 v) {
   r.y = pack_bf16x2(v.z, v.w);
   *reinterpret_cast<uint2*>(p) = r;
 }
+
+// r06, split operands (split.hip): element type of the hi plane of a (hi, lo) pair -- same size as bf16_t, so row / column arithmetic on a
+// `sp16_t*` is that of the 16-bit tensor; the lo plane lies `lo` ELEMENTS behind it.  hi = rn16(x), lo = rn16(x - hi): with bf16 planes
+// hi + lo carries 16 significant bits of x (and fp32's range), the three MFMA products hi.hi + hi.lo + lo.hi recover a product to ~2^-16.
+struct sp16_t { bf16_t v; };
+__device__ __forceinline__ void split_st4(bf16_t* hi, long lo, float4 v) {
+  uint2 h, l;
+  h.x = pack_bf16x2(v.x, v.y);
+  h.y = pack_bf16x2(v.z, v.w);
+  l.x = pack_bf16x2(v.x - h16lo_to_f32(h.x), v.y - h16hi_to_f32(h.x));
+  l.y = pack_bf16x2(v.z - h16lo_to_f32(h.y), v.w - h16hi_to_f32(h.y));
+  *reinterpret_cast<uint2*>(hi) = h;
+  *reinterpret_cast<uint2*>(hi + lo) = l;
+}
+// st4 with a lo-plane offset that only the split type uses
+template <typename T> __device__ __forceinline__ void st4x(T* p, long, float4 v) { st4(p, v); }
+template <> __device__ __forceinline__ void st4x<sp16_t>(sp16_t* p, long lo, float4 v) { split_st4(reinterpret_cast<bf16_t*>(p), lo, v); }
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

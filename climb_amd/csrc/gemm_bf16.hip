@@ -47,11 +47,13 @@ __device__ __forceinline__ void nt_store(const u32x4 (&r)[4], unsigned char* __r
 // 128 x 128 tile; waves arranged (8/MJ/2) x 2, each owning MJ*32 rows x 64 columns: MJ = 1 -> 8 waves (twice the waves per CU
 // hiding LDS-DMA / L2 latency for the same LDS footprint, at 1.5x the fragment reads per MFMA); MJ = 2 -> 4 waves.
 // (16 waves of 32 x 32 measured the same as 8 within noise on the multi-round shapes: 60 / 105 / 100 us against 62 / 103 / 102.)
-template <typename TO, int EPI, bool GLDS, int MJ>
+// SPLIT (r06, split.hip): A / B are the hi planes of (hi, lo) pairs, the lo planes a_lo / b_lo elements behind; the reduction walks three phases of
+// K / 64 k-tiles -- A {hi, hi, lo} against B {hi, lo, hi} (K % 64 == 0)
+template <typename TO, int EPI, bool GLDS, int MJ, bool SPLIT = false>
 __global__ __launch_bounds__(512 / MJ)
 void gemm_bf16_nt_kernel(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ B, long ldb, TO* __restrict__ C, long ldc, int M, int N,
                          int K, const float* __restrict__ bias, const void* __restrict__ aux, long ldaux, bf16_t* __restrict__ aux_out, long ldauxo,
-                         const bf16_t* __restrict__ aux2, long ldaux2) {
+                         const bf16_t* __restrict__ aux2, long ldaux2, long a_lo = 0, long b_lo = 0) {
   constexpr int NW = 8 / MJ;                       // waves per workgroup
   static_assert(GLDS || MJ == 2, "the register-staged fallback is written for 256 threads");
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * GB_BM * GB_BK * 2];   // [buf][A|B][128][64] bf16 = 64 KB
@@ -68,10 +70,13 @@ void gemm_bf16_nt_kernel(const bf16_t* __restrict__ A, long lda, const bf16_t* _
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   u32x4 ra[4], rb[4];
-  const int nk = (K + GB_BK - 1) / GB_BK;
+  const int ksp = K / GB_BK;
+  const int nk = SPLIT ? 3 * ksp : (K + GB_BK - 1) / GB_BK;
   AuxRegs<EPI, 8 * MJ> ax;
   nt_aux_prefetch<EPI, 2, MJ>(ax, m0 + wm * (32 * MJ), n0 + wn * 64, M, N, aux, ldaux, aux2, ldaux2);
-#define KOFF(kt_) ((kt_) * GB_BK)
+#define KOFF(kt_) (SPLIT ? ((kt_) - ((kt_) >= 2 * ksp ? 2 * ksp : ((kt_) >= ksp ? ksp : 0))) * GB_BK : (kt_) * GB_BK)
+#define KPA(kt_) (SPLIT && (kt_) >= 2 * ksp ? A + a_lo : A)
+#define KPB(kt_) (SPLIT && (kt_) >= ksp && (kt_) < 2 * ksp ? B + b_lo : B)
   if constexpr (GLDS) {
     nt_glds<NW>(A, lda, m0, KOFF(0), M, smem);
     nt_glds<NW>(B, ldb, n0, KOFF(0), N, smem + GB_BM * GB_BK * 2);
@@ -88,11 +93,11 @@ void gemm_bf16_nt_kernel(const bf16_t* __restrict__ A, long lda, const bf16_t* _
     if (kt + 1 < nk) {
       if constexpr (GLDS) {
         unsigned char* An = smem + ((kt + 1) & 1) * (2 * GB_BM * GB_BK * 2);
-        nt_glds<NW>(A, lda, m0, KOFF(kt + 1), M, An);
-        nt_glds<NW>(B, ldb, n0, KOFF(kt + 1), N, An + GB_BM * GB_BK * 2);
+        nt_glds<NW>(KPA(kt + 1), lda, m0, KOFF(kt + 1), M, An);
+        nt_glds<NW>(KPB(kt + 1), ldb, n0, KOFF(kt + 1), N, An + GB_BM * GB_BK * 2);
       } else {
-        nt_load(ra, A, lda, m0, KOFF(kt + 1), M, K);
-        nt_load(rb, B, ldb, n0, KOFF(kt + 1), N, K);
+        nt_load(ra, KPA(kt + 1), lda, m0, KOFF(kt + 1), M, K);
+        nt_load(rb, KPB(kt + 1), ldb, n0, KOFF(kt + 1), N, K);
       }
     }
 #pragma unroll
@@ -124,6 +129,8 @@ void gemm_bf16_nt_kernel(const bf16_t* __restrict__ A, long lda, const bf16_t* _
     __syncthreads();    // with LDS-DMA in flight the compiler drains vmcnt(0) here: tile kt+1 has landed for every wave
   }
 #undef KOFF
+#undef KPA
+#undef KPB
   // every wave is past the last k-tile (barrier above): the buffers become the per-wave staging regions (8 KB each)
   nt_epilogue<TO, EPI, 2, MJ>(acc, ax, smem + wid * 8192, m0 + wm * (32 * MJ), n0 + wn * 64, M, N, C, ldc, bias, aux_out, ldauxo);
 }
@@ -452,6 +459,21 @@ static int nt_dispatch(const bf16_t* A, long lda, const bf16_t* B, long ldb, TO*
 }
 
 static inline bool al16p(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+// r06 (split.hip): the 128 x 128 kernel over split operands -- every shape the four-wave kernel does not take (ragged M, small problems).  fp32 C.
+int climb_nt_split_generic(const bf16_t* A, long lda, long a_lo, const bf16_t* B, long ldb, long b_lo, float* C, long ldc, int M, int N, int K, const float* bias,
+                           int epi, const float* aux, long ldaux, hipStream_t st) {
+  if (K % GB_BK) return CLIMB_EUNSUPPORTED;
+  const int nwg = ((M + GB_BM - 1) / GB_BM) * ((N + GB_BN - 1) / GB_BN);
+#define NTS(E) hipLaunchKernelGGL((gemm_bf16_nt_kernel<float, E, true, 1, true>), dim3(nwg), dim3(512), 0, st, A, lda, B, ldb, C, ldc, M, N, K, bias, (const void*)aux, ldaux, \
+                                  (bf16_t*)nullptr, 0L, (const bf16_t*)nullptr, 0L, a_lo, b_lo)
+  if (epi == EPI_NONE) NTS(EPI_NONE);
+  else if (epi == EPI_RESID) NTS(EPI_RESID);
+  else return CLIMB_EINVAL;
+#undef NTS
+  LAUNCH_CHECK();
+  return CLIMB_OK;
+}
 
 // C (c_dtype: 0 fp32 / 1 bf16) [M,N] = epi(A[M,K] B[N,K]^T + bias).  A, B bf16 with K contiguous; K % 8 == 0, N % 4 == 0.
 // epi 1/5 (GELU/SiLU): aux_out (bf16 [M,N]) receives the pre-activation.  epi 2: aux = fp32 residual [M,N].  epi 3/6: aux = bf16

@@ -81,6 +81,8 @@ struct Nt4Uni {             // wave-uniform state
   // DMA stream
   Nt4Walk dw;
   int dkt, dleft, nk;
+  int ksp;                       // r06, split operands: k-tiles per PHASE (nk = 3 ksp: A hi.B hi, A hi.B lo, A lo.B hi); unused otherwise
+  unsigned alo, blo;             // ... and the byte distance from an operand's hi plane to its lo plane
   unsigned curA, curB;           // byte offset of the stream's k-tile: tile rows + k
   unsigned nxtA, nxtB;           // the NEXT window's (computed under this window's MFMAs, committed before its barrier)
   unsigned dma_off, rd_off;      // stage offsets: DMA destination / fragment reads of this window
@@ -142,6 +144,8 @@ __device__ __forceinline__ void nt4_dma(const Nt4Uni& u, const Nt4Lane& l, unsig
 // MFMA: the r04 kernel ran this bookkeeping there, a dozen scalar instructions and four taken branches (k-tile wrap, last tile, the walk's while loop), and
 // the measurement builds of option 18 put the pure MFMA stream of a launch at 43 cycles per MFMA instead of 32.  Now it is branch-free (selects), computes
 // the NEXT window's offsets in a filler position of slot 20 (under the MFMAs), and nt4_window_end commits them BEFORE the barrier.
+// r06 SPLIT: the stream's k-tile index d runs over three phases of ksp tiles; phase ph reads k-tile d - ph * ksp of A's {hi, hi, lo} and B's {hi, lo, hi} plane.
+template <bool SPLIT = false>
 __device__ __forceinline__ void nt4_dma_next(Nt4Uni& u) {
   const int d1 = u.dkt + 1;
   const bool wrap = d1 == u.nk, more = u.dleft > 1, adv = wrap && more;
@@ -151,12 +155,21 @@ __device__ __forceinline__ void nt4_dma_next(Nt4Uni& u) {
   w.advance();
   u.dw.tml = adv ? w.tml : u.dw.tml;
   u.dw.tn = adv ? w.tn : u.dw.tn;
-  u.nxtA = (unsigned)u.dw.m0() * u.lda2 + (unsigned)u.dkt * 128u;
-  u.nxtB = (unsigned)u.dw.n0() * u.ldb2 + (unsigned)u.dkt * 128u;
+  if constexpr (SPLIT) {
+    const bool p1 = u.dkt >= u.ksp, p2 = u.dkt >= 2 * u.ksp;
+    const unsigned kk = (unsigned)(u.dkt - (p2 ? 2 * u.ksp : (p1 ? u.ksp : 0))) * 128u;
+    u.nxtA = (unsigned)u.dw.m0() * u.lda2 + kk + (p2 ? u.alo : 0u);
+    u.nxtB = (unsigned)u.dw.n0() * u.ldb2 + kk + ((p1 && !p2) ? u.blo : 0u);
+  } else {
+    u.nxtA = (unsigned)u.dw.m0() * u.lda2 + (unsigned)u.dkt * 128u;
+    u.nxtB = (unsigned)u.dw.n0() * u.ldb2 + (unsigned)u.dkt * 128u;
+  }
 }
 __device__ __forceinline__ void nt4_dma_commit(Nt4Uni& u) { u.curA = u.nxtA; u.curB = u.nxtB; }
+template <bool SPLIT = false>
 __device__ __forceinline__ void nt4_dma_advance(Nt4Uni& u) {
 #if NT4_OLD_BOUNDARY
+  static_assert(!SPLIT, "the A/B build has no split instantiation");
   ++u.dkt;
   if (u.dkt == u.nk) {
     if (u.dleft > 1) { --u.dleft; u.dkt = 0; u.dw.advance(); }
@@ -165,7 +178,7 @@ __device__ __forceinline__ void nt4_dma_advance(Nt4Uni& u) {
   u.curA = (unsigned)u.dw.m0() * u.lda2 + (unsigned)u.dkt * 128u;
   u.curB = (unsigned)u.dw.n0() * u.ldb2 + (unsigned)u.dkt * 128u;
 #else
-  nt4_dma_next(u);
+  nt4_dma_next<SPLIT>(u);
   nt4_dma_commit(u);
 #endif
 }
@@ -320,6 +333,7 @@ __device__ __forceinline__ void nt4_set_prev(Nt4Uni& u, int m0, int n0) {
 template <int PR_, bool SW_, int EB_, int AB_, bool BL_, bool DMA_, bool RD_, int SB_ = -1> struct Nt4Cfg {
   static constexpr bool SW = SW_, BL = BL_ && !(PR_ & 2), DMA = DMA_ && !(PR_ & 1), RD = RD_ && !(PR_ & 16), STAG = (PR_ & 4) != 0, NOBAR = (PR_ & 8) != 0;
   static constexpr int EB = (PR_ & 2) ? -1 : EB_, AB = (PR_ & 2) ? -1 : AB_, SB = (PR_ & 2) ? -1 : SB_;
+  static constexpr bool SPLIT = (PR_ & 32) != 0;          // r06: three-phase reduction over (hi, lo) operand planes (not a measurement build)
 };
 template <typename TO, int EPI, class CFG, int Q>
 __device__ __forceinline__ void nt4_slot(f32x16 (&accC)[3][3], f32x16 (&accP)[3][3], bf16x8 (&fa)[2][3], bf16x8 (&fb)[2][3], f32x4 (&rbk)[4], u32x2 (&hold)[8], Nt4Act& act,
@@ -350,7 +364,7 @@ __device__ __forceinline__ void nt4_slot(f32x16 (&accC)[3][3], f32x16 (&accP)[3]
   if constexpr (CFG::DMA && !CFG::STAG && nt4_dma_piece(Q) >= 0) nt4_dma<(nt4_dma_piece(Q) < 0 ? 0 : nt4_dma_piece(Q))>(u, l, smem);
   if constexpr (CFG::DMA && CFG::STAG && Q >= 4 && Q < 16) nt4_dma<(Q >= 4 && Q < 16 ? Q - 4 : 0)>(u, l, smem);      // every piece early in the window
 #if !NT4_OLD_BOUNDARY
-  if constexpr (CFG::DMA && Q == 20) nt4_dma_next(u);          // the next window's stream position (scalar selects, under this slot's MFMA)
+  if constexpr (CFG::DMA && Q == 20) nt4_dma_next<CFG::SPLIT>(u);          // the next window's stream position (scalar selects, under this slot's MFMA)
 #endif
   if constexpr (CFG::EB >= 0) {
     constexpr int ei = CFG::EB / 3, ej = CFG::EB % 3;
@@ -432,7 +446,7 @@ template <typename TO, int EPI, class CFG>
 __device__ __forceinline__ void nt4_window(f32x16 (&accC)[3][3], f32x16 (&accP)[3][3], bf16x8 (&fa)[2][3], bf16x8 (&fb)[2][3], f32x4 (&rbk)[4], u32x2 (&hold)[8], Nt4Act& act,
                                            f32x4 (&bias)[3], Nt4Aux<EPI> (&aux)[2], Nt4Uni& u, const Nt4Lane& l, unsigned char* smem) {
 #if NT4_OLD_BOUNDARY
-  nt4_dma_advance(u);
+  nt4_dma_advance<CFG::SPLIT>(u);
 #endif
   nt4_slots<TO, EPI, CFG, 0, 36>(accC, accP, fa, fb, rbk, hold, act, bias, aux, u, l, smem);
   nt4_window_end<12, EPI, CFG::NOBAR>(u, aux, bias);
@@ -462,7 +476,8 @@ __device__ __forceinline__ void nt4_final(f32x16 (&accP)[3][3], f32x4 (&rbk)[4],
 
 template <typename TO, int EPI, int PROBE = 0>
 __global__ __launch_bounds__(256) void gemm_bf16_nt4_kernel(const bf16_t* A, long lda, const bf16_t* B, long ldb, TO* C, long ldc, int M, int N, int K, const float* bias_g,
-                                                            const void* aux_g, long ldaux, bf16_t* aux_out, long ldauxo, int probe) {
+                                                            const void* aux_g, long ldaux, bf16_t* aux_out, long ldauxo, int probe, unsigned a_lo_b = 0, unsigned b_lo_b = 0) {
+  constexpr bool SPLIT = (PROBE & 32) != 0;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63;
   Nt4Uni u;
@@ -471,7 +486,10 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt4_kernel(const bf16_t* A, lon
   const int half = lane >> 5, l31 = lane & 31;
   const int nbm = M / NT4_T, nbn = N / NT4_T, nwg = nbm * nbn, G = gridDim.x;
   const int ntw = (nwg - (int)blockIdx.x + G - 1) / G;          // tiles of this workgroup (>= 1)
-  u.nk = K / GB_BK;
+  u.ksp = K / GB_BK;
+  u.nk = SPLIT ? 3 * u.ksp : u.ksp;
+  u.alo = a_lo_b;
+  u.blo = b_lo_b;
   u.probe = probe;          // (r04's run-time vmcnt experiments are gone; the compile-time measurement builds remain)
   u.stag = u.wid % 3u;
   // resources: raw buffers (stride 0), range = 2 GB (the launcher checks sizes); a missing bias reads as zeros through an empty range
@@ -533,13 +551,13 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt4_kernel(const bf16_t* A, lon
   // prologue: k-tiles 0, 1, 2 of the stream into stages 0, 1, 2
 #pragma unroll
   for (int s = 0; s < 3; ++s) {
-    nt4_dma_advance(u);
+    nt4_dma_advance<SPLIT>(u);
     u.dma_off = s * NT4_STAGE;
     nt4_dma<0>(u, l, smem); nt4_dma<1>(u, l, smem); nt4_dma<2>(u, l, smem); nt4_dma<3>(u, l, smem); nt4_dma<4>(u, l, smem); nt4_dma<5>(u, l, smem);
     nt4_dma<6>(u, l, smem); nt4_dma<7>(u, l, smem); nt4_dma<8>(u, l, smem); nt4_dma<9>(u, l, smem); nt4_dma<10>(u, l, smem); nt4_dma<11>(u, l, smem);
   }
 #if !NT4_OLD_BOUNDARY
-  nt4_dma_next(u);                                            // the first full window's k-tile (committed by the half window's end below)
+  nt4_dma_next<SPLIT>(u);                                     // the first full window's k-tile (committed by the half window's end below)
 #endif
   asm volatile("s_waitcnt vmcnt(24)" ::: "memory");          // k-tile 0 is all this half window reads
   __builtin_amdgcn_s_barrier();
@@ -669,3 +687,36 @@ int climb_nt4_launch(const bf16_t* A, long lda, const bf16_t* B, long ldb, void*
 #undef L4
   return CLIMB_EUNSUPPORTED;
 }
+
+#ifndef NT4_SLP_BUILD
+// r06: the same kernel over split operands (split.hip): A / B name the hi planes, the lo planes lie a_lo / b_lo ELEMENTS behind; fp32 C, epilogues NONE / RESID.
+// K = the logical reduction depth (the kernel walks 3 K / 64 k-tiles).
+int climb_nt4_split_launch(const bf16_t* A, long lda, long a_lo, const bf16_t* B, long ldb, long b_lo, float* C, long ldc, int M, int N, int K, const float* bias,
+                           int epi, const void* aux, long ldaux, hipStream_t st) {
+  if (g_nt4 == 0) return CLIMB_EUNSUPPORTED;
+  if ((M % NT4_T) || (N % NT4_T) || ((M / NT4_T) % 8) || (K % GB_BK) || 3 * K < 10 * GB_BK) return CLIMB_EUNSUPPORTED;
+  const long lim = 1L << 31;
+  if (((long)M * lda + K + a_lo) * 2 >= lim || ((long)N * ldb + K + b_lo) * 2 >= lim || (long)M * ldc * 4 >= lim || (long)M * ldaux * 4 >= lim || a_lo < 0 || b_lo < 0)
+    return CLIMB_EUNSUPPORTED;
+  const int tiles = (M / NT4_T) * (N / NT4_T);
+  int grid = g_nt4_grid > 0 ? (g_nt4_grid / 8) * 8 : 256;
+  if (grid < 8) grid = 8;
+  const int nwg = tiles < grid ? tiles : grid;
+#define L4S(E)                                                                                                                                              \
+  do {                                                                                                                                                      \
+    static bool configured = false;                                                                                                                         \
+    if (!configured) {                                                                                                                                      \
+      hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_nt4_kernel<float, E, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, NT4_LDS);             \
+      if (e != hipSuccess) return (int)e;                                                                                                                   \
+      configured = true;                                                                                                                                    \
+    }                                                                                                                                                       \
+    hipLaunchKernelGGL((gemm_bf16_nt4_kernel<float, E, 32>), dim3(nwg), dim3(256), NT4_LDS, st, A, lda, B, ldb, C, ldc, M, N, K, bias, aux, ldaux,          \
+                       (bf16_t*)nullptr, 0L, 0, (unsigned)(a_lo * 2), (unsigned)(b_lo * 2));                                                                \
+    return CLIMB_OK;                                                                                                                                        \
+  } while (0)
+  if (epi == EPI_RESID) L4S(EPI_RESID);
+  if (epi == EPI_NONE) L4S(EPI_NONE);
+#undef L4S
+  return CLIMB_EUNSUPPORTED;
+}
+#endif

@@ -24,15 +24,19 @@
 __device__ __forceinline__ int tnp_aswz(int row) { return (row & 3) << 2; }
 __device__ __forceinline__ int tnp_bswz(int row) { return ((row >> 1) & 1) << 2; }
 
-template <int NI>
+// SPLIT (r06, split.hip): the operands are (hi, lo) plane pairs stacked along the token dimension ([2 M, .]: the lo plane follows the hi plane), and the
+// reduction walks 3 M / 64 VIRTUAL tiles -- A {hi, hi, lo} against B {hi, lo, hi}: virtual tile v = t0 + t reads row tile v - (v >= mt ? mt : 0) of A
+// and v - (v >= 2 mt ? 2 mt : 0) of B (mt = M / 64).
+template <int NI, bool SPLIT = false>
 struct TnpStage {
   unsigned a_off[4];       // per lane: byte offset (from A + first token row of the split) of its 4 DMA sources of the A image
   unsigned b_off[NI];      // per lane: byte offset (from B + first token row of the split) of its DMA source of B unit p
   unsigned wid;
+  int mt, t0;              // SPLIT only
 };
 
-template <int NI, int P, bool D1, bool D2, int K_ = 0>
-__device__ __forceinline__ void tnp_issue(const TnpStage<NI>& sg, const unsigned char* __restrict__ A, long a_tile, const unsigned char* __restrict__ B,
+template <int NI, int P, bool D1, bool D2, int K_ = 0, bool SPLIT = false>
+__device__ __forceinline__ void tnp_issue(const TnpStage<NI, SPLIT>& sg, const unsigned char* __restrict__ A, long a_tile, const unsigned char* __restrict__ B,
                                           long b_tile, unsigned char* __restrict__ smem, int T) {
   if constexpr (K_ < NTP_MAXI) {
     constexpr int BUF = NTP_A_BYTES + NI * NTP_B_UNIT;
@@ -42,13 +46,19 @@ __device__ __forceinline__ void tnp_issue(const TnpStage<NI>& sg, const unsigned
       if constexpr ((d == 1 && D1) || (d == 2 && D2)) {
         const int t = T + d;
         unsigned char* buf = smem + (t & 1) * BUF;
+        int ta = t, tb = t;
+        if constexpr (SPLIT) {
+          const int v = sg.t0 + t;
+          ta = v - (v >= sg.mt ? sg.mt : 0);
+          tb = v - (v >= 2 * sg.mt ? 2 * sg.mt : 0);
+        }
         if constexpr (unit < 2) {
 #pragma unroll
           for (int i = 0; i < 2; ++i)
-            __builtin_amdgcn_global_load_lds((gbl_void_t*)(A + (long)t * a_tile + sg.a_off[unit * 2 + i]),
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)(A + (long)ta * a_tile + sg.a_off[unit * 2 + i]),
                                              (lds_void_t*)(buf + unit * (NTP_A_BYTES / 2) + (sg.wid * 2 + i) * 1024), 16, 0, 0);
         } else {
-          __builtin_amdgcn_global_load_lds((gbl_void_t*)(B + (long)t * b_tile + sg.b_off[unit - 2]),
+          __builtin_amdgcn_global_load_lds((gbl_void_t*)(B + (long)tb * b_tile + sg.b_off[unit - 2]),
                                            (lds_void_t*)(buf + NTP_A_BYTES + (unit - 2) * NTP_B_UNIT + sg.wid * 1024), 16, 0, 0);
         }
       }
@@ -77,8 +87,8 @@ __device__ __forceinline__ float tnp_sum8(bf16x8 v) {
   return s;
 }
 
-template <int NI, int P, bool D1, bool D2, int W>
-__device__ __forceinline__ void tnp_phase(f32x16 (&acc)[NI][2], bf16x8 (&a)[2][4], float (&bsum)[2], bool bias_tile, const TnpStage<NI>& sg,
+template <int NI, int P, bool D1, bool D2, int W, bool SPLIT = false>
+__device__ __forceinline__ void tnp_phase(f32x16 (&acc)[NI][2], bf16x8 (&a)[2][4], float (&bsum)[2], bool bias_tile, const TnpStage<NI, SPLIT>& sg,
                                           const unsigned char* __restrict__ A, long a_tile, const unsigned char* __restrict__ B, long b_tile,
                                           unsigned char* __restrict__ smem, int T, const unsigned (&aoff)[2], unsigned boff) {
   constexpr int BUF = NTP_A_BYTES + NI * NTP_B_UNIT;
@@ -117,8 +127,8 @@ __device__ __forceinline__ void tnp_phase(f32x16 (&acc)[NI][2], bf16x8 (&a)[2][4
   __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int NI, int MODE, int P = 0>
-__device__ __forceinline__ void tnp_ktile(f32x16 (&acc)[NI][2], bf16x8 (&a)[2][4], float (&bsum)[2], bool bias_tile, const TnpStage<NI>& sg,
+template <int NI, int MODE, int P = 0, bool SPLIT = false>
+__device__ __forceinline__ void tnp_ktile(f32x16 (&acc)[NI][2], bf16x8 (&a)[2][4], float (&bsum)[2], bool bias_tile, const TnpStage<NI, SPLIT>& sg,
                                           const unsigned char* __restrict__ A, long a_tile, const unsigned char* __restrict__ B, long b_tile,
                                           unsigned char* __restrict__ smem, int T, const unsigned (&aoff)[2], unsigned boff) {
   if constexpr (P < NI) {
@@ -127,8 +137,8 @@ __device__ __forceinline__ void tnp_ktile(f32x16 (&acc)[NI][2], bf16x8 (&a)[2][4
     tnp_ktile<NI, MODE, P + 1>(acc, a, bsum, bias_tile, sg, A, a_tile, B, b_tile, smem, T, aoff, boff);
   }
 }
-template <int NI, int P = 0>
-__device__ __forceinline__ void tnp_prologue(const TnpStage<NI>& sg, const unsigned char* __restrict__ A, long a_tile, const unsigned char* __restrict__ B,
+template <int NI, int P = 0, bool SPLIT = false>
+__device__ __forceinline__ void tnp_prologue(const TnpStage<NI, SPLIT>& sg, const unsigned char* __restrict__ A, long a_tile, const unsigned char* __restrict__ B,
                                              long b_tile, unsigned char* __restrict__ smem) {
   if constexpr (P < NI) {
     tnp_issue<NI, P, false, true>(sg, A, a_tile, B, b_tile, smem, -2);
@@ -396,7 +406,7 @@ __device__ __forceinline__ void tn_quad_transpose(float (&r)[4], int lane) {
 
 // RAGGED: N, K any multiples of 8 (the adapters' 768 x 48 / 48 x 768 gradients ride in the same launch as 256 x 256 tiles whose surplus
 // columns are computed on clamped addresses and never stored -- the FLOPs of those GEMMs are nothing, their launches and operand reads were).
-template <bool RAGGED, bool FUSED = false, bool EWC = false>
+template <bool RAGGED, bool FUSED = false, bool EWC = false, bool SPLIT = false>
 __global__ __launch_bounds__(512) void gemm_bf16_tn_grouped_kernel(const TnGroupProblem* __restrict__ probs, const TnGroupItem* __restrict__ items,
                                                                    const int* __restrict__ first, const TnGroupOpt* __restrict__ opts = nullptr, TnAdam ad = TnAdam()) {
   constexpr int NI = 4, BK_ = 256;
@@ -425,10 +435,12 @@ __global__ __launch_bounds__(512) void gemm_bf16_tn_grouped_kernel(const TnGroup
     const long lda = P.lda, ldb = P.ldb, ldc = P.ldc;
     const int n0 = tn * NTP_BM, k0 = tk * BK_;
     const long a_tile = 64 * lda * 2, b_tile = 64 * ldb * 2;
-    const unsigned char* A = reinterpret_cast<const unsigned char*>(P.A) + (long)kt0 * a_tile;
-    const unsigned char* B = reinterpret_cast<const unsigned char*>(P.B) + (long)kt0 * b_tile;
-    TnpStage<NI> sg;
+    const unsigned char* A = reinterpret_cast<const unsigned char*>(P.A) + (SPLIT ? 0L : (long)kt0 * a_tile);
+    const unsigned char* B = reinterpret_cast<const unsigned char*>(P.B) + (SPLIT ? 0L : (long)kt0 * b_tile);
+    TnpStage<NI, SPLIT> sg;
     sg.wid = wid;
+    sg.mt = P.reserved;          // (SPLIT: reduction tiles per phase; the problem's M counts all three)
+    sg.t0 = kt0;
 #pragma unroll
     for (int u = 0; u < 2; ++u)
 #pragma unroll
@@ -463,9 +475,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_tn_grouped_kernel(const TnGroup
     if (grp == 1) __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     int T = 0;
-    for (; T + 2 < nk; ++T) tnp_ktile<NI, 0>(acc, a, bsum, do_bias && (T % nbk) == tb, sg, A, a_tile, B, b_tile, smem, T, aoff, boff);
-    tnp_ktile<NI, 1>(acc, a, bsum, do_bias && (T % nbk) == tb, sg, A, a_tile, B, b_tile, smem, T, aoff, boff);
-    tnp_ktile<NI, 2>(acc, a, bsum, do_bias && ((T + 1) % nbk) == tb, sg, A, a_tile, B, b_tile, smem, T + 1, aoff, boff);
+    // (SPLIT: the column sums of A are those of its hi and lo planes once each -- the second phase re-reads the hi plane and is left out)
+    auto bias_at = [&](int t_) { return do_bias && (t_ % nbk) == tb && !(SPLIT && kt0 + t_ >= sg.mt && kt0 + t_ < 2 * sg.mt); };
+    for (; T + 2 < nk; ++T) tnp_ktile<NI, 0>(acc, a, bsum, bias_at(T), sg, A, a_tile, B, b_tile, smem, T, aoff, boff);
+    tnp_ktile<NI, 1>(acc, a, bsum, bias_at(T), sg, A, a_tile, B, b_tile, smem, T, aoff, boff);
+    tnp_ktile<NI, 2>(acc, a, bsum, bias_at(T + 1), sg, A, a_tile, B, b_tile, smem, T + 1, aoff, boff);
     if (grp == 0) __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     float* Cb = P.C + (long)(n0 + wr * 64 + 4 * half) * ldc + k0 + wc * (32 * NI) + l31;
@@ -741,6 +755,24 @@ extern "C" int climb_gemm_bf16_tn_grouped(const void* probs, const void* items, 
   else
     hipLaunchKernelGGL(gemm_bf16_tn_grouped_kernel<false>, dim3(nwg), dim3(512), LDS, (hipStream_t)stream, (const TnGroupProblem*)probs,
                        (const TnGroupItem*)items, (const int*)first);
+  LAUNCH_CHECK();
+  return CLIMB_OK;
+}
+
+// r06 (split.hip): the grouped launch over split operands.  A problem's A / B name the hi planes of (hi, lo) pairs stacked along the token dimension (the
+// lo plane directly behind the hi plane: [2 Mt, .]), its M field = 3 Mt (the three phases the planner cuts like any reduction) and `reserved` = Mt / 64.
+// Whole 256 x 256 tiles only (no ragged problems); dbias += the column sums of A hi + A lo.
+extern "C" int climb_gemm_split_tn_grouped(const void* probs, const void* items, const void* first, int nwg, void* stream) {
+  if (!probs || !items || !first || nwg <= 0) return CLIMB_EINVAL;
+  constexpr int LDS = 2 * (NTP_A_BYTES + 4 * NTP_B_UNIT);
+  static bool configured = false;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_tn_grouped_kernel<false, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) return (int)e;
+    configured = true;
+  }
+  hipLaunchKernelGGL((gemm_bf16_tn_grouped_kernel<false, false, false, true>), dim3(nwg), dim3(512), LDS, (hipStream_t)stream, (const TnGroupProblem*)probs,
+                     (const TnGroupItem*)items, (const int*)first);
   LAUNCH_CHECK();
   return CLIMB_OK;
 }

@@ -15,7 +15,7 @@
 template <typename TO, int NV, int RPW>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, long ldx, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float eps, TO* __restrict__ y, long ldy,
-                                                            float* __restrict__ mean_out, float* __restrict__ rstd_out, int M, int C) {
+                                                            float* __restrict__ mean_out, float* __restrict__ rstd_out, int M, int C, long ylo = 0) {
   const int lane = threadIdx.x & 63;
   const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW;
   if (row0 >= M) return;
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
         float4 g = ld4(gamma + c), b = ld4(beta + c);
         float4 o = make_float4((v[r][i].x - mean) * rstd * g.x + b.x, (v[r][i].y - mean) * rstd * g.y + b.y,
                                (v[r][i].z - mean) * rstd * g.z + b.z, (v[r][i].w - mean) * rstd * g.w + b.w);
-        st4(yr + c, o);
+        st4x(yr + c, ylo, o);          // (ylo: the lo plane of a split output, r06)
       }
     }
   }
@@ -70,11 +70,11 @@ static int g_ln_rpw = 1;
 void climb_ln_set_rpw(int v) { g_ln_rpw = v; }
 template <typename TO>
 static int layernorm_fwd_launch(const float* x, long ldx, const float* g, const float* b, float eps, TO* y, long ldy, float* mean,
-                                float* rstd, int M, int C, hipStream_t st) {
+                                float* rstd, int M, int C, hipStream_t st, long ylo = 0) {
   if (C % 4 || M <= 0) return CLIMB_EINVAL;
   const int rpw = (g_ln_rpw >= 2 && M >= 4096) ? g_ln_rpw : 1;          // the small launches (B rows of the pooler / heads) keep one row per wave
   dim3 grid((M + 4 * rpw - 1) / (4 * rpw)), blk(256);
-#define LNF(NV_, R_) hipLaunchKernelGGL((layernorm_fwd_kernel<TO, NV_, R_>), grid, blk, 0, st, x, ldx, g, b, eps, y, ldy, mean, rstd, M, C)
+#define LNF(NV_, R_) hipLaunchKernelGGL((layernorm_fwd_kernel<TO, NV_, R_>), grid, blk, 0, st, x, ldx, g, b, eps, y, ldy, mean, rstd, M, C, ylo)
   if (C <= 768) { if (rpw == 2) LNF(3, 2); else if (rpw >= 3) LNF(3, 3); else LNF(3, 1); }
   else if (C <= 1536) { if (rpw == 2) LNF(6, 2); else LNF(6, 1); }
   else return CLIMB_EUNSUPPORTED;
@@ -88,6 +88,7 @@ extern "C" int climb_layernorm_fwd(const float* x, long ldx, const float* gamma,
   hipStream_t st = (hipStream_t)stream;
   if (y_dtype == CLIMB_DT_F32) return layernorm_fwd_launch<float>(x, ldx, gamma, beta, eps, (float*)y, ldy, mean, rstd, M, C, st);
   if (y_dtype == CLIMB_DT_BF16) return layernorm_fwd_launch<bf16_t>(x, ldx, gamma, beta, eps, (bf16_t*)y, ldy, mean, rstd, M, C, st);
+  if (y_dtype == CLIMB_DT_SPLIT) return layernorm_fwd_launch<sp16_t>(x, ldx, gamma, beta, eps, (sp16_t*)y, ldy, mean, rstd, M, C, st, (long)M * ldy);
   return CLIMB_EINVAL;
 }
 
@@ -105,7 +106,7 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void layernorm_bwd_kernel(const TI*
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             const float* __restrict__ gamma, const float* dres_in, long ldr,
                                                             float* dxo, long ldo, TO* __restrict__ dcast, long ldc,
-                                                            float* __restrict__ part, int M, int C) {
+                                                            float* __restrict__ part, int M, int C, long clo = 0) {
   __shared__ __attribute__((aligned(16))) float red[LNB_WAVES][NV * 256];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   float4 ag[NV], ab[NV], as[NV];
@@ -153,7 +154,7 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void layernorm_bwd_kernel(const TI*
         float4 o = make_float4(r.x + rs * (g[i].x - m1 - xh[i].x * m2), r.y + rs * (g[i].y - m1 - xh[i].y * m2),
                                r.z + rs * (g[i].z - m1 - xh[i].z * m2), r.w + rs * (g[i].w - m1 - xh[i].w * m2));
         st4(dxo + (long)row * ldo + c, o);
-        if (dcast) st4(dcast + (long)row * ldc + c, o);
+        if (dcast) st4x(dcast + (long)row * ldc + c, clo, o);
         ag[i].x += d[i].x * xh[i].x; ag[i].y += d[i].y * xh[i].y; ag[i].z += d[i].z * xh[i].z; ag[i].w += d[i].w * xh[i].w;
         ab[i].x += d[i].x; ab[i].y += d[i].y; ab[i].z += d[i].z; ab[i].w += d[i].w;
         as[i].x += o.x; as[i].y += o.y; as[i].z += o.z; as[i].w += o.w;
@@ -181,19 +182,19 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void layernorm_bwd_kernel(const TI*
 template <typename TI, typename TO>
 static int layernorm_bwd_launch(const TI* dy, long lddy, const float* x, long ldx, const float* mean, const float* rstd, const float* gamma,
                                 const float* dres_in, long ldr, float* dxo, long ldo, TO* dcast, long ldc, float* part, int M, int C,
-                                hipStream_t st) {
+                                hipStream_t st, long clo = 0) {
   if (C % 4 || M <= 0) return CLIMB_EINVAL;
   dim3 grid((M + LNB_ROWS - 1) / LNB_ROWS), blk(64 * LNB_WAVES);
   if (C <= 768)
-    hipLaunchKernelGGL((layernorm_bwd_kernel<TI, TO, 3>), grid, blk, 0, st, dy, lddy, x, ldx, mean, rstd, gamma, dres_in, ldr, dxo, ldo, dcast, ldc, part, M, C);
+    hipLaunchKernelGGL((layernorm_bwd_kernel<TI, TO, 3>), grid, blk, 0, st, dy, lddy, x, ldx, mean, rstd, gamma, dres_in, ldr, dxo, ldo, dcast, ldc, part, M, C, clo);
   else if (C <= 1536)
-    hipLaunchKernelGGL((layernorm_bwd_kernel<TI, TO, 6>), grid, blk, 0, st, dy, lddy, x, ldx, mean, rstd, gamma, dres_in, ldr, dxo, ldo, dcast, ldc, part, M, C);
+    hipLaunchKernelGGL((layernorm_bwd_kernel<TI, TO, 6>), grid, blk, 0, st, dy, lddy, x, ldx, mean, rstd, gamma, dres_in, ldr, dxo, ldo, dcast, ldc, part, M, C, clo);
   else return CLIMB_EUNSUPPORTED;
   LAUNCH_CHECK();
   return CLIMB_OK;
 }
 
-// part must hold ceil(M/32)*3*C floats.  dtype applies to dy and dcast.
+// part must hold ceil(M/32)*3*C floats.  dtype applies to dy and dcast (CLIMB_DT_SPLIT: dy fp32, dcast a (hi, lo) plane pair [2][M][ldc]).
 extern "C" int climb_layernorm_bwd(const void* dy, long lddy, int dtype, const float* x, long ldx, const float* mean, const float* rstd,
                                    const float* gamma, const float* dres_in, long ldr, float* dxo, long ldo, void* dcast, long ldc,
                                    float* part, int M, int C, void* stream) {
@@ -202,6 +203,8 @@ extern "C" int climb_layernorm_bwd(const void* dy, long lddy, int dtype, const f
     return layernorm_bwd_launch<float, float>((const float*)dy, lddy, x, ldx, mean, rstd, gamma, dres_in, ldr, dxo, ldo, (float*)dcast, ldc, part, M, C, st);
   if (dtype == CLIMB_DT_BF16)
     return layernorm_bwd_launch<bf16_t, bf16_t>((const bf16_t*)dy, lddy, x, ldx, mean, rstd, gamma, dres_in, ldr, dxo, ldo, (bf16_t*)dcast, ldc, part, M, C, st);
+  if (dtype == CLIMB_DT_SPLIT)
+    return layernorm_bwd_launch<float, sp16_t>((const float*)dy, lddy, x, ldx, mean, rstd, gamma, dres_in, ldr, dxo, ldo, (sp16_t*)dcast, ldc, part, M, C, st, (long)M * ldc);
   return CLIMB_EINVAL;
 }
 extern "C" int climb_layernorm_bwd_rows_per_block() { return LNB_ROWS; }

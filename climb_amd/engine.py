@@ -2,11 +2,14 @@
 sequences the C-ABI HIP launchers for the ViLT forward, backward and update.  PyTorch is used for device memory,
 streams and (elsewhere) torch.distributed only; every FLOP and every byte of the step goes through libclimb_hip.so.
 
-Two arithmetic modes share all of this code:
+Three arithmetic modes share all of this code:
   * "fp32": exact-fp32 matrix-core GEMMs (v_mfma_f32_32x32x2_f32) -- the parity mode (<= 1e-3 rel vs the CPU reference,
             argmax exact) of BASELINE.json's north_star
   * "bf16": bf16 MFMA operands, fp32 accumulation / statistics / residual stream / master weights -- the throughput mode
             (BASELINE.json configs[1])
+  * "bf16x3" (r06): the fp32 mode's data flow (fp32 activations, statistics, attention, exact GELU) with every encoder GEMM on SPLIT operands --
+            (hi, lo) bf16 plane pairs, three MFMA products per k-step (csrc/split.hip): inside the 1e-3 / argmax bar at a third of the 16-bit
+            MFMA rate instead of a sixteenth
 """
 from __future__ import annotations
 
@@ -19,7 +22,7 @@ import torch
 from . import _lib
 from .layout import ENC, FlatLayout, VILT_CFG, TASK_ARITH
 
-F32, BF16 = 0, 1
+F32, BF16, SPLIT = 0, 1, 2
 _FUSED_ADAPTER = os.environ.get("CLIMB_AMD_FUSED_ADAPTER", "1") != "0"       # measurement knob: 0 = the two skinny GEMMs
 # weight gradients of the encoder layers as grouped launches (csrc/gemm_bf16_tnp.hip: gemm_bf16_tn_grouped_kernel): layers per launch.
 # "0" = off (one split GEMM + reduce per weight, the r02 path); default: all layers in one launch, 4 per launch under a data-parallel hook
@@ -95,9 +98,14 @@ class Workspace:
         M = self.M
         adt = torch.float32 if eng.precision == "fp32" else eng.t16
         f32 = torch.float32
+        sp = eng.split
 
         def buf(shape, dt=f32):
             return torch.empty(shape, dtype=dt, device=dev)
+
+        def opbuf(rows, cols):
+            """a tensor that only GEMMs read: the operand dtype, or (split mode) a (hi, lo) pair of 16-bit planes [2][rows][cols]"""
+            return buf((2, rows, cols), eng.t16) if sp else buf((rows, cols), adt)
         self.key_bias = buf((B, self.S_pad))
         self.img_type = torch.empty((B,), dtype=torch.int32, device=dev)
         self.dims = torch.empty((B, 2), dtype=torch.int32, device=dev)     # valid patch extent per sample (variable resolution)
@@ -106,12 +114,18 @@ class Workspace:
         self.proj = buf((B * self.NP, H))
         self.x = [buf((M, H)) for _ in range(L + 1)]          # residual stream at every layer boundary (fp32)
         self.h1 = [buf((M, H)) for _ in range(L)]
-        self.xn = [buf((M, H), adt) for _ in range(L)]
-        self.hn = [buf((M, H), adt) for _ in range(L)]
+        self.xn = [opbuf(M, H) for _ in range(L)]
+        self.hn = [opbuf(M, H) for _ in range(L)]
         self.qkv = [buf((M, 3 * H), adt) for _ in range(L)]
         self.ctx = [buf((M, H), adt) for _ in range(L)]
         self.u = [buf((M, Fd), adt) for _ in range(L)]
-        self.a = [buf((M, Fd), adt) for _ in range(L)]
+        self.a = [opbuf(M, Fd) for _ in range(L)]
+        if sp:      # split twins of the fp32 tensors that something besides a GEMM reads too (attention output / gradient, im2col, d(projection))
+            self.a_patch_s = opbuf(B * self.NP, cfg["channels"] * cfg["patch"] ** 2)
+            self.ctx_s = [opbuf(M, H) for _ in range(L)]
+            self.dqkv_s = opbuf(M, 3 * H)
+            self.dproj_s = opbuf(B * self.NP, H)
+            self.du_f = buf((M, Fd))          # d(gelu output) before x gelu'(u) (the input-gradient GEMM's fp32 result)
         self.mean1 = [buf((M,)) for _ in range(L)]
         self.rstd1 = [buf((M,)) for _ in range(L)]
         self.mean2 = [buf((M,)) for _ in range(L)]
@@ -126,8 +140,8 @@ class Workspace:
         self.dyc, self.duc, self.dhnc, self.dhcc = buf((B, H), adt), buf((B, Fd), adt), buf((B, H), adt), buf((B, H), adt)
         # backward scratch (shared by all layers)
         self.dres = buf((M, H))
-        self.dres_c = self.dres if eng.precision == "fp32" else buf((M, H), adt)
-        self.du = buf((M, Fd), adt)
+        self.dres_c = opbuf(M, H) if sp else (self.dres if eng.precision == "fp32" else buf((M, H), adt))
+        self.du = opbuf(M, Fd)
         self.dhn = buf((M, H), adt)
         self.dctx = buf((M, H), adt)
         self.dqkv = buf((M, 3 * H), adt)
@@ -170,10 +184,11 @@ class Workspace:
             return
         cfg, dev, t16 = eng.cfg, eng.device, eng.t16
         H, Fd, L, M = cfg["hidden"], cfg["ffn"], cfg["layers"], self.M
-        self.dx_c = [torch.empty((M, H), dtype=t16, device=dev) for _ in range(L + 1)]
-        self.dh_c = [torch.empty((M, H), dtype=t16, device=dev) for _ in range(L)]
-        self.du_l = [torch.empty((M, Fd), dtype=t16, device=dev) for _ in range(L)]
-        self.dqkv_l = [torch.empty((M, 3 * H), dtype=t16, device=dev) for _ in range(L)]
+        pl = (2,) if eng.split else ()          # split mode: (hi, lo) plane pairs
+        self.dx_c = [torch.empty(pl + (M, H), dtype=t16, device=dev) for _ in range(L + 1)]
+        self.dh_c = [torch.empty(pl + (M, H), dtype=t16, device=dev) for _ in range(L)]
+        self.du_l = [torch.empty(pl + (M, Fd), dtype=t16, device=dev) for _ in range(L)]
+        self.dqkv_l = [torch.empty(pl + (M, 3 * H), dtype=t16, device=dev) for _ in range(L)]
         self.dz_l = [torch.empty((M, self.r), dtype=t16, device=dev) for _ in range(2 * L)] if self.has_adapters else None      # adapters: d(bottleneck) per site
         # ... and of the LayerNorm backwards' {dgamma, dbeta, bias} partial column sums: reduced by ONE launch per group instead of one per LayerNorm
         lnb = _lib.query("climb_layernorm_bwd_rows_per_block")
@@ -188,15 +203,17 @@ class HeadState:
 class ViltEngine:
     def __init__(self, layout: FlatLayout, device: torch.device, precision: str = "bf16", task_cfgs: Optional[Dict[str, dict]] = None):
         # "fp16": the throughput ("bf16") code path on the IEEE-half build of the library, with a scaled loss gradient
-        assert precision in ("fp32", "bf16", "fp16")
-        self.h16 = None if precision == "fp32" else precision
+        # "bf16x3" (r06): the fp32 code path with every encoder GEMM on split (hi, lo) bf16 operands, three MFMA products per k-step (csrc/split.hip)
+        assert precision in ("fp32", "bf16", "fp16", "bf16x3")
+        self.split = precision == "bf16x3"
+        self.h16 = None if precision == "fp32" else ("bf16" if self.split else precision)
         if self.h16 is not None:
             _lib.select_h16(self.h16)
             if _lib.h16() != self.h16:
                 raise RuntimeError(f"engine precision {precision}: the loaded HIP library computes in {_lib.h16()}")
             self.t16 = _lib.torch_h16()
         self.precision_name = precision
-        precision = "fp32" if precision == "fp32" else "bf16"      # the two code paths; `h16` says which 16-bit type the second one runs on
+        precision = "fp32" if precision in ("fp32", "bf16x3") else "bf16"      # the two code paths; `h16` says which 16-bit type the second one runs on
         # the GELU pair's epilogue codes (GELU_SAVE above): ws.u holds gelu'(pre-activation) under "deriv", the pre-activation otherwise
         deriv = precision == "bf16" and GELU_SAVE == "deriv"
         self.epi_gelu, self.epi_dgelu = (EPI_GELUD, EPI_MUL) if deriv else (EPI_GELU, EPI_DGELU)
@@ -245,7 +262,7 @@ class ViltEngine:
         # `pooler_output` alone), so after the last layer's attention only the B [CLS] rows go through the out-projection / MLP / final
         # LayerNorm, forward and backward.  Same loss, same gradients (tests/test_gpu_parity.py compares the two steps); off by default so that
         # the default step executes every FLOP of the reference's (bench.py times both).
-        self.cls_only_last = os.environ.get("CLIMB_AMD_CLS_ONLY_LAST", "0") != "0"
+        self.cls_only_last = os.environ.get("CLIMB_AMD_CLS_ONLY_LAST", "0") != "0" and not self.split      # (the opt-in row pruning has no split path)
 
     # ------------------------------------------------------------------ buffers
     def allocate(self):
@@ -255,7 +272,7 @@ class ViltEngine:
         _lib.load()
         self.flat = torch.zeros(self.layout.total, dtype=torch.float32, device=self.device)
         self.grad = torch.zeros(self.layout.total, dtype=torch.float32, device=self.device)
-        if self.precision == "bf16":
+        if self.precision == "bf16" or self.split:
             tn_workspace(self.device)
         self._ws.clear()
         self._shadow = None
@@ -317,8 +334,14 @@ class ViltEngine:
             self.apply_parked_ewc()
         held, self._dw_deferred = self._dw_deferred, []
         for ws, plan in held:
-            self._timed_call("gemm_bf16_tn", plan["flops"], "climb_gemm_bf16_tn_grouped", plan["probs"], plan["items"], plan["first"], plan["nwg"], plan["ragged"], _stream())
+            self._launch_dw_plan(plan)
             self._grad_extra = True
+
+    def _launch_dw_plan(self, plan):
+        if plan.get("split"):
+            self._timed_call("gemm_split_tn", plan["flops"], "climb_gemm_split_tn_grouped", plan["probs"], plan["items"], plan["first"], plan["nwg"], _stream())
+        else:
+            self._timed_call("gemm_bf16_tn", plan["flops"], "climb_gemm_bf16_tn_grouped", plan["probs"], plan["items"], plan["first"], plan["nwg"], plan["ragged"], _stream())
 
     def begin_scaled_backward(self, max_dlogit: float):
         """fp16 operands only.  Picks the power-of-two loss scale that puts the largest possible |d(logits)| near 1 (the BCE gradient of a
@@ -383,15 +406,31 @@ class ViltEngine:
         self._timed_call("skinny_f32", 2.0 * M * N * K, "climb_skinny_f32", A, lda, B, sbn, sbk, C, ldc, M, N, K, bias, epi, aux, ldaux, colsum, 1.0,
                          acol, 1.0, _stream())
 
+    # ---- split operands (r06): X / dY are (hi, lo) plane pairs [2][M][.], weights come from the split shadows, results are fp32
+    def _split_nt(self, X, ldx, x_lo, Wp, ldw, w_lo, Y, ldy, M, N, K, bias, epi, aux, ldaux):
+        self._timed_call("gemm_split_nt", 2.0 * M * N * K, "climb_gemm_split_nt", X, ldx, x_lo, Wp, ldw, w_lo, Y, ldy, M, N, K, bias, epi, aux, ldaux, _stream())
+
+    def split_of(self, src, dst, M, C, mode=0, aux=None):
+        """dst (split [2][M][C]) = f(src fp32 [M, C]): 0 copy, 1 gelu, 2 src * gelu'(aux)"""
+        _lib.call("climb_split_f32", src, C, dst, C, M * C, M, C, mode, aux, C, _stream())
+
     def linear_fwd(self, X, wname, bname, Y, M, N, K, epi=EPI_NONE, aux=None, aux_out=None, aux2=None, out_f32=False):
-        if self.precision == "fp32":
+        if self.split:
+            if epi not in (EPI_NONE, EPI_RESID):
+                raise NotImplementedError("bf16x3: adapters / fused activation epilogues are not built for split operands")
+            self._split_nt(X, K, M * K, self.sp(wname), K, self.layout.total, Y, N, M, N, K, self.p(bname) if bname else None, epi, aux, N)
+        elif self.precision == "fp32":
             self._gemm_f32(X, K, 1, self.p(wname), K, 1, Y, N, M, N, K, self.p(bname) if bname else None, epi, aux, N, aux_out, N, 0.0, aux2, N)
         else:
             self._bf16_fwd(X, wname, bname, Y, M, N, K, epi, aux, aux_out, out_f32=out_f32, aux2=aux2)
 
     def linear_dx(self, dY, wname, dX, M, N, K, epi=EPI_NONE, aux=None):
         """dX[M,K] = dY[M,N] @ W[N,K]   (epi DGELU multiplies by gelu'(aux[M,K]))"""
-        if self.precision == "fp32":
+        if self.split:
+            if epi not in (EPI_NONE, EPI_RESID):
+                raise NotImplementedError("bf16x3: adapters / fused activation epilogues are not built for split operands")
+            self._split_nt(dY, N, M * N, self.spt(wname), N, self._shadow_t.numel() // 2, dX, K, M, K, N, None, epi, aux, K)
+        elif self.precision == "fp32":
             self._gemm_f32(dY, N, 1, self.p(wname), 1, K, dX, K, M, K, N, None, epi, aux, K)
         else:
             self._bf16_dx(dY, wname, dX, M, N, K, epi, aux)
@@ -403,7 +442,10 @@ class ViltEngine:
             if want_b:
                 self.bias_grad(dY, self.adt, bname, M, N, ws)
             return
-        if self.precision == "fp32":
+        if self.split:          # (shapes the grouped launch does not take: three ordinary weight-gradient launches; the bias gradient rides in two of them)
+            self._timed_call("gemm_split_tn", 2.0 * M * N * K, "climb_gemm_split_tn", dY, N, M * N, X, K, M * K, self.g(wname), K, M, N, K,
+                             self.g(bname) if want_b else None, _stream())
+        elif self.precision == "fp32":
             if want_b:
                 self.bias_grad(dY, F32, bname, M, N, ws)
             self._gemm_f32(dY, 1, N, X, 1, K, self.g(wname), K, N, K, M, beta=1.0)
@@ -479,6 +521,11 @@ class ViltEngine:
         if not self.requires_grad[bname]:
             return
         csr = _lib.query("climb_colsum_rows_per_block")
+        if self.split and dY.dim() == 3:          # a split operand: the column sums of its hi plane + those of its lo plane
+            for plane in (dY[0], dY[1]):
+                _lib.call("climb_colsum", plane, C, BF16, None, 0, ws.part, M, C, _stream())
+                _lib.call("climb_colreduce", ws.part, C, (M + csr - 1) // csr, self.g(bname), C, 1.0, _stream())
+            return
         _lib.call("climb_colsum", dY, C, dtype, None, 0, ws.part, M, C, _stream())
         _lib.call("climb_colreduce", ws.part, C, (M + csr - 1) // csr, self.g(bname), C, 1.0, _stream())
 
@@ -500,21 +547,22 @@ class ViltEngine:
     def _build_shadow(self):
         import numpy as np
         dev = self.device
-        self._shadow = torch.empty(self.layout.total, dtype=self.t16, device=dev)
+        npl = 2 if self.split else 1          # split mode: [2][total] -- the hi plane, then the lo plane
+        self._shadow = torch.empty(npl * self.layout.total, dtype=self.t16, device=dev)
         rows, off = [], 0
         self._t_off = {}
         for name, N, K in self._linear_weight_names():
             self._t_off[name] = off
             rows.append((self.layout.offset[name], off, N, K))
             off += N * K
-        self._shadow_t = torch.empty(off, dtype=self.t16, device=dev)
+        self._shadow_t = torch.empty(npl * off, dtype=self.t16, device=dev)
         self._t_table = torch.from_numpy(np.array(rows, dtype=np.int64)).to(dev)
         self._t_n = len(rows)
 
     def refresh_shadow(self, cast: bool = True):
         """bf16 copies of the weights for the MFMA operands: refreshed when the fp32 master changed (torch in-place ops
         bump the version counter; our fused AdamW refreshes the straight shadow itself and calls params_updated)."""
-        if self.precision != "bf16":
+        if self.precision != "bf16" and not self.split:
             return
         if self._shadow is None:
             self._build_shadow()
@@ -524,6 +572,15 @@ class ViltEngine:
             return
         st = _stream()
         table, tn = self._t_table, self._t_n
+        if self.split:          # both planes of the straight shadow in one pass over the master weights, then the two planes' transposes
+            tot, tt = self.layout.total, self._shadow_t.numel() // 2
+            _lib.call("climb_split_f32", self.flat, tot, self._shadow, tot, tot, 1, tot, 0, None, 0, st)
+            _lib.call("climb_transpose_bf16_batched", self._shadow, self._shadow_t, table, tn, 96, st)
+            _lib.call("climb_transpose_bf16_batched", self._shadow[tot:], self._shadow_t[tt:], table, tn, 96, st)
+            self._t_fresh = None
+            self._shadow_version = ver
+            self._shadow_stale = False
+            return
         if self._shadow_stale != "transpose-only":
             _lib.call("climb_cast_bf16", self.flat, self._shadow, self.layout.total, st)
         elif self._t_fresh:
@@ -543,7 +600,7 @@ class ViltEngine:
 
     def shadow_ptr(self):
         """bf16 weight shadow the fused AdamW refreshes in the same pass (None in fp32 mode)."""
-        if self.precision != "bf16":
+        if self.precision != "bf16":          # (split mode: the optimizer leaves the planes to refresh_shadow())
             return None
         if self._shadow is None:
             self.refresh_shadow()          # first use: full cast, so tensors the optimiser skips have valid shadows too
@@ -572,6 +629,8 @@ class ViltEngine:
             e1.record()
             # (bench.py's per-kind table) an NT GEMM launch is named by its output width, reduction depth, epilogue and output type
             kind = f"N{args[8]}_K{args[9]}_epi{args[11]}_{'f32' if args[6] == F32 else 'h16'}" if name == "climb_gemm_bf16_nt" else name
+            if name == "climb_gemm_split_nt":
+                kind = f"N{args[9]}_K{args[10]}_epi{args[12]}_split"
             prof["events"].append((e0, e1, flops, kind))
         else:
             _lib.call(name, *args)
@@ -591,6 +650,11 @@ class ViltEngine:
     @property
     def adt(self):
         return F32 if self.precision == "fp32" else BF16
+
+    @property
+    def odt(self):
+        """dtype code of a tensor that only GEMMs read (LayerNorm outputs, the LayerNorm backward's cast)"""
+        return SPLIT if self.split else self.adt
 
     # ------------------------------------------------------------------ encoder forward
     def encoder_forward(self, input_ids, token_type_ids, attention_mask, pixel_values, img_type: torch.Tensor, save: bool = True,
@@ -649,7 +713,11 @@ class ViltEngine:
         if var:
             _lib.call("climb_patch_grid_dims", pixel_mask, B, Hc, Wc, P_, ws.dims, st)
         Kp = cfg["channels"] * cfg["patch"] ** 2
-        self.linear_fwd_f32out(ws.a_patch, e + "patch_embeddings.projection.weight", e + "patch_embeddings.projection.bias", ws.proj,
+        a_patch = ws.a_patch
+        if self.split:
+            self.split_of(ws.a_patch, ws.a_patch_s, B * ws.NP, Kp)
+            a_patch = ws.a_patch_s
+        self.linear_fwd_f32out(a_patch, e + "patch_embeddings.projection.weight", e + "patch_embeddings.projection.bias", ws.proj,
                                B * ws.NP, H, Kp)
         _lib.call("climb_assemble_image", ws.proj, self.p(e + "cls_token"), self.p(e + "position_embeddings"),
                   self.p(e + "token_type_embeddings.weight"), ws.img_type, ws.dims if var else None, x0, ws.key_bias, B, T, ws.NP, gw, g0,
@@ -658,11 +726,14 @@ class ViltEngine:
         ad = self.active_adapter
         r = self.layout.adapters[ad] if ad is not None else 0
         prune = self.cls_only_last and ad is None
+        odt = self.odt
+        if self.split and ad is not None:
+            raise NotImplementedError("bf16x3: adapters are not built for split operands")
         for i in range(cfg["layers"]):
             l = f"{ENC}encoder.layer.{i}."
             x = ws.x[i]
             _lib.call("climb_layernorm_fwd", x, H, self.p(l + "layernorm_before.weight"), self.p(l + "layernorm_before.bias"), cfg["ln_eps"],
-                      ws.xn[i], H, adt, ws.mean1[i], ws.rstd1[i], M, H, st)
+                      ws.xn[i], H, odt, ws.mean1[i], ws.rstd1[i], M, H, st)
             # fused QKV projection: q/k/v weights are adjacent in the flat buffer (HF:325-327 as one [2304,768] GEMM)
             self.linear_fwd(ws.xn[i], l + "attention.attention.query.weight", l + "attention.attention.query.bias", ws.qkv[i], M, 3 * H, H)
             self.attn_fwd(ws.qkv[i], ws.key_bias, ws.ctx[i], ws.lse[i], B, ws.S_pad)
@@ -677,15 +748,22 @@ class ViltEngine:
                                  None, 0, ws.uc, Fd)
                 self._lin_fwd_ld(ws.ac, Fd, l + "output.dense.weight", l + "output.dense.bias", ws.xLc, H, B, H, Fd, EPI_RESID, ws.h1c, H, out_f32=True)
                 continue
-            if ad is None:
+            if self.split:          # the attention output as a GEMM operand (its fp32 form stays: the backward's softmax row term reads it)
+                self.split_of(ws.ctx[i], ws.ctx_s[i], M, H)
+                self.linear_fwd_resid(ws.ctx_s[i], l + "attention.output.dense.weight", l + "attention.output.dense.bias", ws.h1[i], M, H, H, x)
+            elif ad is None:
                 self.linear_fwd_resid(ws.ctx[i], l + "attention.output.dense.weight", l + "attention.output.dense.bias", ws.h1[i], M, H, H, x)
             else:   # h1 = x + y + up(silu(down(y))),  y = Wo ctx + bo
                 a_ = f"{l}attention.output.adapters.{ad}."
                 self.linear_fwd(ws.ctx[i], l + "attention.output.dense.weight", l + "attention.output.dense.bias", ws.ya[i], M, H, H)
                 self.adapter_fwd(a_, ws.ya[i], x, ws.za[i], ws.sa[i], ws.h1[i], M, H, r)
             _lib.call("climb_layernorm_fwd", ws.h1[i], H, self.p(l + "layernorm_after.weight"), self.p(l + "layernorm_after.bias"), cfg["ln_eps"],
-                      ws.hn[i], H, adt, ws.mean2[i], ws.rstd2[i], M, H, st)
-            self.linear_fwd(ws.hn[i], l + "intermediate.dense.weight", l + "intermediate.dense.bias", ws.a[i], M, Fd, H, self.epi_gelu, None, ws.u[i])
+                      ws.hn[i], H, odt, ws.mean2[i], ws.rstd2[i], M, H, st)
+            if self.split:          # u = W1 hn + b1 in fp32 (the backward evaluates gelu' on it), a = gelu(u) as the down-projection's operand
+                self.linear_fwd(ws.hn[i], l + "intermediate.dense.weight", l + "intermediate.dense.bias", ws.u[i], M, Fd, H)
+                self.split_of(ws.u[i], ws.a[i], M, Fd, mode=1)
+            else:
+                self.linear_fwd(ws.hn[i], l + "intermediate.dense.weight", l + "intermediate.dense.bias", ws.a[i], M, Fd, H, self.epi_gelu, None, ws.u[i])
             if ad is None:
                 self.linear_fwd_resid(ws.a[i], l + "output.dense.weight", l + "output.dense.bias", ws.x[i + 1], M, H, Fd, ws.h1[i])
             else:
@@ -716,13 +794,13 @@ class ViltEngine:
         return ws.pooled
 
     def linear_fwd_f32out(self, X, wname, bname, Y, M, N, K):
-        if self.precision == "fp32":
+        if self.precision == "fp32":          # (and split: linear_fwd dispatches)
             self.linear_fwd(X, wname, bname, Y, M, N, K)
         else:
             self._bf16_fwd(X, wname, bname, Y, M, N, K, EPI_NONE, None, None, out_f32=True)
 
     def linear_fwd_resid(self, X, wname, bname, Y, M, N, K, resid):
-        if self.precision == "fp32":
+        if self.precision == "fp32":          # (and split)
             self.linear_fwd(X, wname, bname, Y, M, N, K, EPI_RESID, resid)
         else:
             self._bf16_fwd(X, wname, bname, Y, M, N, K, EPI_RESID, resid, None, out_f32=True)
@@ -746,7 +824,7 @@ class ViltEngine:
     # ------------------------------------------------------------------ deferred, grouped weight gradients
     def _dw_group_size(self, ws: Workspace, ad) -> int:
         """Layers per grouped weight-gradient launch for this backward; 0 = the immediate per-GEMM path."""
-        if self.precision != "bf16" or (ws.M % 128) or self.overlap_dw:
+        if (self.precision != "bf16" and not self.split) or (ws.M % 128) or self.overlap_dw:
             return 0
         if ad is not None:
             # under an active adapter the base is normally frozen (train_adapter); the backward then keeps one d(y) scratch for all layers,
@@ -810,6 +888,14 @@ class ViltEngine:
         if not pending:
             return
         import numpy as np
+        sp = self.split
+        if sp and any((N % 256) or (K % 256) for _, _, _, _, M, N, K in pending):          # the split launch takes whole tiles only: run those now
+            odd = [p for p in pending if (p[5] % 256) or (p[6] % 256)]
+            pending[:] = [p for p in pending if not ((p[5] % 256) or (p[6] % 256))]
+            for dY, X, w, b, M, N, K in odd:
+                self.linear_dw(dY, X, w, M, N, K, b, ws)
+            if not pending:
+                return
         key = (self._cu_reserve,) + tuple((w, b, dY.data_ptr(), X.data_ptr()) for dY, X, w, b, M, N, K in pending)
         plan = ws.dw_plans.get(key)
         if plan is None:
@@ -820,6 +906,8 @@ class ViltEngine:
             for r, (dY, X, w, b, M, N, K) in zip(rec, pending):
                 r["A"], r["B"], r["C"], r["dbias"] = dY.data_ptr(), X.data_ptr(), self.g(w), (self.g(b) if b is not None else 0)
                 r["lda"], r["ldb"], r["ldc"], r["M"], r["N"], r["K"] = N, K, K, M, N, K
+                if sp:          # three phases over the (hi, lo) planes stacked along the tokens (csrc/gemm_bf16_tnp.hip, SPLIT)
+                    r["M"], r["reserved"] = 3 * M, M // 64
             Ms, Ns, Ks = (np.ascontiguousarray(rec[f], dtype=np.int32) for f in ("M", "N", "K"))
             cap = int(sum(((n + 255) // 256) * ((k + 255) // 256) for n, k in zip(Ns, Ks))) + 2 * nwg + 1
             items = np.zeros((cap, 8), dtype=np.int32)
@@ -834,14 +922,14 @@ class ViltEngine:
                         keep=[(dY, X) for dY, X, *_ in pending],
                         names=[w for _, _, w, *_ in pending], shapes=[(N, K) for _, _, _, _, M, N, K in pending],
                         # problems ALL of whose tiles are whole tiles (no stream-K share): the ones the optimizer may be fused into
-                        whole=[bool(i not in set(int(x) for x in items[:n_items][items[:n_items, 5] == 1, 0])) for i in range(len(pending))], opts={})
+                        whole=[bool(i not in set(int(x) for x in items[:n_items][items[:n_items, 5] == 1, 0])) for i in range(len(pending))], opts={}, split=sp)
             if len(ws.dw_plans) >= 16:           # requires_grad patterns / group sizes seen on this shape: bounded
                 ws.dw_plans.pop(next(iter(ws.dw_plans)))
             ws.dw_plans[key] = plan
-        if self.defer_dw and self.grad_ready_hook is None and self.loss_scale == 1.0 and not plan["ragged"]:
+        if self.defer_dw and self.grad_ready_hook is None and self.loss_scale == 1.0 and not plan["ragged"] and not sp:
             self._dw_deferred.append((ws, plan))          # FusedAdamW.step() (or materialize_dw()) launches it
         else:
-            self._timed_call("gemm_bf16_tn", plan["flops"], "climb_gemm_bf16_tn_grouped", plan["probs"], plan["items"], plan["first"], plan["nwg"], plan["ragged"], _stream())
+            self._launch_dw_plan(plan)
             self._grad_extra = True
         pending.clear()
 
@@ -1010,12 +1098,16 @@ class ViltEngine:
         dxc = (lambda i: ws.dx_c[i]) if G else (lambda i: ws.dres_c)          # 16-bit d(x_i) / d(h1_i) / d(u_i) / d(qkv_i): per layer when deferred
         dhc = (lambda i: ws.dh_c[i]) if G else (lambda i: ws.dres_c)
         du_ = (lambda i: ws.du_l[i]) if G else (lambda i: ws.du)
-        dqkv_ = (lambda i: ws.dqkv_l[i]) if G else (lambda i: ws.dqkv)
+        dqkv_ = (lambda i: ws.dqkv_l[i]) if G else (lambda i: ws.dqkv_s if self.split else ws.dqkv)
+        odt = self.odt
+        no_cast = self.precision == "fp32" and not self.split          # the plain fp32 mode's GEMMs read the fp32 residual-gradient stream itself
         dw = (lambda *a, **k: self._dw_defer(pending, *a, **k)) if G else self.dw_async
         nL = cfg["layers"]
         if prune:       # d(x_L) is non-zero on the [CLS] rows alone: their 16-bit copy is a compact [B, H] operand
             if self.precision != "fp32":
                 ws.dyc.copy_(ws.dres.view(B, ws.S_pad, H)[:, 0])
+        elif self.split:                    # d(x_L) as a GEMM operand
+            self.split_of(ws.dres, dxc(nL), M, H)
         elif self.precision != "fp32":      # the GEMMs' 16-bit copy of d(x_L): zeros, and the B rows that are not
             dxc(nL).zero_()
             dxc(nL).view(B, ws.S_pad, H)[:, 0].copy_(ws.dres.view(B, ws.S_pad, H)[:, 0])
@@ -1033,32 +1125,40 @@ class ViltEngine:
                                                dxc(i + 1), ws.dz_l[2 * i + 1] if G else ws.dz, dw)
                     dw(dy, ws.a[i], l + "output.dense.weight", M, H, Fd, l + "output.dense.bias", ws)
                 du = du_(i)
-                self.linear_dx(dy, l + "output.dense.weight", du, M, H, Fd, self.epi_dgelu, ws.u[i])
+                if self.split:          # d(gelu output) in fp32, then x gelu'(u) (exact erf form, like the fp32 mode) into the operand planes
+                    self.linear_dx(dy, l + "output.dense.weight", ws.du_f, M, H, Fd)
+                    self.split_of(ws.du_f, du, M, Fd, mode=2, aux=ws.u[i])
+                else:
+                    self.linear_dx(dy, l + "output.dense.weight", du, M, H, Fd, self.epi_dgelu, ws.u[i])
                 dw(du, ws.hn[i], l + "intermediate.dense.weight", M, Fd, H, l + "intermediate.dense.bias", ws)
                 self.linear_dx(du, l + "intermediate.dense.weight", ws.dhn, M, Fd, H)
                 self.join_side()          # LN backward overwrites d(residual) that dW2 is reading
-                _lib.call("climb_layernorm_bwd", ws.dhn, H, adt, ws.h1[i], H, ws.mean2[i], ws.rstd2[i], self.p(l + "layernorm_after.weight"),
-                          ws.dres, H, ws.dres, H, None if self.precision == "fp32" else dhc(i), H, lnpart(2 * i + 1), M, H, st)
+                _lib.call("climb_layernorm_bwd", ws.dhn, H, odt, ws.h1[i], H, ws.mean2[i], ws.rstd2[i], self.p(l + "layernorm_after.weight"),
+                          ws.dres, H, ws.dres, H, None if no_cast else dhc(i), H, lnpart(2 * i + 1), M, H, st)
                 red3(lnpart(2 * i + 1), l + "layernorm_after.weight", l + "layernorm_after.bias", l + "attention.output.dense.bias" if ad is None else None)
                 # attention: h1 = x + Wo ctx + bo
                 if ad is None:
                     dy = dhc(i)
-                    dw(dy, ws.ctx[i], l + "attention.output.dense.weight", M, H, H)
+                    dw(dy, ws.ctx_s[i] if self.split else ws.ctx[i], l + "attention.output.dense.weight", M, H, H)
                 else:
                     dy = self.adapter_backward(ws, f"{l}attention.output.adapters.{ad}.", ws.sa[i], ws.za[i], ws.ya[i], M, H, r,
                                                dhc(i), ws.dz_l[2 * i] if G else ws.dz, dw)
                     dw(dy, ws.ctx[i], l + "attention.output.dense.weight", M, H, H, l + "attention.output.dense.bias", ws)
                 self.linear_dx(dy, l + "attention.output.dense.weight", ws.dctx, M, H, H)
             dqkv = dqkv_(i)
-            self.attn_bwd(ws.qkv[i], ws.key_bias, ws.dctx, ws.ctx[i], ws.lse[i], ws.delta, dqkv, B, ws.S_pad)
+            if self.split:          # fp32 attention backward, then its result as the operand of the two QKV gradient GEMMs
+                self.attn_bwd(ws.qkv[i], ws.key_bias, ws.dctx, ws.ctx[i], ws.lse[i], ws.delta, ws.dqkv, B, ws.S_pad)
+                self.split_of(ws.dqkv, dqkv, M, 3 * H)
+            else:
+                self.attn_bwd(ws.qkv[i], ws.key_bias, ws.dctx, ws.ctx[i], ws.lse[i], ws.delta, dqkv, B, ws.S_pad)
             # q/k/v weights and biases are adjacent: one [2304,768] weight-gradient GEMM + one [2304] bias reduction
             dw(dqkv, ws.xn[i], l + "attention.attention.query.weight", M, 3 * H, H, l + "attention.attention.query.bias", ws)
             need_dx = i > first_layer or embeddings
             if need_dx:
                 self.linear_dx(dqkv, l + "attention.attention.query.weight", ws.dxn, M, 3 * H, H)
                 self.join_side()      # LN backward overwrites d(residual) (read by dWo); next layer overwrites du / dqkv
-                _lib.call("climb_layernorm_bwd", ws.dxn, H, adt, ws.x[i], H, ws.mean1[i], ws.rstd1[i], self.p(l + "layernorm_before.weight"),
-                          ws.dres, H, ws.dres, H, None if self.precision == "fp32" else dxc(i), H, lnpart(2 * i), M, H, st)
+                _lib.call("climb_layernorm_bwd", ws.dxn, H, odt, ws.x[i], H, ws.mean1[i], ws.rstd1[i], self.p(l + "layernorm_before.weight"),
+                          ws.dres, H, ws.dres, H, None if no_cast else dxc(i), H, lnpart(2 * i), M, H, st)
                 red3(lnpart(2 * i), l + "layernorm_before.weight", l + "layernorm_before.bias",
                      f"{ENC}encoder.layer.{i - 1}.output.dense.bias" if (i > first_layer and ad is None) else None)
             self.join_side()
@@ -1156,10 +1256,14 @@ class ViltEngine:
                   1 if ws.compact else 0, st)
         self.bias_grad_from_part(ws.part.data_ptr(), ntypes * H, ws.NP + 1, e + "token_type_embeddings.weight", ntypes * H)
         Kp = cfg["channels"] * cfg["patch"] ** 2
+        dproj, a_patch = ws.dproj, ws.a_patch
+        if self.split:
+            self.split_of(ws.dproj, ws.dproj_s, B * ws.NP, H)
+            dproj, a_patch = ws.dproj_s, ws.a_patch_s
         if pending is not None:
-            self._dw_defer(pending, ws.dproj, ws.a_patch, e + "patch_embeddings.projection.weight", B * ws.NP, H, Kp, e + "patch_embeddings.projection.bias", ws)
+            self._dw_defer(pending, dproj, a_patch, e + "patch_embeddings.projection.weight", B * ws.NP, H, Kp, e + "patch_embeddings.projection.bias", ws)
         else:
-            self.linear_dw(ws.dproj, ws.a_patch, e + "patch_embeddings.projection.weight", B * ws.NP, H, Kp, e + "patch_embeddings.projection.bias", ws)
+            self.linear_dw(dproj, a_patch, e + "patch_embeddings.projection.weight", B * ws.NP, H, Kp, e + "patch_embeddings.projection.bias", ws)
         te = e + "text_embeddings."
         ie = sv.get("inputs_embeds")
         _lib.call("climb_embed_text_bwd", sv["input_ids"] if ie is None else None, sv["token_type_ids"],

@@ -26,7 +26,7 @@ class ViltBertEncoderWrapper(ViltEncoderWrapper):
     def __init__(self, processor, vilt: ViltModelParams, bert: BertParams, device: torch.device, precision: Optional[str] = None):
         super().__init__(processor, vilt, device, precision)
         self.bert = bert
-        self.bert.precision = self.precision
+        self.bert.precision = "fp32" if self.precision == "bf16x3" else self.precision      # (the frozen BERT has no split path: exact fp32 under the split mode)
 
     def get_bert_outputs(self, **encodings) -> torch.Tensor:
         """REF:115-121: BERT's last hidden state, no gradient.  [B, roundup(T, 32), 768] fp32, first T rows of a sequence valid.

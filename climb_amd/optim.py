@@ -106,10 +106,10 @@ class FusedAdamW(torch.optim.Optimizer):
                     # is not carried in its epilogue this step (measured, tools/ewc_ab.py: the epilogue is exposed time -- two more operands there cost
                     # more than the separate pass they replace)
                     eng.materialize_dw(keep_parked_ewc=True)
+        idx = {n: i for i, n in enumerate(self._seg_names)}          # (also read below when nothing was deferred)
         if eng._dw_deferred:
             # r04: weight-gradient launches held back for this step (the fused training step armed engine.defer_dw): run them with the update in
             # their epilogue for the tensors of the most common (group, step) combination; the flat pass below skips what was updated there
-            idx = {n: i for i, n in enumerate(self._seg_names)}
             names = [n for _, plan in eng._dw_deferred for n, w in zip(plan["names"], plan["whole"]) if w]          # (a fused QKV problem is named by its query weight)
             slots = [int(seg_group[idx[n]]) for n in names]
             if shadow is not None and any(sl >= 0 for sl in slots):

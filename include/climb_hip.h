@@ -11,7 +11,7 @@
  *     never allocates, and is safe to capture into a hipGraph
  *   - return value: 0 = ok, >0 = hipError_t, <0 = library code (-1 invalid argument, -2 unsupported shape);
  *     climb_error_string() renders either.  Nothing throws across this boundary.
- *   - dtype codes: 0 = fp32, 1 = bf16 (raw 16-bit).  ld* = leading dimension in ELEMENTS.
+ *   - dtype codes: 0 = fp32, 1 = bf16 (raw 16-bit), 2 = split (a (hi, lo) pair of 16-bit planes, see "split-operand arithmetic").  ld* = leading dimension in ELEMENTS.
  *   - token layout: activations are [B, S_pad, H] row-major with S_pad = roundup(T + 1 + NP, 32);
  *     rows [0,T) text, T image [CLS], [T+1, T+1+NP) patches in raster order, the rest zero padding (masked as keys).
  */
@@ -215,6 +215,26 @@ int climb_gemm_bf16_tn_grouped_adamw_ewc(const void* probs, const void* items, c
  * computes delta itself (its first phase); `delta` [B,heads,S_pad] is scratch it writes */
 int climb_attn_fwd_bf16(const void* qkv, const float* key_bias, void* ctx, float* lse, int B, int S_pad, int heads, int head_dim, void* stream);
 int climb_attn_bwd_bf16(const void* qkv, const float* key_bias, const void* dctx, const void* ctx, const float* lse, float* delta, void* dqkv, int B, int S_pad, int heads, int head_dim, void* stream);
+
+/* ---- split-operand arithmetic (r06): the fast mode INSIDE north_star's tolerance ---------------------------------------------------------
+ * HF:325-327, :366-369, :397-414 (every nn.Linear of the layer, forward / input gradient / weight gradient) with each GEMM operand carried as a PAIR of
+ * 16-bit planes, x ~= hi + lo, hi = rn16(x), lo = rn16(x - hi), and each product as three MFMA passes hi.hi + hi.lo + lo.hi accumulated in fp32: with
+ * bf16 planes 16 significant bits per operand at fp32's range (the reference computes in fp32: REF/train/visionlanguage_tasks/train_vqa.py:135-174),
+ * at a third of the 16-bit MFMA rate instead of the sixteenth v_mfma_f32_32x32x2_f32 runs at.
+ * dtype code 2 = CLIMB_DT_SPLIT (accepted by climb_layernorm_fwd's y_dtype and climb_layernorm_bwd's dtype, where it means: dy fp32, dcast split): the
+ * pointer names the hi plane [rows, ld]; the lo plane lies rows * ld elements behind it (a split tensor is [2][rows][ld] 16-bit). */
+/* y (split, lo plane lo_off elements behind y) = f(x), x fp32 [M, C]: mode 0 f = x; 1 f = gelu(x) (erf form, HF:393); 2 f = x * gelu'(aux), aux fp32 [M, C].
+ * With M = 1 and C = n it splits a flat buffer (the weight shadow: lo_off = the buffer's length). */
+int climb_split_f32(const float* x, long ldx, void* y, long ldy, long lo_off, int M, int C, int mode, const float* aux, long ldaux, void* stream);
+/* C[M,N] (fp32) = epi(A B^T + bias); A = split [M,K] (lda, lo plane a_lo elements behind), B = split [N,K] (ldb, b_lo); epi 0 none, 2 + aux (fp32 [M,N]).
+ * K % 64 == 0.  Runs on the four-wave persistent kernel when the shape tiles into 192 x 192 (gemm_bf16_nt4.hip), on the 128 x 128 kernel otherwise. */
+int climb_gemm_split_nt(const void* A, long lda, long a_lo, const void* B, long ldb, long b_lo, float* C, long ldc, int M, int N, int K, const float* bias, int epi, const float* aux, long ldaux, void* stream);
+/* C[N,K] (fp32) += A^T B over M tokens; A = split [M,N], B = split [M,K]; dbias (optional) += column sums of A.  Three ordinary weight-gradient launches:
+ * the path of shapes climb_gemm_split_tn_grouped does not take. */
+int climb_gemm_split_tn(const void* A, long lda, long a_lo, const void* B, long ldb, long b_lo, float* C, long ldc, int M, int N, int K, float* dbias, void* stream);
+/* climb_gemm_bf16_tn_grouped over split operands: a problem's A / B name the hi planes of pairs whose lo plane DIRECTLY follows ([2 Mt, .]); its M field
+ * (and the M handed to climb_tn_grouped_plan) = 3 Mt, the three phases of the reduction, and its `reserved` field = Mt / 64.  N % 256 == K % 256 == 0. */
+int climb_gemm_split_tn_grouped(const void* probs, const void* items, const void* first, int nwg, void* stream);
 
 /* ---- image pre-processing on the device (replaces the host call REF/modeling/vilt.py:86-96 -> ViltProcessor ->
  * transformers image_processing_pil_vilt.py:127-242 -> Pillow Resample.c).  All images of a batch live in byte arenas; `table` holds

@@ -95,12 +95,17 @@ def test_state_dict_names_and_layout():
         assert torch.equal(p.detach().cpu(), P[n]), n
 
 
+# the two modes that promise north_star's bar: exact-fp32 MFMA, and (r06) split (hi, lo) bf16 operands with three MFMA products per k-step
+PARITY_MODES = ["fp32"] + (["bf16x3"] if os.environ.get("CLIMB_AMD_H16", "bf16") == "bf16" else [])
+
+
+@pytest.mark.parametrize("precision", PARITY_MODES)
 @pytest.mark.parametrize("fname", ["vqa_b2.npz", "vqa_b3_ragged.npz", "snlive_b2.npz"])
-def test_single_image_step_vs_oracle_and_golden(golden_dir, fname):
+def test_single_image_step_vs_oracle_and_golden(golden_dir, fname, precision):
     z = np.load(os.path.join(golden_dir, fname))
     m = _meta(z)
     tasks, B, task = m["tasks"].split(","), int(m["B"]), m["task"]
-    model, P = make_model(tasks, int(m["wseed"]))
+    model, P = make_model(tasks, int(m["wseed"]), precision=precision)
     enc = vo.synthetic_encodings(B, seed=int(m["dseed"]), ragged_text=bool(int(m["ragged"])))
     if task == "vqa":
         target = vo.synthetic_vqa_targets(B, seed=int(m["dseed"]))
@@ -153,7 +158,7 @@ def test_nlvr2_two_images(golden_dir):
     _close(heads, z["grad_heads"], TOL, "grad heads")
 
 
-@pytest.mark.parametrize("precision,tol", [("fp32", TOL), (H16, 3e-2)])
+@pytest.mark.parametrize("precision,tol", [(p_, TOL) for p_ in PARITY_MODES] + [(H16, 3e-2)])
 def test_nlvr2_two_variable_resolution_images_vs_reference(golden_dir, precision, tol):
     """NLVR2 as it arrives in practice (r03 fixture from the reference): two images per example, every image its own resolution and
     orientation on one padded canvas, ragged text.  The reference runs two encoder passes with their own patch counts
@@ -174,7 +179,7 @@ def test_nlvr2_two_variable_resolution_images_vs_reference(golden_dir, precision
     G = grads_of(model)
     names = [str(n) for n in z["grad_names"]]
     norms, heads = _summary(G, names)
-    if precision == "fp32":
+    if precision in PARITY_MODES:
         assert np.array_equal(logits.argmax(-1).cpu().numpy(), z["logits"].argmax(-1))
         _close(norms, z["grad_norms"], tol, "grad norms")
         _close(heads, z["grad_heads"], tol, "grad heads")
@@ -214,7 +219,7 @@ def test_tasks_at_their_real_input_shapes_vs_reference(golden_dir, fixture, prec
     G = grads_of(model)
     names = [str(n) for n in z["grad_names"]]
     norms, heads = _summary(G, names)
-    if precision == "fp32":
+    if precision in PARITY_MODES:
         assert np.array_equal(logits.argmax(-1).cpu().numpy(), z["logits"].argmax(-1))
         _close(norms, z["grad_norms"], tol, "grad norms")
         _close(heads, z["grad_heads"], tol, "grad heads")
@@ -344,13 +349,14 @@ def test_fisher_accumulating_quirk(golden_dir):
         assert torch.equal(ewc.param_dict["vqa"][k].cpu(), P["vilt_encoder." + k])
 
 
-def test_ten_steps_config1(golden_dir):
+@pytest.mark.parametrize("precision", PARITY_MODES)
+def test_ten_steps_config1(golden_dir, precision):
     """BASELINE.json configs[0] on the GPU path: 10 AdamW steps at B=2 with the reference's schedule."""
     from climb_amd.train import polynomial_decay_schedule_with_warmup
     z = np.load(os.path.join(golden_dir, "vqa_b2_10steps.npz"))
     m = _meta(z)
     B, steps = int(m["B"]), int(m["steps"])
-    model, P = make_model(m["tasks"].split(","), int(m["wseed"]))
+    model, P = make_model(m["tasks"].split(","), int(m["wseed"]), precision=precision)
     P0 = {n: t.clone() for n, t in P.items()}
     opt = model.create_optimizer({"lr": float(m["lr"]), "weight_decay": 1e-2, "adam_epsilon": 1e-8})
     sched = polynomial_decay_schedule_with_warmup(opt, int(steps * 0.1), steps, 0.0, 1.0)
@@ -360,7 +366,7 @@ def test_ten_steps_config1(golden_dir):
     for s in range(steps):
         enc = vo.synthetic_encodings(B, seed=100 + s)
         images, texts = enc_to_inputs(enc)
-        loss, _, _, _ = model.fused_forward_backward("vqa", images, texts, vo.synthetic_vqa_targets(B, seed=100 + s))
+        loss, _, _, _ = model.fused_forward_backward("vqa", images, texts, vo.synthetic_vqa_targets(B, seed=100 + s), optimizer=opt if precision != "fp32" else None)
         opt.step()
         sched.step()
         opt.zero_grad()
@@ -684,7 +690,7 @@ def test_viltbert_vs_reference(golden_dir, precision, tol):
     names = [str(n) for n in z["grad_names"]]
     assert set(G) == set(names), set(G) ^ set(names)       # no gradient for BERT, none for the bypassed word-embedding table
     norms, heads = _summary(G, names)
-    if precision == "fp32":
+    if precision in PARITY_MODES:
         assert np.array_equal(logits.argmax(-1).cpu().numpy(), z["logits"].argmax(-1))
         _close(norms, z["grad_norms"], tol, "grad norms vs reference")
         _close(heads, z["grad_heads"], tol, "grad heads vs reference")
@@ -755,7 +761,7 @@ def test_viltbert_train_mode_with_the_references_bert_dropout_masks(golden_dir, 
     names = [str(n) for n in z["grad_names"]]
     assert set(G) == set(names)
     norms, heads = _summary(G, names)
-    if precision == "fp32":
+    if precision in PARITY_MODES:
         assert np.array_equal(logits.argmax(-1).cpu().numpy(), z["logits"].argmax(-1))
         _close(norms, z["grad_norms"], tol, "grad norms vs reference")
         _close(heads, z["grad_heads"], tol, "grad heads vs reference")
@@ -825,13 +831,14 @@ def full_size_errors(z, precision):
 FULL_SIZE = ["vqa_b64.npz", "nlvr2_b32.npz", "vcr_b16.npz"]
 
 
+@pytest.mark.parametrize("precision", PARITY_MODES)
 @pytest.mark.parametrize("fname", FULL_SIZE)
-def test_full_size_fp32_vs_reference(golden_dir, fname):
+def test_full_size_fp32_vs_reference(golden_dir, fname, precision):
     """BASELINE.json configs[1] at ITS OWN size (64 sequences x (40 tokens + 384x384)) and the equal-sized NLVR2 (32 pairs) / VCR
     (16 x 4 choices) batches: the HIP path in the parity mode against what the reference's `*Trainer.train_step` computed
     (REF train_vqa.py:135-174).  These sizes select the 192x192 three-stage, 256x256 and one-round split kernels."""
-    e = full_size_errors(np.load(os.path.join(golden_dir, fname)), "fp32")
-    print(f"{fname} fp32 vs reference: {e}")
+    e = full_size_errors(np.load(os.path.join(golden_dir, fname)), precision)
+    print(f"{fname} {precision} vs reference: {e}")
     assert e["pooled"] <= TOL and e["logits"] <= TOL and e["loss"] <= TOL
     assert e["argmax_agreement"] == 1.0, "argmax task predictions must be bit-exact on every row"
     assert e["grad_norm_max"] <= TOL and e["grad_heads"] <= TOL
@@ -1200,7 +1207,7 @@ def test_last_layer_on_cls_rows_only_equals_every_row(precision, tol, B, frozen)
 
 # ------------------------------------------------------------------------------------------------ variable resolution (row F2)
 @pytest.mark.parametrize("fixture", ["vqa_b4_varres.npz", "vqa_b16_mixed.npz"])
-@pytest.mark.parametrize("precision,tol", [("fp32", TOL), (H16, BF16_TOL)])
+@pytest.mark.parametrize("precision,tol", [(p_, TOL) for p_ in PARITY_MODES] + [(H16, BF16_TOL)])
 def test_variable_resolution_batch_vs_reference(golden_dir, precision, tol, fixture):
     """Padded variable-resolution batch (HF:92-178 masked visual_embed with per-sample bilinear position resize): the HIP path keeps
     every canvas patch in raster order and masks the invalid ones; the reference shuffles and pads randomly.  Pooled output,
@@ -1224,7 +1231,7 @@ def test_variable_resolution_batch_vs_reference(golden_dir, precision, tol, fixt
     G = grads_of(model)
     names = [str(n) for n in z["grad_names"]]
     norms, heads = _summary(G, names)
-    if precision == "fp32":
+    if precision in PARITY_MODES:
         assert np.array_equal(logits.argmax(-1).cpu().numpy(), z["logits"].argmax(-1))
         _close(norms, z["grad_norms"], tol, "grad norms vs reference")
         _close(heads, z["grad_heads"], tol, "grad heads vs reference")

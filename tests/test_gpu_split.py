@@ -1,0 +1,202 @@
+"""Split-operand arithmetic (r06, csrc/split.hip): the passes that produce (hi, lo) 16-bit plane pairs and the three-phase GEMMs over them, each
+against float64 on the CPU.  Two bars per GEMM: against float64 of the SAME planes (what the kernel was given: only the fp32 accumulation differs,
+<= 1e-5), and against float64 of the ORIGINAL fp32 operands (what the mode promises: the lo.lo term and the planes' own rounding, <= 4e-5 of the
+output's scale -- 25x inside north_star's 1e-3)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from climb_amd import _lib
+    if _lib.h16() != "bf16":
+        pytest.skip("split operands are built on the bf16 library")
+    return torch.device("cuda:0")
+
+
+def _st():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def _planes(x):
+    """the oracle's split: hi = rn_bf16(x), lo = rn_bf16(x - hi)"""
+    hi = x.to(torch.bfloat16)
+    lo = (x - hi.float()).to(torch.bfloat16)
+    return hi, lo
+
+
+def _split_dev(x):
+    """[2][M][C] planes of an fp32 device matrix, through the library's own pass"""
+    from climb_amd import _lib
+    M, C = x.shape
+    out = torch.empty((2, M, C), dtype=torch.bfloat16, device=x.device)
+    _lib.call("climb_split_f32", x, C, out, C, M * C, M, C, 0, None, 0, _st())
+    return out
+
+
+def gelu(x):
+    return 0.5 * x * (1.0 + torch.erf(x / math.sqrt(2.0)))
+
+
+def dgelu(x):
+    return 0.5 * (1.0 + torch.erf(x / math.sqrt(2.0))) + x * torch.exp(-0.5 * x * x) / math.sqrt(2.0 * math.pi)
+
+
+@pytest.mark.parametrize("M,C", [(1, 4096), (37, 768), (200, 3072)])
+def test_split_pass_planes_and_activations(M, C):
+    from climb_amd import _lib
+    dev = _dev()
+    g = torch.Generator().manual_seed(M + C)
+    x = torch.randn(M, C, generator=g) * torch.logspace(-6, 3, C)[None, :]          # nine decades: the lo plane keeps bf16's range
+    v = torch.randn(M, C, generator=g)
+    u = torch.randn(M, C, generator=g) * 2.0
+    xd, vd, ud = x.to(dev), v.to(dev), u.to(dev)
+    out = _split_dev(xd)
+    hi, lo = _planes(x)
+    assert torch.equal(out[0].cpu(), hi) and torch.equal(out[1].cpu(), lo)          # bit-exact: two hardware round-to-nearest-even converts
+    rel = ((out[0].double() + out[1].double()).cpu() - x.double()).abs() / x.double().abs().clamp_min(1e-30)
+    assert float(rel.max()) < 2.0 ** -16                                            # element-wise: 16 significant bits
+    o1 = torch.empty_like(out)
+    _lib.call("climb_split_f32", ud, C, o1, C, M * C, M, C, 1, None, 0, _st())
+    assert _rel(o1[0].double() + o1[1].double(), gelu(u.double())) < 1e-5
+    o2 = torch.empty_like(out)
+    _lib.call("climb_split_f32", vd, C, o2, C, M * C, M, C, 2, ud, C, _st())
+    assert _rel(o2[0].double() + o2[1].double(), v.double() * dgelu(u.double())) < 1e-5
+
+
+@pytest.mark.parametrize("M,N,K,epi", [(1536, 192, 256, 0), (1536, 768, 768, 2), (3072, 2304, 768, 0), (12288, 768, 3072, 2), (12288, 3072, 768, 0),
+                                       (384, 768, 768, 2), (200, 2304, 768, 0), (77, 48, 128, 0), (384, 768, 3072, 2)])
+def test_gemm_split_nt(M, N, K, epi):
+    """forward / input-gradient GEMM on split operands: the four-wave persistent kernel where the shape tiles into 192 x 192 (the first five), the
+    128 x 128 kernel otherwise (ragged M, small N)"""
+    from climb_amd import _lib
+    dev = _dev()
+    g = torch.Generator(device=dev).manual_seed(M + 3 * N + K)
+    A = torch.randn(M, K, device=dev, generator=g)
+    W = torch.randn(N, K, device=dev, generator=g) * 0.05
+    bias = torch.randn(N, device=dev, generator=g)
+    res = torch.randn(M, N, device=dev, generator=g)
+    As, Ws = _split_dev(A), _split_dev(W)
+    C = torch.full((M, N), float("nan"), device=dev)
+    _lib.call("climb_gemm_split_nt", As, K, M * K, Ws, K, N * K, C, N, M, N, K, bias, epi, res if epi == 2 else None, N, _st())
+    torch.cuda.synchronize()
+    extra = bias.double().cpu() + (res.double().cpu() if epi == 2 else 0.0)
+    Ah, Al, Wh, Wl = (t.double().cpu() for t in (As[0], As[1], Ws[0], Ws[1]))
+    same_planes = Ah @ Wh.t() + Ah @ Wl.t() + Al @ Wh.t() + extra
+    assert _rel(C, same_planes) < 1e-5
+    exact = A.double().cpu() @ W.double().cpu().t() + extra
+    assert _rel(C, exact) < 4e-5
+    # the lo planes at an arbitrary distance (the weight shadow's planes are a whole parameter buffer apart)
+    far = torch.zeros(2 * N * K + 4096, dtype=torch.bfloat16, device=dev)
+    far[:N * K].copy_(Ws[0].reshape(-1))
+    far[N * K + 4096:].copy_(Ws[1].reshape(-1))
+    C2 = torch.empty_like(C)
+    _lib.call("climb_gemm_split_nt", As, K, M * K, far, K, N * K + 4096, C2, N, M, N, K, bias, epi, res if epi == 2 else None, N, _st())
+    assert torch.equal(C, C2)
+
+
+@pytest.mark.parametrize("M,N,K", [(384, 768, 768), (1000, 2304, 768), (320, 768, 3072), (2048, 256, 512)])
+def test_gemm_split_tn_three_launches(M, N, K):
+    from climb_amd import _lib
+    dev = _dev()
+    g = torch.Generator(device=dev).manual_seed(M + N)
+    dY = torch.randn(M, N, device=dev, generator=g)
+    X = torch.randn(M, K, device=dev, generator=g)
+    C0 = torch.randn(N, K, device=dev, generator=g)
+    b0 = torch.randn(N, device=dev, generator=g)
+    dYs, Xs = _split_dev(dY), _split_dev(X)
+    C, db = C0.clone(), b0.clone()
+    _lib.call("climb_gemm_split_tn", dYs, N, M * N, Xs, K, M * K, C, K, M, N, K, db, _st())
+    torch.cuda.synchronize()
+    exact = C0.double().cpu() + dY.double().cpu().t() @ X.double().cpu()
+    assert _rel(C, exact) < 4e-5
+    assert _rel(db, b0.double().cpu() + dY.double().cpu().sum(0)) < 2e-5
+
+
+@pytest.mark.parametrize("nwg", [256, 8, 24])
+def test_gemm_split_tn_grouped_launch(nwg):
+    """the grouped weight-gradient launch over split operands: three phases over the stacked planes, whole tiles and stream-K shares that cut
+    through phase boundaries, bias gradients = column sums of hi + lo (the repeated hi phase left out)"""
+    from climb_amd import _lib
+    dev = _dev()
+    shapes = [(2048, 768, 768, True), (2048, 256, 512, False), (1024, 512, 256, True), (3072, 256, 256, False), (1152, 768, 256, True)]
+    g = torch.Generator(device=dev).manual_seed(11 + nwg)
+    ops = []
+    for M, N, K, bias in shapes:
+        dY, X = torch.randn(M, N, device=dev, generator=g), torch.randn(M, K, device=dev, generator=g)
+        ops.append((dY, X, _split_dev(dY), _split_dev(X), torch.randn(N, K, device=dev, generator=g), torch.randn(N, device=dev, generator=g) if bias else None))
+    rec = np.zeros(len(shapes), dtype=[("A", "<u8"), ("B", "<u8"), ("C", "<u8"), ("dbias", "<u8"), ("lda", "<i8"), ("ldb", "<i8"), ("ldc", "<i8"),
+                                       ("M", "<i4"), ("N", "<i4"), ("K", "<i4"), ("reserved", "<i4")])
+    Cs = [o[4].clone() for o in ops]
+    dbs = [o[5].clone() if o[5] is not None else None for o in ops]
+    for r, (M, N, K, _), o, C, db in zip(rec, shapes, ops, Cs, dbs):
+        r["A"], r["B"], r["C"], r["dbias"] = o[2].data_ptr(), o[3].data_ptr(), C.data_ptr(), (db.data_ptr() if db is not None else 0)
+        r["lda"], r["ldb"], r["ldc"], r["M"], r["N"], r["K"], r["reserved"] = N, K, K, 3 * M, N, K, M // 64
+    Ms, Ns, Ks = (np.ascontiguousarray(rec[f], dtype=np.int32) for f in ("M", "N", "K"))
+    cap = int(sum(((n + 255) // 256) * ((k + 255) // 256) for n, k in zip(Ns, Ks))) + 2 * nwg + 1
+    items, first = np.zeros((cap, 8), dtype=np.int32), np.zeros(nwg + 1, dtype=np.int32)
+    n = _lib.load().climb_tn_grouped_plan(len(shapes), Ms.ctypes.data, Ns.ctypes.data, Ks.ctypes.data, nwg, items.ctypes.data, cap, first.ctypes.data)
+    assert n > 0
+    d_rec = torch.from_numpy(rec.view(np.uint8).copy()).to(dev)
+    d_items, d_first = torch.from_numpy(items[:n].copy()).to(dev), torch.from_numpy(first).to(dev)
+    _lib.call("climb_gemm_split_tn_grouped", d_rec, d_items, d_first, nwg, _st())
+    torch.cuda.synchronize()
+    for (dY, X, _, _, C0, b0), C, db in zip(ops, Cs, dbs):
+        exact = C0.double().cpu() + dY.double().cpu().t() @ X.double().cpu()
+        assert _rel(C, exact) < 4e-5
+        if b0 is not None:
+            assert _rel(db, b0.double().cpu() + dY.double().cpu().sum(0)) < 2e-5
+
+
+@pytest.mark.parametrize("C", [768, 1536])
+def test_layernorm_split_outputs(C):
+    """LayerNorm forward writing its output, and the backward writing the cast of its result, as split planes: the planes of the fp32 kernels' results"""
+    from climb_amd import _lib
+    dev = _dev()
+    M = 100
+    g = torch.Generator(device=dev).manual_seed(C)
+    x = torch.randn(M, C, device=dev, generator=g) * 3.0 + 0.5
+    gamma, beta = torch.randn(C, device=dev, generator=g), torch.randn(C, device=dev, generator=g)
+    y32 = torch.empty(M, C, device=dev)
+    mean, rstd = torch.empty(M, device=dev), torch.empty(M, device=dev)
+    _lib.call("climb_layernorm_fwd", x, C, gamma, beta, 1e-12, y32, C, 0, mean, rstd, M, C, _st())
+    ys = torch.empty((2, M, C), dtype=torch.bfloat16, device=dev)
+    _lib.call("climb_layernorm_fwd", x, C, gamma, beta, 1e-12, ys, C, 2, mean, rstd, M, C, _st())
+    hi, lo = _planes(y32.cpu())
+    assert torch.equal(ys[0].cpu(), hi) and torch.equal(ys[1].cpu(), lo)
+    dy = torch.randn(M, C, device=dev, generator=g)
+    dres = torch.randn(M, C, device=dev, generator=g)
+    lnb = _lib.query("climb_layernorm_bwd_rows_per_block")
+    part = torch.empty(((M + lnb - 1) // lnb) * 3 * C, device=dev)
+    o32 = torch.empty(M, C, device=dev)
+    _lib.call("climb_layernorm_bwd", dy, C, 0, x, C, mean, rstd, gamma, dres, C, o32, C, None, 0, part, M, C, _st())
+    o2, cs = torch.empty(M, C, device=dev), torch.empty((2, M, C), dtype=torch.bfloat16, device=dev)
+    _lib.call("climb_layernorm_bwd", dy, C, 2, x, C, mean, rstd, gamma, dres, C, o2, C, cs, C, part, M, C, _st())
+    assert torch.equal(o2, o32)
+    hi, lo = _planes(o32.cpu())
+    assert torch.equal(cs[0].cpu(), hi) and torch.equal(cs[1].cpu(), lo)
+
+
+def test_split_abi_rejects_bad_arguments():
+    from climb_amd import _lib
+    dev = _dev()
+    lib = _lib.load()
+    x = torch.zeros(8, 64, device=dev)
+    y = torch.zeros((2, 8, 64), dtype=torch.bfloat16, device=dev)
+    c = torch.zeros(8, 8, device=dev)
+    assert lib.climb_split_f32(x.data_ptr(), 64, y.data_ptr(), 64, 512, 8, 63, 0, None, 0, _st()) == -1          # C % 4
+    assert lib.climb_split_f32(x.data_ptr(), 64, y.data_ptr(), 64, 512, 8, 64, 2, None, 0, _st()) == -1          # mode 2 without aux
+    assert lib.climb_gemm_split_nt(y.data_ptr(), 64, 512, y.data_ptr(), 64, 512, c.data_ptr(), 8, 8, 8, 48, None, 0, None, 0, _st()) == -1      # K % 64
+    assert lib.climb_gemm_split_nt(y.data_ptr(), 64, 512, y.data_ptr(), 64, 512, c.data_ptr(), 8, 8, 8, 64, None, 1, None, 0, _st()) == -1      # epilogue
+    assert lib.climb_gemm_split_nt(y.data_ptr(), 64, 512, y.data_ptr(), 64, 512, c.data_ptr(), 8, 8, 8, 64, None, 2, None, 0, _st()) == -1      # residual missing
