@@ -736,7 +736,10 @@ class ViltEngine:
                       ws.xn[i], H, odt, ws.mean1[i], ws.rstd1[i], M, H, st)
             # fused QKV projection: q/k/v weights are adjacent in the flat buffer (HF:325-327 as one [2304,768] GEMM)
             self.linear_fwd(ws.xn[i], l + "attention.attention.query.weight", l + "attention.attention.query.bias", ws.qkv[i], M, 3 * H, H)
-            self.attn_fwd(ws.qkv[i], ws.key_bias, ws.ctx[i], ws.lse[i], B, ws.S_pad)
+            if self.split:          # three-product bf16 MFMAs on planes formed inside the kernel; ctx as fp32 (the backward's softmax row term) AND as the out-projection's operand
+                _lib.call("climb_attn_fwd_split", ws.qkv[i], ws.key_bias, ws.ctx[i], ws.ctx_s[i], M * H, ws.lse[i], B, ws.S_pad, nh, cfg["head_dim"], st)
+            else:
+                self.attn_fwd(ws.qkv[i], ws.key_bias, ws.ctx[i], ws.lse[i], B, ws.S_pad)
             if prune and i == cfg["layers"] - 1:
                 # last layer: only the [CLS] row of every sequence is read downstream (row b * S_pad of the [M, .] operands)
                 SH = ws.S_pad * H
@@ -748,8 +751,7 @@ class ViltEngine:
                                  None, 0, ws.uc, Fd)
                 self._lin_fwd_ld(ws.ac, Fd, l + "output.dense.weight", l + "output.dense.bias", ws.xLc, H, B, H, Fd, EPI_RESID, ws.h1c, H, out_f32=True)
                 continue
-            if self.split:          # the attention output as a GEMM operand (its fp32 form stays: the backward's softmax row term reads it)
-                self.split_of(ws.ctx[i], ws.ctx_s[i], M, H)
+            if self.split:
                 self.linear_fwd_resid(ws.ctx_s[i], l + "attention.output.dense.weight", l + "attention.output.dense.bias", ws.h1[i], M, H, H, x)
             elif ad is None:
                 self.linear_fwd_resid(ws.ctx[i], l + "attention.output.dense.weight", l + "attention.output.dense.bias", ws.h1[i], M, H, H, x)
@@ -1146,9 +1148,9 @@ class ViltEngine:
                     dw(dy, ws.ctx[i], l + "attention.output.dense.weight", M, H, H, l + "attention.output.dense.bias", ws)
                 self.linear_dx(dy, l + "attention.output.dense.weight", ws.dctx, M, H, H)
             dqkv = dqkv_(i)
-            if self.split:          # fp32 attention backward, then its result as the operand of the two QKV gradient GEMMs
-                self.attn_bwd(ws.qkv[i], ws.key_bias, ws.dctx, ws.ctx[i], ws.lse[i], ws.delta, ws.dqkv, B, ws.S_pad)
-                self.split_of(ws.dqkv, dqkv, M, 3 * H)
+            if self.split:          # d(qkv) leaves the kernel as the operand planes of the two QKV gradient GEMMs (nothing else reads it)
+                _lib.call("climb_attn_delta", ws.dctx, ws.ctx[i], F32, ws.delta, B, ws.S_pad, cfg["heads"], st)
+                _lib.call("climb_attn_bwd_split", ws.qkv[i], ws.key_bias, ws.dctx, ws.lse[i], ws.delta, None, dqkv, M * 3 * H, B, ws.S_pad, cfg["heads"], cfg["head_dim"], st)
             else:
                 self.attn_bwd(ws.qkv[i], ws.key_bias, ws.dctx, ws.ctx[i], ws.lse[i], ws.delta, dqkv, B, ws.S_pad)
             # q/k/v weights and biases are adjacent: one [2304,768] weight-gradient GEMM + one [2304] bias reduction

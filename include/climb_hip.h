@@ -236,6 +236,12 @@ int climb_gemm_split_tn(const void* A, long lda, long a_lo, const void* B, long 
  * (and the M handed to climb_tn_grouped_plan) = 3 Mt, the three phases of the reduction, and its `reserved` field = Mt / 64.  N % 256 == K % 256 == 0. */
 int climb_gemm_split_tn_grouped(const void* probs, const void* items, const void* first, int nwg, void* stream);
 
+/* HF:322-351 on split operands (csrc/attention_split.hip): the fp32 entry points' contract -- qkv / dctx fp32, lse and delta as above -- with every product as
+ * three bf16 MFMA passes over (hi, lo) planes formed on the way into LDS / registers.  The forward writes ctx as fp32 (may be NULL) and / or as split planes
+ * (ctx_split = the hi plane [B*S_pad, H], the lo plane ctx_lo elements behind; may be NULL); the backward writes d(qkv) as fp32 and / or split planes likewise. */
+int climb_attn_fwd_split(const float* qkv, const float* key_bias, float* ctx, void* ctx_split, long ctx_lo, float* lse, int B, int S_pad, int heads, int head_dim, void* stream);
+int climb_attn_bwd_split(const float* qkv, const float* key_bias, const float* dctx, const float* lse, const float* delta, float* dqkv, void* dqkv_split, long dqkv_lo, int B, int S_pad, int heads, int head_dim, void* stream);
+
 /* ---- image pre-processing on the device (replaces the host call REF/modeling/vilt.py:86-96 -> ViltProcessor ->
  * transformers image_processing_pil_vilt.py:127-242 -> Pillow Resample.c).  All images of a batch live in byte arenas; `table` holds
  * 16 longs per image: byte offsets of its raw [sh][sw][3] pixels, its [sh][dw][3] intermediate and its [dh][dw][3] result, then

@@ -200,3 +200,59 @@ def test_split_abi_rejects_bad_arguments():
     assert lib.climb_gemm_split_nt(y.data_ptr(), 64, 512, y.data_ptr(), 64, 512, c.data_ptr(), 8, 8, 8, 48, None, 0, None, 0, _st()) == -1      # K % 64
     assert lib.climb_gemm_split_nt(y.data_ptr(), 64, 512, y.data_ptr(), 64, 512, c.data_ptr(), 8, 8, 8, 64, None, 1, None, 0, _st()) == -1      # epilogue
     assert lib.climb_gemm_split_nt(y.data_ptr(), 64, 512, y.data_ptr(), 64, 512, c.data_ptr(), 8, 8, 8, 64, None, 2, None, 0, _st()) == -1      # residual missing
+
+
+def _attn_ref(qkv, bias, heads):
+    B, S, H3 = qkv.shape
+    H = H3 // 3
+    d = H // heads
+    q, k, v = (qkv[..., i * H:(i + 1) * H].reshape(B, S, heads, d).transpose(1, 2) for i in range(3))
+    s = q @ k.transpose(-1, -2) / math.sqrt(d) + bias[:, None, None, :]
+    return (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(B, S, H)
+
+
+@pytest.mark.parametrize("S_pad,valid", [(32, 20), (64, 50), (160, 150), (192, 185), (224, 200), (288, 281)])
+def test_attention_split_fwd_bwd(S_pad, valid):
+    """the split-operand attention against float64 autograd of the same fp32 inputs: forward ctx (fp32 and planes) and lse, backward d(qkv) (fp32 and
+    planes); 4 / 6 / 8 waves per workgroup and the two-chunk path (S_pad > 192) are all among the shapes"""
+    from climb_amd import _lib
+    dev = _dev()
+    B, heads, d = 2, 3, 64
+    H = heads * d
+    g = torch.Generator().manual_seed(S_pad)
+    qkv = torch.randn(B, S_pad, 3 * H, generator=g)
+    qkv[..., :2 * H] *= 1.5                       # non-trivial softmax
+    bias = torch.zeros(B, S_pad)
+    bias[:, valid:] = -3.0e38
+    bias[1, 3:7] = -3.0e38                        # masked text tokens in the middle
+    dctx = torch.randn(B, S_pad, H, generator=g)
+    dctx[:, valid:] = 0
+    qr = qkv.double().requires_grad_(True)
+    ref = _attn_ref(qr, bias.double().clamp(min=-1e300), heads)
+    ref.backward(dctx.double())
+    M = B * S_pad
+    qd, bd, dd = qkv.to(dev).view(M, 3 * H), bias.to(dev), dctx.to(dev).view(M, H)
+    ctx = torch.full((M, H), float("nan"), device=dev)
+    ctx_s = torch.empty((2, M, H), dtype=torch.bfloat16, device=dev)
+    lse = torch.empty(B, heads, S_pad, device=dev)
+    _lib.call("climb_attn_fwd_split", qd, bd, ctx, ctx_s, M * H, lse, B, S_pad, heads, d, _st())
+    assert _rel(ctx.view(B, S_pad, H)[:, :valid], ref.detach()[:, :valid]) < 3e-5
+    hi, lo = _planes(ctx.cpu())
+    assert torch.equal(ctx_s[0].cpu(), hi) and torch.equal(ctx_s[1].cpu(), lo)
+    # against the exact-fp32 kernels' statistics
+    ctx32, lse32 = torch.empty(M, H, device=dev), torch.empty(B, heads, S_pad, device=dev)
+    _lib.call("climb_attn_fwd_f32", qd, bd, ctx32, lse32, B, S_pad, heads, d, _st())
+    assert float((lse[..., :valid] - lse32[..., :valid]).abs().max()) < 2e-4
+    delta = torch.empty(B, heads, S_pad, device=dev)
+    dqkv = torch.full((M, 3 * H), float("nan"), device=dev)
+    dq_s = torch.empty((2, M, 3 * H), dtype=torch.bfloat16, device=dev)
+    _lib.call("climb_attn_delta", dd, ctx, 0, delta, B, S_pad, heads, _st())
+    _lib.call("climb_attn_bwd_split", qd, bd, dd, lse, delta, dqkv, dq_s, M * 3 * H, B, S_pad, heads, d, _st())
+    assert not torch.isnan(dqkv).any()
+    assert _rel(dqkv.view(B, S_pad, 3 * H), qr.grad) < 4e-5
+    hi, lo = _planes(dqkv.cpu())
+    assert torch.equal(dq_s[0].cpu(), hi) and torch.equal(dq_s[1].cpu(), lo)
+    # planes only (what the engine asks for)
+    dq2 = torch.empty_like(dq_s)
+    _lib.call("climb_attn_bwd_split", qd, bd, dd, lse, delta, None, dq2, M * 3 * H, B, S_pad, heads, d, _st())
+    assert torch.equal(dq2, dq_s)
