@@ -224,6 +224,19 @@ def main():
     dt = float(tmax.item())
     events = prof["events"]
     in_sync = ddp.replicas_in_sync() if ddp is not None else True
+    # r06: what makes a first multi-GPU lease self-validating -- the world size as the PROCESS GROUP reports it (not the launcher's
+    # environment), and which physical device every rank computed on (one UUID / PCI address per rank: N distinct ones under RCCL, the same one N times in
+    # the gloo test that time-shares a GPU)
+    pg_info = rank_devices = None
+    if dist.is_initialized():
+        import socket
+        pr = torch.cuda.get_device_properties(dev)
+        mine = {"rank": rank, "local_rank": local_rank, "cuda_device": int(torch.cuda.current_device()), "name": pr.name, "uuid": str(getattr(pr, "uuid", "")),
+                "pci": "%04x:%02x:%02x" % (int(getattr(pr, "pci_domain_id", 0)), int(getattr(pr, "pci_bus_id", 0)), int(getattr(pr, "pci_device_id", 0))),
+                "host": socket.gethostname()}
+        rank_devices = [None] * dist.get_world_size()
+        dist.all_gather_object(rank_devices, mine)
+        pg_info = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "reducer_world": int(ddp.world) if ddp is not None else 1}
 
     if rank == 0:
         ws = eng.workspace(B, T)
@@ -300,6 +313,11 @@ def main():
                "roofline": roof}
         if cls_only is not None:
             out["cls_only_last_layer"] = cls_only
+        out["value_per_gpu"] = round(value / world, 2)          # BASELINE.json's metric is quoted per GPU; `value` is the whole job
+        if pg_info is not None:
+            out["process_group"] = pg_info
+            out["rank_devices"] = rank_devices
+            out["distinct_devices"] = len({(d["host"], d["uuid"] or d["pci"], d["cuda_device"]) for d in rank_devices})
         if ddp is not None:
             out["replicas_in_sync"] = in_sync
             out["dp_overlap"] = bool(ddp.overlap)
@@ -512,8 +530,12 @@ def spawn_check(world, rank):
     dist.init_process_group("gloo")
     t = torch.tensor([float(rank + 1)])
     dist.all_reduce(t)
+    who = [None] * dist.get_world_size()          # the same gather the real run prints as `rank_devices` (here: which process is which rank)
+    dist.all_gather_object(who, {"rank": rank, "local_rank": int(os.environ.get("LOCAL_RANK", "0")), "pid": os.getpid()})
     if rank == 0:
-        print(json.dumps({"spawn_check": True, "n_gpus": world, "sum_of_ranks_plus_one": float(t.item()), "master_addr": os.environ.get("MASTER_ADDR")}), flush=True)
+        print(json.dumps({"spawn_check": True, "n_gpus": world, "sum_of_ranks_plus_one": float(t.item()), "master_addr": os.environ.get("MASTER_ADDR"),
+                          "process_group": {"backend": dist.get_backend(), "world_size": dist.get_world_size()}, "rank_devices": who,
+                          "value_per_gpu_is_value_over": world}), flush=True)
     dist.barrier()
     dist.destroy_process_group()
 

@@ -10,7 +10,13 @@ Data parallel: theta* and F are replicated per rank.  T
 batches in order (:56-64), so its value depends on the batch sequence and sharding it would change the result: every rank runs the pass on
 the WHOLE global batches (sharded loader switched to `replicated()`, gradient reducer suspended) -- the single-process arithmetic -- and
 rank 0's F is then broadcast so that replicas stay bit-identical even where a kernel's summation order is not (split-K atomics).  The task
-draw of `compute_ewc_loss` uses Python's `random`, seeded identically on every rank; the penalty gradient is added after the all-reduce."""
+draw of `compute_ewc_loss` uses Python's `random`, seeded identically on every rank; the penalty gradient is added after the all-reduce.
+
+r06, opt-in (`args.ewc_fisher_sharded` / CLIMB_AMD_FISHER_SHARDED=1): the SHARDED Fisher pass.  The replicated pass costs every rank the whole pass (N x
+redundant).  What makes the estimate order-dependent is only the running sum G_k = sum_{j<=k} g_j that batch k squares -- g_j itself is a batch-mean
+gradient and shards like any training step's: rank r computes its weighted share of g_k (the sharded loader's `dp_weight`), ONE fp32 all-reduce over the
+encoder range makes g_k whole on every rank, every rank adds it to its own copy of G and squares that.  Same estimate up to the summation order of the
+shares (tests compare the two passes); 1 / N of the forward / backward work per rank and one 0.36 GB collective per Fisher batch."""
 from __future__ import annotations
 
 import argparse
@@ -71,6 +77,8 @@ class EWC:
     def __init__(self, args: argparse.Namespace):
         self.fisher_sample_percentage = args.ewc_fisher_sample_percentage
         self.ewc_loss_weight = args.ewc_loss_weight
+        import os
+        self.fisher_sharded = bool(getattr(args, "ewc_fisher_sharded", False)) or os.environ.get("CLIMB_AMD_FISHER_SHARDED", "0") == "1"
         self.fisher_dict = {}
         self.param_dict = {}
         self.fisher_flat: Dict[str, torch.Tensor] = {}
@@ -96,14 +104,17 @@ class EWC:
         num_samples_completed = 0
         world = parallel.rank_world()[1]
         reducer = host.ddp if world > 1 else None
-        with replicated(dataloader), (reducer.suspended() if reducer is not None else contextlib.nullcontext()):
-            for step, batch in enumerate(dataloader):
-                task_trainer.train_step(model, batch)
-                eng = host.engine()
-                eng.fisher_accumulate(fisher)
-                num_samples_completed += _num_examples(batch["raw_texts"])
-                if num_samples_completed >= fisher_sample_size:
-                    break
+        if world > 1 and getattr(self, "fisher_sharded", False):
+            num_samples_completed = self._sharded_fisher_pass(model, task_trainer, dataloader, fisher, n, fisher_sample_size, reducer)
+        else:
+            with replicated(dataloader), (reducer.suspended() if reducer is not None else contextlib.nullcontext()):
+                for step, batch in enumerate(dataloader):
+                    task_trainer.train_step(model, batch)
+                    eng = host.engine()
+                    eng.fisher_accumulate(fisher)
+                    num_samples_completed += _num_examples(batch["raw_texts"])
+                    if num_samples_completed >= fisher_sample_size:
+                        break
         _lib.call("climb_scale", fisher, n, 1.0 / max(1, num_samples_completed), torch.cuda.current_stream().cuda_stream)
         if world > 1:
             import torch.distributed as dist
@@ -113,6 +124,36 @@ class EWC:
         self.fisher_dict[task_key] = _views(fisher, eng)
         self.param_dict[task_key] = _views(self.param_flat[task_key], eng)
         logger.info("Saved encoder parameters for {} task!".format(task_key))
+
+    def _sharded_fisher_pass(self, model, task_trainer, dataloader, fisher: torch.Tensor, n: int, fisher_sample_size: int, reducer) -> int:
+        """The Fisher pass with every batch's gradient computed on the rank's SHARD (module docstring, r06).  Returns the examples consumed (global)."""
+        import torch.distributed as dist
+        host = model._host
+        pg = getattr(reducer, "pg", None)
+        world = dist.get_world_size(pg)
+        st = lambda: torch.cuda.current_stream().cuda_stream          # noqa: E731
+        gsum = torch.zeros(n, dtype=torch.float32, device=fisher.device)          # G_k: the accumulating sum REF ewc.py:56-64 leaves in .grad
+        done = 0
+        with (reducer.suspended() if reducer is not None else contextlib.nullcontext()):
+            for step, batch in enumerate(dataloader):
+                eng = host.engine()
+                eng.zero_grad()                                   # this batch's share alone: the accumulation lives in gsum
+                task_trainer.train_step(model, batch)             # d(loss) weighted by the shard's share of the global batch (dp_weight)
+                eng = host.engine()
+                eng.materialize_dw()
+                g = eng.grad[:n]
+                dist.all_reduce(g, op=dist.ReduceOp.SUM, group=pg)
+                _lib.call("climb_scale_f32", g, n, 1.0 / world, st())          # mean over ranks of the weighted shares = the global batch's gradient
+                _lib.call("climb_elementwise", 5, gsum, g, gsum, n, 1.0, st())
+                _lib.call("climb_fisher_accum", fisher, gsum, n, st())
+                w = float(batch.get("dp_weight", 1.0)) if isinstance(batch, dict) else 1.0
+                cnt = torch.tensor([float(_num_examples(batch["raw_texts"])) if w > 0 else 0.0], dtype=torch.float64, device=fisher.device)
+                dist.all_reduce(cnt, op=dist.ReduceOp.SUM, group=pg)
+                done += int(round(float(cnt.item())))
+                if done >= fisher_sample_size:
+                    break
+            host.engine().zero_grad()
+        return done
 
     def set_task_state(self, task_key: str, model, fisher_named: Dict[str, torch.Tensor], param_named: Dict[str, torch.Tensor]):
         """Install an externally computed Fisher / theta* (dicts keyed like the reference's: `vilt.*`)."""

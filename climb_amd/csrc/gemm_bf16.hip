@@ -350,7 +350,8 @@ int climb_nt256_get_grid();
 void climb_attn_set_1pp_grid(int v);
 void climb_ln_set_rpw(int v);
 // current value of a library option (only the ones a caller has to put back: 9 = persistent NT grid); -1 = not readable
-extern "C" int climb_get_option(int key) { return key == 9 ? climb_nt256_get_grid() : -1; }
+int climb_tn_get_stagger();
+extern "C" int climb_get_option(int key) { return key == 9 ? climb_nt256_get_grid() : (key == 22 ? climb_tn_get_stagger() : -1); }
 extern "C" int climb_set_option(int key, int value) {
   if (key == 1 && (value == 4 || value == 8)) { g_nt_waves = value; return CLIMB_OK; }
   if (key == 2) { g_nt_small_m = value; return CLIMB_OK; }

@@ -646,6 +646,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_tn_grouped_kernel(const TnGroup
 // meet through atomics; a share cut in two at an even reduction tile adds one partial item).
 static int g_tn_stagger = 0;          // measured r05 (profiles/r05_dw_stagger_ab.txt): the step is 0.03 - 0.13 ms SLOWER with any grouping (inside an XCD the phase groups stop sharing panels in L2; by XCD nothing is gained): off
 void climb_tn_set_stagger(int v) { g_tn_stagger = v; }
+int climb_tn_get_stagger() { return g_tn_stagger; }
 extern "C" int climb_tn_grouped_plan(int nprob, const int* M, const int* N, const int* K, int nwg, int* items_out, int cap, int* first_out) {
   if (nprob <= 0 || nwg <= 0 || (nwg % 8) || !M || !N || !K || !items_out || !first_out) return CLIMB_EINVAL;
   struct Tile { int prob, tn, tk, nkt; };

@@ -169,14 +169,23 @@ def _load_or_build_cache(cache_file: str, build):
         try:
             with open(cache_file, "rb") as f:
                 return pkl.load(f)
-        except (EOFError, pkl.UnpicklingError):
-            pass
+        except Exception as e:          #  a cut can surface as EOFError / UnpicklingError, but also as AttributeError, ValueError, IndexError ... depending on where it lands
+            logger.warning("parse cache %s could not be read (%s: %s); building it again", cache_file, type(e).__name__, e)
     data = build()
     if os.path.isdir(os.path.dirname(cache_file)):          # the reference's data trees ship these directories; never create them
         tmp = f"{cache_file}.tmp.{os.getpid()}"
-        with open(tmp, "wb") as f:
-            pkl.dump(data, f)
-        os.replace(tmp, cache_file)
+        try:
+            with open(tmp, "wb") as f:
+                pkl.dump(data, f)
+            os.replace(tmp, cache_file)
+        except OSError as e:            # a full / read-only data tree must not fail the run, nor leave the temporary behind
+            logger.warning("parse cache %s not written (%s)", cache_file, e)
+        finally:
+            if os.path.exists(tmp):
+                try:
+                    os.unlink(tmp)
+                except OSError:
+                    pass
     return data
 
 

@@ -29,7 +29,19 @@ _FUSED_ADAPTER = os.environ.get("CLIMB_AMD_FUSED_ADAPTER", "1") != "0"       # m
 # (ranges must become ready in a few chunks for the all-reduce to overlap the rest of the backward)
 _DW_GROUP = os.environ.get("CLIMB_AMD_DW_GROUP")
 _NT_GRID_BEFORE_RESERVE = 0        # library-wide persistent NT grid (option 9) in force before the first CU reserve
-_NT_RESERVING = set()              # engines that currently hold a reserve
+import weakref
+_NT_RESERVING = weakref.WeakSet()  # engines that currently hold a reserve (weak: an engine that dies holding one -- a model re-created between tasks -- drops out)
+
+
+def _restore_nt_grid_if_unreserved(cell):
+    """finalizer of an engine that DIED holding a CU reserve (cell[0] > 0): once nobody reserves any more, the library-wide persistent NT grid goes back to
+    what was in force before the first reserve"""
+    try:
+        if cell[0] > 0 and not len(_NT_RESERVING):
+            _lib.call("climb_set_option", 9, _NT_GRID_BEFORE_RESERVE)
+    except Exception:
+        pass
+
 _RED_BATCH = os.environ.get("CLIMB_AMD_RED_BATCH", "1") != "0"          # measurement knob: 0 = one reduce launch per LayerNorm backward
 _UNSCALE_MODE = os.environ.get("CLIMB_AMD_FP16_UNSCALE", "end")      # measurement knob: "range" (per finished range), "end" (one pass), "none" (timing only)
 EPI_NONE, EPI_GELU, EPI_RESID, EPI_DGELU, EPI_TANH, EPI_SILU, EPI_DSILU, EPI_RESID2, EPI_GELUD, EPI_MUL = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
@@ -247,6 +259,7 @@ class ViltEngine:
         self._head_ws: Dict[tuple, dict] = {}
         self.requires_grad: Dict[str, bool] = {n: True for n in layout.shapes}
         self.grad_ready_hook: Optional[Callable[[int, int], None]] = None   # (lo, hi) flat range whose grads are final
+        self._reserve_cell = None        # [reserve] shared with this engine's finalizer (set_cu_reserve)
         self._cu_reserve = 0             # CUs the persistent GEMMs leave free (set_cu_reserve: collectives running under the backward)
         self.touched: List[tuple] = []                  # flat ranges that received gradients in the last backward
         self.saved = None
@@ -866,18 +879,24 @@ class ViltEngine:
             #  the saved value lives at module level -- the setting is the library's, not this engine's: engines that reserve in turn must
             # not restore each other's reduced grids -- and 0 ("uncapped") counts as every CU when the reduced grid is computed
             global _NT_GRID_BEFORE_RESERVE, _NT_RESERVING
-            if not _NT_RESERVING:
+            if not len(_NT_RESERVING):
                 _NT_GRID_BEFORE_RESERVE = int(_lib.query_arg("climb_get_option", 9))
             base = _NT_GRID_BEFORE_RESERVE
             if n == 0:
-                _NT_RESERVING.discard(id(self))
-                if not _NT_RESERVING:
+                _NT_RESERVING.discard(self)
+                if not len(_NT_RESERVING):
                     _lib.call("climb_set_option", 9, base)
             else:
-                _NT_RESERVING.add(id(self))
+                if self not in _NT_RESERVING:
+                    _NT_RESERVING.add(self)
+                    if self._reserve_cell is None:
+                        self._reserve_cell = [0]
+                        weakref.finalize(self, _restore_nt_grid_if_unreserved, self._reserve_cell)
                 full = base if base > 0 else torch.cuda.get_device_properties(self.device).multi_processor_count
                 _lib.call("climb_set_option", 9, max(8, (full - n) // 8 * 8))
         self._cu_reserve = n
+        if self._reserve_cell is not None:
+            self._reserve_cell[0] = n
 
     def _dw_defer(self, pending: list, dY, X, wname, M, N, K, bname=None, ws=None):
         """linear_dw, but recorded for the group's launch when the shape fits its 256 x 256 tiles (else run now)."""
@@ -898,7 +917,8 @@ class ViltEngine:
                 self.linear_dw(dY, X, w, M, N, K, b, ws)
             if not pending:
                 return
-        key = (self._cu_reserve,) + tuple((w, b, dY.data_ptr(), X.data_ptr()) for dY, X, w, b, M, N, K in pending)
+        #  the planner reads option 22 (staggered epilogues) when the plan is BUILT: its value is part of the key, so an in-process A/B re-plans
+        key = (self._cu_reserve, int(_lib.query_arg("climb_get_option", 22))) + tuple((w, b, dY.data_ptr(), X.data_ptr()) for dY, X, w, b, M, N, K in pending)
         plan = ws.dw_plans.get(key)
         if plan is None:
             nwg = max(8, (torch.cuda.get_device_properties(self.device).multi_processor_count - self._cu_reserve) // 8 * 8)

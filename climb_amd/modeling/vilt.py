@@ -601,7 +601,11 @@ class ViltContinualLearner(ContinualLearner):
         `optimizer`: the caller's promise that `optimizer.step()` (this model's FusedAdamW) is the next thing that happens to the gradients
         (REF/train/visionlanguage_tasks/train_vqa.py:160-170: backward, step, zero_grad).  The grouped weight-gradient launch of the encoder is then
         held back and run BY that step with AdamW in its epilogue (csrc/gemm_bf16_tnp.hip): `.grad` of those matrices is never written.  Without the
-        promise -- or whenever something else reads the buffer first -- the launch runs as before."""
+        promise -- or whenever something else reads the buffer first -- the launch runs as before.
+        DEFERRED-VALUE CONTRACT of the promise: with an EWC plug-in the returned `ewc_loss` tensor RECEIVES its value when `optimizer.step()`
+        runs (it reads 0 until then), and the gradient buffer / `.grad` never holds the 2 lam F (theta - theta*) term -- the optimizer adds it inside its
+        own passes (engine.park_ewc).  REF/train/visionlanguage_tasks/train_vqa.py:160-170 reads the value after the step, as climb_amd's trainers do; a
+        caller that wants loss + ewc_loss, or the penalised gradient, BEFORE the step must not name its optimizer (or call `engine.apply_parked_ewc()`)."""
         host = self._host
         eng = host.engine()
         from ..optim import FusedAdamW

@@ -41,7 +41,8 @@ int climb_mfma_sustained_probe(const void* src, float* out, int blocks, int iter
  * key 15 = store-wave mode of the persistent NT kernel (0 default: measured slower);
  * key 16 = de-phased start of the persistent NT kernel's workgroups in multi-round launches: value % 1000 = hold-back unit (x 64 clocks), value / 1000 = k: 2 << k groups (0 = off) */
 int climb_set_option(int key, int value);
-/* current value of option `key` (9 = persistent NT grid: what a caller that shrinks it temporarily must put back); -1 = not readable */
+/* current value of option `key` (9 = persistent NT grid: what a caller that shrinks it temporarily must put back; 22 = phase groups of the grouped
+ * weight-gradient plan, read by climb_tn_grouped_plan when a plan is BUILT -- a caller that caches plans keys them by it); -1 = not readable */
 int climb_get_option(int key);
 
 /* ---- embeddings -------------------------------------------------------------------------------------------------- */

@@ -35,7 +35,7 @@ def _spawn(target, backend, *args):
 
 
 # ------------------------------------------------------------------------------------------------ EWC: replicated Fisher pass, rank 0's F broadcast
-def _fisher_worker(rank, world, port, q, backend, golden_dir):
+def _fisher_worker(rank, world, port, q, backend, golden_dir, sharded=False):
     dist = dp_join(rank, world, port, backend)
     try:
         from climb_amd.cl_algorithms import EWC
@@ -55,10 +55,14 @@ def _fisher_worker(rank, world, port, q, backend, golden_dir):
         for i in range(nb):
             e = vo.synthetic_encodings(B, seed=200 + i)
             images, texts = enc_to_inputs(e)
-            loader.append({"raw_texts": [""] * B, "encodings": texts, "images": images, "target_scores": vo.synthetic_vqa_targets(B, seed=200 + i)})
+            tgt = vo.synthetic_vqa_targets(B, seed=200 + i)
+            if sharded:          # this rank's strided share of every global batch (equal shares: weight 1), as climb_amd/data/sharding.py deals them
+                images, texts = enc_to_inputs({k: v[rank::world] for k, v in e.items()})
+                tgt = tgt[rank::world]
+            loader.append({"raw_texts": [""] * (B // world if sharded else B), "encodings": texts, "images": images, "target_scores": tgt})
         loader.dataset = list(range(int(nb * B / 0.01)))
         trainer = VQATrainer(types.SimpleNamespace(cl_algorithm="ewc"), task_configs, model_configs["vilt"], _dev(), train_dataloader=loader, val_dataloader=loader)
-        ewc = EWC(types.SimpleNamespace(ewc_fisher_sample_percentage=0.01, ewc_loss_weight=100.0))
+        ewc = EWC(types.SimpleNamespace(ewc_fisher_sample_percentage=0.01, ewc_loss_weight=100.0, ewc_fisher_sharded=sharded))
         before = (ddp.bytes_reduced, ddp.collectives)
         ewc.save_task_parameters(task_key="vqa", model=model, task_trainer=trainer, device=_dev())
         torch.cuda.synchronize()
@@ -94,6 +98,21 @@ def test_fisher_pass_is_replicated_and_broadcast(golden_dir, backend):
         _close(r[3], z["fisher_norms"], 2e-3, f"fisher norms, rank {r[0]}")
         _close(r[4], z["fisher_heads"], 2e-3, f"fisher heads, rank {r[0]}")
         assert r[6], "replicas diverged in the EWC step after the Fisher pass"
+    assert res[0][5] == res[1][5], "F differs between the ranks after the broadcast"
+
+
+def test_fisher_pass_sharded_over_the_ranks_is_the_same_estimate(golden_dir):
+    """r06 (SURVEY.md 8(e) "Fisher under DP"): the opt-in sharded pass -- each rank runs its share of every Fisher batch, one fp32
+    all-reduce per batch rebuilds the batch gradient, every rank accumulates and squares the running sum itself -- gives the reference's estimate
+    (fisher_3x2.npz, same tolerance as the replicated pass) on every rank, and the replicas stay identical through the EWC step that follows."""
+    need_backend("gloo")
+    res = _spawn(_fisher_worker, "gloo", golden_dir, True)
+    z = np.load(os.path.join(golden_dir, "fisher_3x2.npz"))
+    for r in res:
+        assert r[1], "the reducer stayed suspended after the Fisher pass"
+        _close(r[3], z["fisher_norms"], 2e-3, f"fisher norms, rank {r[0]}")
+        _close(r[4], z["fisher_heads"], 2e-3, f"fisher heads, rank {r[0]}")
+        assert r[6], "replicas diverged in the EWC step after the sharded Fisher pass"
     assert res[0][5] == res[1][5], "F differs between the ranks after the broadcast"
 
 
@@ -163,6 +182,11 @@ def test_bench_two_ranks_on_one_gpu_through_gloo():
     assert j["n_gpus"] == 2 and j["replicas_in_sync"] is True and j["config"]["global_batch"] == 16 and j["scaling"] == "weak"
     assert j["allreduce_MB_per_step"] > 100 and j["value"] > 0 and float(j["config"]["final_loss"]) == float(j["config"]["final_loss"]) and j["dp_payload"] in ("bf16", "none")
     assert set(j["dp_overlap_warmup_trial"]) >= {"overlap_ms", "deferred_ms", "chosen"} and "dp_overlap_ab" in j
+    # r06: the fields that make a multi-GPU lease self-validating
+    assert j["value_per_gpu"] == pytest.approx(j["value"] / 2, rel=1e-3)
+    assert j["process_group"] == {"backend": "gloo", "world_size": 2, "reducer_world": 2}
+    assert sorted(d["rank"] for d in j["rank_devices"]) == [0, 1] and all(d["uuid"] or d["pci"] for d in j["rank_devices"])
+    assert j["distinct_devices"] == 1          # both ranks of THIS test share the box's GPU; under RCCL the launch binds one GPU per rank: N
 
 
 # ------------------------------------------------------------------------------------------------ bench.py --gpus 2 (RCCL only: its ranks bind one GPU each)
@@ -177,3 +201,4 @@ def test_bench_two_gpus_smoke():
     j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert j["n_gpus"] == 2 and j["replicas_in_sync"] is True and j["config"]["global_batch"] == 128
     assert j["allreduce_MB_per_step"] > 100 and j["value"] > 0
+    assert j["process_group"]["backend"] == "nccl" and j["process_group"]["world_size"] == 2 and j["distinct_devices"] == 2

@@ -274,6 +274,9 @@ def test_bench_gpus_n_launches_itself_and_prints_one_json_line_last():
     last = [l for l in r.stdout.splitlines() if l.strip()][-1]
     j = json.loads(last)
     assert j["spawn_check"] is True and j["n_gpus"] == 2 and j["sum_of_ranks_plus_one"] == 3.0 and j["master_addr"] == "127.0.0.1"
+    # r06: the world size as the process group reports it, and one entry per rank from distinct processes
+    assert j["process_group"] == {"backend": "gloo", "world_size": 2}
+    assert sorted(d["rank"] for d in j["rank_devices"]) == [0, 1] and len({d["pid"] for d in j["rank_devices"]}) == 2
 
 
 def test_nt4_tile_walk_is_a_bijection():
