@@ -1,6 +1,6 @@
 // Multi-head self-attention of the split-operand mode (r06; HF modeling_vilt.py:322-351): the data flow of attention_f32.hip -- one workgroup per
 // (batch, head), K / V (backward: the inner operand pair) resident in LDS, one 32-row block of the outer operand per wave, scores computed "swapped" so
-// that a lane owns one outer row, two passes in the forward (statistics, then normalised probabilities) -- with every product on
+// that a lane owns one outer row (forward: one pass with an online softmax) -- with every product on
 // v_mfma_f32_32x32x16_bf16 over (hi, lo) bf16 planes: a b = a_hi b_hi + a_hi b_lo + a_lo b_hi, fp32 accumulate.  16 significant bits per operand
 // (split.hip) at 3/16 of the MFMA time of the exact-fp32 instruction: 12 MFMAs of 32 cycles per (32 x 32 x 64) product instead of 32 of 64.
 //
@@ -158,14 +158,18 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_split_kernel(const float* __
     const bool active = qb < NB;
     bf16x8 qh[4], ql[4];
     as_load_outer(Qg + (long)(active ? qb : 0) * 32 * ld, ld, l31, half, scale, qh, ql);          // Q / sqrt(d): a power of two, exact
-    // pass 1: online max / sum over all keys -> lse
+    // ONE pass over the keys (online softmax): running maximum m and sum l per query, the unnormalised O^T rescaled whenever m moves; normalised at the end
+    // (the exact-fp32 kernel takes two passes -- statistics, then exp(s - lse) -- at twice the score products; the backward recomputes P from lse either way)
     float m_run = -3.0e38f, l_run = 0.f;
+    f32x16 o[2];
+    as_zero(o[0]);
+    as_zero(o[1]);
     for (int ch = 0; ch < nchunks; ++ch) {
       const int k0 = ch * CK, nk = min(CK, S_pad - k0);
       if (nchunks > 1 || round == 0) {
         __syncthreads();
         as_stage(Kh, Kl, Kg + (long)k0 * ld, ld, nk, tid, 64 * NW);
-        if (nchunks == 1) as_stage(Vh, Vl, Vg + (long)k0 * ld, ld, nk, tid, 64 * NW);
+        as_stage(Vh, Vl, Vg + (long)k0 * ld, ld, nk, tid, 64 * NW);
         __syncthreads();
       }
       if (active)
@@ -181,38 +185,34 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_split_kernel(const float* __
           }
           mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
           const float m_new = fmaxf(m_run, mx);
+          const float alpha = __expf(m_run - m_new);
           float sum = 0.f;
 #pragma unroll
-          for (int r = 0; r < 16; ++r) sum += __expf(s[r] - m_new);
+          for (int r = 0; r < 16; ++r) {
+            s[r] = __expf(s[r] - m_new);
+            sum += s[r];
+          }
           sum += __shfl_xor(sum, 32, 64);
-          l_run = l_run * __expf(m_run - m_new) + sum;
+          l_run = l_run * alpha + sum;
           m_run = m_new;
-        }
-    }
-    const float lse = m_run + __logf(l_run);
-    // pass 2: P = exp(s - lse) (already normalised), O^T = V^T P^T
-    f32x16 o[2];
-    as_zero(o[0]);
-    as_zero(o[1]);
-    for (int ch = 0; ch < nchunks; ++ch) {
-      const int k0 = ch * CK, nk = min(CK, S_pad - k0);
-      if (nchunks > 1) {
-        __syncthreads();
-        as_stage(Kh, Kl, Kg + (long)k0 * ld, ld, nk, tid, 64 * NW);
-        as_stage(Vh, Vl, Vg + (long)k0 * ld, ld, nk, tid, 64 * NW);
-        __syncthreads();
-      }
-      if (active)
-        for (int kb = 0; kb < nk / 32; ++kb) {
-          f32x16 s;
-          as_zero(s);
-          as_prod_rm(s, Kh, Kl, kb * 32, l31, half, qh, ql);
+          if (alpha != 1.0f) {          // (wave-divergent only while the maximum still moves: the first blocks of a row)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) s[r] = __expf(s[r] + bias_s[k0 + kb * 32 + as_drow(r, half)] - lse);
+            for (int d = 0; d < 2; ++d)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+          }
           bf16x8 ph[2], pl[2];
           as_split16(s, ph, pl);
           as_prod_t(o, Vh, Vl, kb * 32, lane, ph, pl);
         }
+    }
+    const float lse = m_run + __logf(l_run);
+    {
+      const float inv = 1.0f / l_run;
+#pragma unroll
+      for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[d][r] *= inv;
     }
     if (active) {
       const long row = (long)b * S_pad + qb * 32 + l31;

@@ -149,8 +149,8 @@ def test_two_rank_data_parallel_driver_run_equals_the_single_process_run(name, d
         pytest.skip("needs a GPU")
     from tests.test_dp_training import _files, _pinned, _same, _scenario
     env = {"CLIMB_AMD_PRECISION": "fp32"}
-    out1, rep1 = _scenario(1, name, dp_tree, tmp_path, abi="hip", env_extra=env, extra=["--pin", "--epochs", "3"])      # 3 epochs per task: the same paths in a third of the time
-    out2, rep2 = _scenario(2, name, dp_tree, tmp_path, abi="hip", env_extra=env, extra=["--pin", "--epochs", "3"])
+    out1, rep1 = _scenario(1, name, dp_tree, tmp_path, abi="hip", env_extra=env, extra=["--pin", "--epochs", "2"])      # 2 epochs per task: the same paths in a fraction of the time
+    out2, rep2 = _scenario(2, name, dp_tree, tmp_path, abi="hip", env_extra=env, extra=["--pin", "--epochs", "2"])
     golden = json.load(open(os.path.join(golden_dir, "driver_calls.json")))["scenarios"][name]
     for rep in rep2 + rep1:
         assert rep["calls"] == golden["calls"]

@@ -44,7 +44,8 @@ def test_fp16_mode_passes_the_step_level_parity_tests():
     """tests/test_gpu_parity.py with H16 = fp16 (bf16 tolerances, i.e. loose for this mode): reference fixtures at full size, the
     reference-style autograd path (loss scale chosen from torch's d(logits)), the Fisher pass (gradient accumulation across backwards
     without zero_grad: earlier sums are pre-scaled), EWC, hipGraph replay, and 30 optimizer steps tracking the fp32 loss curve."""
-    sel = "full_size_bf16 or training_curve or reference_style_autograd or fisher_accumulating or ewc_penalty or hipgraph"
+    # (r06: the suite's time budget -- the full-size step on this build is test_fp16_step_against_the_reference_at_batch_64 above)
+    sel = "training_curve or reference_style_autograd or fisher_accumulating or ewc_penalty or hipgraph"
     r = _run(["-m", "pytest", "tests/test_gpu_parity.py", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider", "-k", sel], timeout=2400)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout

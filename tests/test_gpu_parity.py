@@ -95,6 +95,9 @@ def test_state_dict_names_and_layout():
         assert torch.equal(p.detach().cpu(), P[n]), n
 
 
+_ORACLE_STEPS = {}
+
+
 # the two modes that promise north_star's bar: exact-fp32 MFMA, and (r06) split (hi, lo) bf16 operands with three MFMA products per k-step
 PARITY_MODES = ["fp32"] + (["bf16x3"] if os.environ.get("CLIMB_AMD_H16", "bf16") == "bf16" else [])
 
@@ -126,8 +129,10 @@ def test_single_image_step_vs_oracle_and_golden(golden_dir, fname, precision):
     norms, heads = _summary(G, names)
     _close(norms, z["grad_norms"], TOL, "grad norms vs reference")
     _close(heads, z["grad_heads"], TOL, "grad heads vs reference")
-    # vs oracle, every element of every gradient
-    _, _, _, oG = vo.train_step(P, task, enc, target)
+    # vs oracle, every element of every gradient (the oracle's CPU step is the same for every mode: computed once per fixture)
+    if fname not in _ORACLE_STEPS:
+        _ORACLE_STEPS[fname] = vo.train_step(P, task, enc, target)[3]
+    oG = _ORACLE_STEPS[fname]
     worst = 0.0
     for n in names:
         if n.endswith("attention.key.bias"):
@@ -845,18 +850,22 @@ def test_full_size_fp32_vs_reference(golden_dir, fname, precision):
 
 
 # error budget of the throughput mode at the benchmark's size, measured against the REFERENCE (DESIGN.md section 3 tabulates where it comes from)
-BF16_FULL = dict(pooled=2.5e-2, logits=1.2e-2, loss=3e-3, grad_norm_max=3e-2)      # measured r02: pooled 2.3e-2, logits 8.7e-3, loss 1.4e-3 (NLVR2), grad norms 5.5e-3
+# r06: measured x 1.3 per fixture (a 2x regression used to pass silently).  Measured on the final r06 tree (gpurun_out/r06_gputest1.log):
+#   vqa_b64  pooled 2.24e-2 logits 5.96e-3 loss 4.0e-5 grad norms 5.3e-3 argmax 63 / 64;  nlvr2_b32  2.43e-2 7.07e-3 7.8e-4 3.8e-3 32 / 32;  vcr_b16  2.33e-2 7.45e-3 6.0e-4 3.3e-3 16 / 16
+BF16_FULL = {"vqa_b64.npz": dict(pooled=2.9e-2, logits=7.8e-3, loss=1e-4, grad_norm_max=7e-3),
+             "nlvr2_b32.npz": dict(pooled=3.2e-2, logits=9.2e-3, loss=1.1e-3, grad_norm_max=5e-3),
+             "vcr_b16.npz": dict(pooled=3.1e-2, logits=9.7e-3, loss=8e-4, grad_norm_max=4.4e-3)}
 
 
 @pytest.mark.parametrize("fname", FULL_SIZE)
 def test_full_size_bf16_vs_reference(golden_dir, fname):
     e = full_size_errors(np.load(os.path.join(golden_dir, fname)), H16)
     print(f"{fname} bf16 vs reference: {e}")
-    for k, lim in BF16_FULL.items():
+    for k, lim in BF16_FULL[fname].items():
         assert e[k] <= lim, (k, e[k], lim)
     # random-init heads put many top-2 logits closer than bf16's error (the smallest margin of vqa_b64 is 4e-4 of the logit scale):
     # the agreement is REPORTED (bench.py prints it) and bounded from below, it cannot be 100 % in this mode
-    assert e["argmax_agreement"] >= 0.9
+    assert e["argmax_agreement"] >= 0.95          # (measured: 63 / 64 = 0.984 on vqa_b64, 1.0 on the other two)
 
 
 # ------------------------------------------------------------------------------------------------ full size (bs = 64) properties
@@ -1469,8 +1478,7 @@ def test_data_parallel_optimizer_reads_the_averaged_payload_in_place(backend):
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
-@pytest.mark.parametrize("gbatch", [4, 3])
-@pytest.mark.parametrize("precision,tol", [("fp32", 1e-4), (H16, 4e-2)])      # bf16: payload rounding 2^-9 + bf16 GEMM order noise
+@pytest.mark.parametrize("precision,tol,gbatch", [("fp32", 1e-4, 3), (H16, 4e-2, 4), (H16, 4e-2, 3)])      # bf16: payload rounding 2^-9 + bf16 GEMM order noise; 3 = uneven shards
 def test_data_parallel_two_ranks_equals_single_process_on_the_global_batch(precision, tol, gbatch, backend):
     """Two processes (gloo collectives on device tensors, both on the test box's single GPU) train on halves of a batch of 4 through the
     real engine hooks: weights broadcast from rank 0, per-range gradient all-reduce during the backward, finish() before AdamW.
