@@ -7,10 +7,12 @@
 // the y tile is staged in LDS once, the four waves split K = 768 of the down-projection and meet in LDS, s never leaves the CU before
 // the up-projection consumes it, and the epilogue adds both residuals with row-contiguous 128-byte accesses.  HBM traffic ~ 2 x y + resid +
 // out = 115 MB at M = 12288, against 2 x 100 MB and two launch / fill / drain phases.  Measured: 31.7 us against 38.6 for the two GEMMs (the
-// adapter step 10.83 -> 10.72 ms); what keeps it from the ~20 us its bytes would allow is the epilogue's per-lane 4- and 2-byte accesses
-// (a lane owns a column): the LDS turn of the GEMM epilogues would be the next step.
-// MFMA orientation: D = A B^T with A = activation rows (m) and B = weight rows (n): a lane owns column n = lane & 31, its 16 registers the
-// rows m = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
+// adapter step 10.83 -> 10.72 ms); what kept it from the ~20 us its bytes allow was the epilogue's per-lane 4- and 2-byte accesses (a lane owned a
+// column: 48 memory instructions of 256 B per 32 x 32 block).  r06: the up-projection is issued with its operands swapped (a lane owns ONE row and
+// groups of 4 consecutive columns, as in the NT GEMMs) and every 32 x 32 block is turned through a per-wave 4 KB LDS region (gemm_bf16_nt.h: same
+// swizzle), so that residual, y and the result move as 16- / 8-byte accesses, 8 lanes a 128-byte row segment: 12 memory instructions per block.
+// MFMA orientation of the down-projection: D = A B^T with A = activation rows (m) and B = weight rows (n): a lane owns column n = lane & 31, its 16
+// registers the rows m = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
 #include "common.h"
 
 #define AD_ROWS 32
@@ -28,7 +30,8 @@ __device__ __forceinline__ bf16x8 ad_frag(ad_u32x4 v) {
 //     dz = t * silu'(z)      [M, r]   (z saved by the forward; dz is kept for the down-projection's weight gradient)
 //     dy = dres + dz Wd      [M, H]   (Wd [r, H]: transposed shadow [H, r]; dres = the fp32 residual gradient; dy in the 16-bit operand type)
 // so it is the same kernel with another middle and another epilogue: one launch instead of the two skinny GEMMs (2 x 15.5 us).
-// dynamic LDS: y tile [32][H] (row stride H * 2 + 16 bytes) -- later reused as zred[4][32][64] floats -- then sbuf[32][64] 16-bit
+// dynamic LDS: y tile [32][H] (row stride H * 2 + 16 bytes) -- later reused as zred[4][32][64] floats -- then sbuf[32][64] 16-bit, then the four
+// per-wave 4 KB turn regions of the epilogue
 template <bool BWD>
 __global__ __launch_bounds__(256) void adapter_kernel(const bf16_t* __restrict__ y, long ldy, const float* __restrict__ resid, long ldr,
                                                       const bf16_t* __restrict__ wd, const float* __restrict__ bd, const bf16_t* __restrict__ wu,
@@ -41,6 +44,7 @@ __global__ __launch_bounds__(256) void adapter_kernel(const bf16_t* __restrict__
   const int big = AD_ROWS * ystride > 4 * AD_ROWS * 64 * 4 ? AD_ROWS * ystride : 4 * AD_ROWS * 64 * 4;
   float* zred = reinterpret_cast<float*>(smem);
   bf16_t* sbuf = reinterpret_cast<bf16_t*>(smem + big);
+  unsigned char* turn = smem + big + AD_ROWS * 64 * 2 + wid * 4096;
   // ---- stage the y tile (rows past M re-read the last row: computed, never stored)
   const int chunks = H / 8;                                        // 16-byte chunks per row
   for (int idx = tid; idx < AD_ROWS * chunks; idx += 256) {
@@ -107,28 +111,43 @@ __global__ __launch_bounds__(256) void adapter_kernel(const bf16_t* __restrict__
   const int cw = H / (4 * gridDim.y);                              // columns per wave
 #pragma unroll 1
   for (int nb = 0; nb < cw / 32; ++nb) {
-    const int n = (blockIdx.y * 4 + wid) * cw + nb * 32 + l31;
+    const int n0 = (blockIdx.y * 4 + wid) * cw + nb * 32;
+    const int n = n0 + l31;
     f32x16 o;
 #pragma unroll
     for (int q = 0; q < 16; ++q) o[q] = 0.f;
+    // operands swapped: D[i = column n0 + ..][j = row l31] -- the lane owns row m0 + l31 and columns n0 + 8 g + 4 half .. + 3 per register group g
 #pragma unroll
     for (int ks = 0; ks < AD_MAXR / 16; ++ks)
-      if (ks < ksteps) o = CLIMB_MFMA_H16(sf[ks], ad_frag(*reinterpret_cast<const ad_u32x4*>(wu + (long)n * r + 16 * ks + 8 * half)), o, 0, 0, 0);
-    const float b = BWD ? 0.f : bu[n];
-    float rv[16], yv[16];
+      if (ks < ksteps) o = CLIMB_MFMA_H16(ad_frag(*reinterpret_cast<const ad_u32x4*>(wu + (long)n * r + 16 * ks + 8 * half)), sf[ks], o, 0, 0, 0);
+    // turn: row l31, 16-byte chunk 2 g + half at chunk position (2 g + half) ^ (l31 & 7) (conflict-free writes and row-major reads, gemm_bf16_nt.h)
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {                                 // all loads of the block before its first store
-      const int m = m0 + (q & 3) + 8 * (q >> 2) + 4 * half;
-      const int gm = m < M ? m : M - 1;
-      rv[q] = resid[(long)gm * ldr + n];
-      yv[q] = BWD ? 0.f : bf16_to_f32(y[(long)gm * ldy + n]);
+    for (int g = 0; g < 4; ++g)
+      *reinterpret_cast<float4*>(turn + l31 * 128 + (((2 * g + half) ^ (l31 & 7)) << 4)) = make_float4(o[4 * g], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3]);
+    // row-major walk: pass p covers rows 8 p .. 8 p + 7, a lane one float4 (columns 4 c .. 4 c + 3) of row 8 p + lane / 8.  All loads before the first store.
+    const int rr = lane >> 3, c = lane & 7;
+    float4 ov[4], rv[4];
+    uint2 yv[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int row = 8 * p + rr;
+      ov[p] = *reinterpret_cast<const float4*>(turn + row * 128 + (((c ^ row) & 7) << 4));
+      const int gm = m0 + row < M ? m0 + row : M - 1;
+      rv[p] = ld4(resid + (long)gm * ldr + n0 + 4 * c);
+      if (!BWD) yv[p] = *reinterpret_cast<const uint2*>(y + (long)gm * ldy + n0 + 4 * c);
     }
+    const float4 b4 = BWD ? make_float4(0.f, 0.f, 0.f, 0.f) : ld4(bu + n0 + 4 * c);
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const int m = m0 + (q & 3) + 8 * (q >> 2) + 4 * half;
+    for (int p = 0; p < 4; ++p) {
+      const int m = m0 + 8 * p + rr;
       if (m < M) {
-        if (BWD) reinterpret_cast<bf16_t*>(out_)[(long)m * ldo + n] = f32_to_bf16(o[q] + rv[q]);
-        else reinterpret_cast<float*>(out_)[(long)m * ldo + n] = o[q] + b + rv[q] + yv[q];
+        if (BWD) {
+          st4(reinterpret_cast<bf16_t*>(out_) + (long)m * ldo + n0 + 4 * c, make_float4(ov[p].x + rv[p].x, ov[p].y + rv[p].y, ov[p].z + rv[p].z, ov[p].w + rv[p].w));
+        } else {          // o + b + resid + y, summed in that order (as before the turn: same bits)
+          st4(reinterpret_cast<float*>(out_) + (long)m * ldo + n0 + 4 * c,
+              make_float4(ov[p].x + b4.x + rv[p].x + h16lo_to_f32(yv[p].x), ov[p].y + b4.y + rv[p].y + h16hi_to_f32(yv[p].x),
+                          ov[p].z + b4.z + rv[p].z + h16lo_to_f32(yv[p].y), ov[p].w + b4.w + rv[p].w + h16hi_to_f32(yv[p].y)));
+        }
       }
     }
   }
@@ -143,7 +162,7 @@ static int adapter_launch(const void* y, long ldy, const float* resid, long ldr,
   const int ystride = H * 2 + 16;
   size_t big = (size_t)AD_ROWS * ystride;
   if (big < (size_t)4 * AD_ROWS * 64 * 4) big = (size_t)4 * AD_ROWS * 64 * 4;
-  const size_t lds = big + (size_t)AD_ROWS * 64 * 2;
+  const size_t lds = big + (size_t)AD_ROWS * 64 * 2 + 4 * 4096;
   static size_t lds_set = 0;
   if (lds > lds_set) {
     hipError_t e = hipFuncSetAttribute((const void*)adapter_kernel<BWD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -291,6 +291,7 @@ class ViltEngine:
         self._shadow = None
         self._shadow_version = -1
         self._t_fresh = None
+        self._t_updated = None
         self._t_sub = {}
 
     def view(self, base: torch.Tensor, name: str) -> torch.Tensor:
@@ -591,23 +592,32 @@ class ViltEngine:
             _lib.call("climb_transpose_bf16_batched", self._shadow, self._shadow_t, table, tn, 96, st)
             _lib.call("climb_transpose_bf16_batched", self._shadow[tot:], self._shadow_t[tt:], table, tn, 96, st)
             self._t_fresh = None
+            self._t_updated = None
             self._shadow_version = ver
             self._shadow_stale = False
             return
         if self._shadow_stale != "transpose-only":
             _lib.call("climb_cast_bf16", self.flat, self._shadow, self.layout.total, st)
-        elif self._t_fresh:
-            # the optimizer ran in the weight-gradient epilogue for these tensors and wrote their transposed shadows there
-            key = frozenset(self._t_fresh)
+        elif self._t_fresh or self._t_updated is not None:
+            # the optimizer ran in the weight-gradient epilogue for `_t_fresh` and wrote their transposed shadows there; `_t_updated` (r06) = the tensors
+            # the optimizer touched AT ALL this step: a matrix it did not update (a frozen base under adapters: 85 M elements, 0.1 ms per step) keeps
+            # the transposed shadow it has
+            fresh = frozenset(self._t_fresh or ())
+            upd = None if self._t_updated is None else frozenset(self._t_updated)
+            key = (fresh, upd)
             sub = self._t_sub.get(key)
             if sub is None:
                 import numpy as np
-                rows = [(self.layout.offset[name], self._t_off[name], N, K) for name, N, K in self._linear_weight_names() if name not in key]      # (a fused QKV row is named by its query weight)
+                rows = [(self.layout.offset[name], self._t_off[name], N, K) for name, N, K in self._linear_weight_names()
+                        if name not in fresh and (upd is None or any(c in upd for c in self._covered(name, N * K)))]      # (a fused QKV row is named by its query weight)
+                if len(self._t_sub) >= 16:
+                    self._t_sub.pop(next(iter(self._t_sub)))
                 sub = self._t_sub[key] = (torch.from_numpy(np.array(rows, dtype=np.int64).reshape(-1, 4)).to(self.device), len(rows))
             table, tn = sub
         if tn:
             _lib.call("climb_transpose_bf16_batched", self._shadow, self._shadow_t, table, tn, 96, st)
         self._t_fresh = None
+        self._t_updated = None
         self._shadow_version = ver
         self._shadow_stale = False
 
@@ -619,9 +629,17 @@ class ViltEngine:
             self.refresh_shadow()          # first use: full cast, so tensors the optimiser skips have valid shadows too
         return self._shadow
 
-    def params_updated(self, shadow_fresh: bool = False, t_fresh=None):
-        self._shadow_stale = "transpose-only" if shadow_fresh else True
-        self._t_fresh = set(t_fresh) if (shadow_fresh and t_fresh) else None
+    def params_updated(self, shadow_fresh: bool = False, t_fresh=None, updated=None):
+        """`updated` (names, optional): everything the optimizer changed this step -- anything else keeps its transposed shadow.  Two updates without a
+        refresh in between (nobody ran a forward) accumulate."""
+        prev_pending = self._shadow_stale == "transpose-only"
+        prev_upd = getattr(self, "_t_updated", None)
+        self._shadow_stale = "transpose-only" if (shadow_fresh and self._shadow_stale in (False, "transpose-only")) else True
+        self._t_fresh = set(t_fresh) if (shadow_fresh and t_fresh and not prev_pending) else None
+        if shadow_fresh and updated is not None and (not prev_pending or prev_upd is not None):
+            self._t_updated = set(updated) | (set(prev_upd) if (prev_pending and prev_upd is not None) else set())
+        else:
+            self._t_updated = None
 
     def sp(self, name: str) -> int:
         return self._shadow.data_ptr() + 2 * self.layout.offset[name]

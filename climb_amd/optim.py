@@ -175,7 +175,9 @@ class FusedAdamW(torch.optim.Optimizer):
                 _lib.call("climb_adamw_spans", *args, torch.cuda.current_stream().cuda_stream)
         eng._g16 = None                # consumed
         eng._grad_clean = clean
-        eng.params_updated(shadow_fresh=shadow is not None, t_fresh=fused)
+        # (r06) which tensors changed at all: the transposed shadows of everything else stay as they are (a frozen base under adapters)
+        updated = set(fused) | {n for si, n in enumerate(self._seg_names) if seg_group[si] >= 0}
+        eng.params_updated(shadow_fresh=shadow is not None, t_fresh=fused, updated=updated)
         return loss
 
     # ---- checkpointing: the moments and per-parameter step counts live in flat buffers outside `self.state`, so the inherited

@@ -380,7 +380,13 @@ def test_ten_steps_config1(golden_dir, precision):
     names = [str(n) for n in z["names"]]
     after = {n: p.detach().cpu() for n, p in model.named_parameters()}
     norms, _ = _summary({n: after[n] - P0[n] for n in names}, names)
-    _close(norms, z["delta_norms"], 5e-3, "param delta norms")   # Adam's g/sqrt(v) amplifies rounding of tiny gradients
+    # d loss / d key.bias is identically zero (a per-query constant cancels in the softmax): both sides hold rounding noise only, and Adam's
+    # g / (sqrt(v) + eps) turns noise of ANY size into updates of ~lr -- the reference's own delta of these tensors (2.3e-3 .. 3.5e-3) is that noise, and
+    # every mode differs from it by about as much (measured r06: fp32 3.0e-3, bf16x3 3.5e-3 -- the latter straddled the old common 5e-3 bar from run to
+    # run).  They are bounded by the noise's scale; everything else is compared as before.
+    kb = np.array([n.endswith("attention.key.bias") for n in names])
+    _close(norms[~kb], z["delta_norms"][~kb], 5e-3, "param delta norms")   # Adam's g/sqrt(v) amplifies rounding of tiny gradients
+    assert kb.any() and float(norms[kb].max()) <= 3.0 * float(z["delta_norms"][kb].max()), "key.bias moved by more than its gradient noise allows"
     untouched = "task_layer.nlvr2.0.weight"
     assert torch.equal(after[untouched], P0[untouched]), "a head that received no gradient must not be decayed (torch skips grad=None)"
 
