@@ -62,19 +62,43 @@ __device__ __forceinline__ void as_load_outer(const float* __restrict__ g, long 
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) as_split8(ld4(p + 16 * ks), ld4(p + 16 * ks + 4), sc, hi[ks], lo[ks]);
 }
-// rows [0, nrows) x 64 fp32 columns of a strided global matrix -> (hi, lo) LDS images
-__device__ __forceinline__ void as_stage(unsigned char* __restrict__ hi, unsigned char* __restrict__ lo, const float* __restrict__ src, long ld, int nrows, int tid,
-                                         int nthreads) {
-  for (int e = tid; e < nrows * 16; e += nthreads) {
-    const int r = e >> 4, c = (e & 15) * 4;
-    const float4 v = ld4(src + (long)r * ld + c);
-    uint2 h, l;
-    h.x = pack_bf16x2(v.x, v.y);
-    h.y = pack_bf16x2(v.z, v.w);
-    l.x = pack_bf16x2(v.x - h16lo_to_f32(h.x), v.y - h16hi_to_f32(h.x));
-    l.y = pack_bf16x2(v.z - h16lo_to_f32(h.y), v.w - h16hi_to_f32(h.y));
-    *reinterpret_cast<uint2*>(hi + r * AS_PITCH + c * 2) = h;
-    *reinterpret_cast<uint2*>(lo + r * AS_PITCH + c * 2) = l;
+// rows [0, nrows) x 64 fp32 columns of TWO strided global matrices -> their (hi, lo) LDS images.  Every thread requests a batch of up to 2 x AS_UB float4
+// (forward: 2 -- its register budget is 168 for three waves per SIMD; backward: 4) before it converts the first one: with one load per loop iteration (r06, first version) a thread's 16 loads per chunk were 16 SERIAL round trips -- a
+// third of the forward's time at S_pad = 192.
+__device__ __forceinline__ void as_store_split(unsigned char* __restrict__ hi, unsigned char* __restrict__ lo, int r, int c, const float4& v) {
+  uint2 h, l;
+  h.x = pack_bf16x2(v.x, v.y);
+  h.y = pack_bf16x2(v.z, v.w);
+  l.x = pack_bf16x2(v.x - h16lo_to_f32(h.x), v.y - h16hi_to_f32(h.x));
+  l.y = pack_bf16x2(v.z - h16lo_to_f32(h.y), v.w - h16hi_to_f32(h.y));
+  *reinterpret_cast<uint2*>(hi + r * AS_PITCH + c * 2) = h;
+  *reinterpret_cast<uint2*>(lo + r * AS_PITCH + c * 2) = l;
+}
+template <int AS_UB>
+__device__ __forceinline__ void as_stage2(unsigned char* __restrict__ hi0, unsigned char* __restrict__ lo0, const float* __restrict__ src0, long ld0,
+                                          unsigned char* __restrict__ hi1, unsigned char* __restrict__ lo1, const float* __restrict__ src1, long ld1, int nrows, int tid,
+                                          int nthreads) {
+  const int n = nrows * 16;
+  for (int e0 = tid; e0 < n; e0 += nthreads * AS_UB) {
+    float4 v0[AS_UB], v1[AS_UB];
+#pragma unroll
+    for (int u = 0; u < AS_UB; ++u) {
+      const int e = e0 + u * nthreads;
+      if (e < n) {
+        const int r = e >> 4, c = (e & 15) * 4;
+        v0[u] = ld4(src0 + (long)r * ld0 + c);
+        if (src1) v1[u] = ld4(src1 + (long)r * ld1 + c);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < AS_UB; ++u) {
+      const int e = e0 + u * nthreads;
+      if (e < n) {
+        const int r = e >> 4, c = (e & 15) * 4;
+        as_store_split(hi0, lo0, r, c, v0[u]);
+        if (src1) as_store_split(hi1, lo1, r, c, v1[u]);
+      }
+    }
   }
 }
 // A operand, row-major: rows row0 + l31, columns 16 ks + 8 half .. + 8
@@ -132,8 +156,9 @@ __device__ __forceinline__ void as_store_row(const f32x16 (&acc)[2], float* __re
 
 // ---------------------------------------------------------------------------------------------- forward
 // dynamic LDS: K hi | K lo | V hi | V lo (CK rows each) | bias_s[S_pad]
+// (second launch bound = waves per SIMD the register budget must allow: 3 = two 6-wave workgroups per CU at 96-row chunks)
 template <int NW>
-__global__ __launch_bounds__(64 * NW) void attn_fwd_split_kernel(const float* __restrict__ qkv, const float* __restrict__ key_bias, float* __restrict__ ctx,
+__global__ __launch_bounds__(64 * NW, 3) void attn_fwd_split_kernel(const float* __restrict__ qkv, const float* __restrict__ key_bias, float* __restrict__ ctx,
                                                                  bf16_t* __restrict__ ctx_hi, long ctx_lo, float* __restrict__ lse_out, int S_pad, int heads, int CK,
                                                                  float scale) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -168,8 +193,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_split_kernel(const float* __
       const int k0 = ch * CK, nk = min(CK, S_pad - k0);
       if (nchunks > 1 || round == 0) {
         __syncthreads();
-        as_stage(Kh, Kl, Kg + (long)k0 * ld, ld, nk, tid, 64 * NW);
-        as_stage(Vh, Vl, Vg + (long)k0 * ld, ld, nk, tid, 64 * NW);
+        as_stage2<2>(Kh, Kl, Kg + (long)k0 * ld, ld, Vh, Vl, Vg + (long)k0 * ld, ld, nk, tid, 64 * NW);
         __syncthreads();
       }
       if (active)
@@ -222,15 +246,21 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_split_kernel(const float* __
   }
 }
 
-static int as_waves(int NB) {          // waves per workgroup: the fewest idle wave-rounds, then the fewest rounds
-  int best = 4, best_cost = 1 << 30;
-  for (int nw = 4; nw <= 8; nw += 2) {
-    const int rounds = (NB + nw - 1) / nw, cost = rounds * nw * 16 + rounds;
-    if (cost < best_cost) { best_cost = cost; best = nw; }
-  }
-  return best;
+// measurement knobs (climb_set_option 23 / 24 / 25): rows of the inner operands resident per chunk (LDS = 4 planes x 144 B x rows: 192 rows = 111 KB = one
+// workgroup per CU, 96 rows = 55 KB = two), waves per workgroup of the forward / the backward (0 = as_waves)
+static int g_as_maxkeys = AS_MAXKEYS, g_as_nw_fwd = 0, g_as_nw_bwd = 0;
+void climb_attn_split_set(int key, int v) {
+  if (key == 23 && v >= 32 && v <= AS_MAXKEYS && v % 32 == 0) g_as_maxkeys = v;
+  if (key == 24 && (v == 0 || v == 4 || v == 6 || v == 8)) g_as_nw_fwd = v;
+  if (key == 25 && (v == 0 || v == 4 || v == 6 || v == 8)) g_as_nw_bwd = v;
 }
-static int as_chunk(int S_pad) { return S_pad <= AS_MAXKEYS ? S_pad : ((S_pad / 32 + 1) / 2) * 32; }
+static int as_waves(int NB) {          // waves per workgroup: one round of query blocks where four waves do not suffice, and then eight -- the two idle waves of
+  return NB <= 4 ? 4 : 8;              // S_pad = 192 still stage (measured r06, tools/attn_split_bench.py: forward 62.5 / 58.0 us, backward 163.7 / 150.8 us with 6 / 8)
+}
+static int as_chunk(int S_pad) {          // equal chunks of whole 32-row blocks, at most g_as_maxkeys rows each
+  const int nb = S_pad / 32, nch = (S_pad + g_as_maxkeys - 1) / g_as_maxkeys;
+  return ((nb + nch - 1) / nch) * 32;
+}
 
 // qkv fp32 [B*S_pad, 3H] -> ctx fp32 [B*S_pad, H] (may be NULL) and / or ctx_split (hi plane; the lo plane ctx_lo elements behind; may be NULL), lse
 extern "C" int climb_attn_fwd_split(const float* qkv, const float* key_bias, float* ctx, void* ctx_split, long ctx_lo, float* lse, int B, int S_pad, int heads,
@@ -239,7 +269,7 @@ extern "C" int climb_attn_fwd_split(const float* qkv, const float* key_bias, flo
   const int CK = as_chunk(S_pad);
   if (CK > AS_MAXKEYS) return CLIMB_EUNSUPPORTED;
   const size_t lds = (size_t)4 * CK * AS_PITCH + (size_t)S_pad * sizeof(float);
-  const int nw = as_waves(S_pad / 32);
+  const int nw = g_as_nw_fwd ? g_as_nw_fwd : as_waves(S_pad / 32);
   static size_t lds_set[3] = {0, 0, 0};
   const float scale = 1.0f / sqrtf((float)head_dim);
 #define ASF(NW_, IDX_)                                                                                                                       \
@@ -265,7 +295,7 @@ extern "C" int climb_attn_fwd_split(const float* qkv, const float* key_bias, flo
 //     S = Q K^T, P, dP = dO V^T, dS;  dV^T += dO^T P,  dK^T += Q^T dS
 // dynamic LDS: X hi | X lo | Y hi | Y lo (CK rows each) | bias[S_pad] | lse[S_pad] | delta[S_pad]
 template <int PHASE, int NW>
-__global__ __launch_bounds__(64 * NW) void attn_bwd_split_kernel(const float* __restrict__ qkv, const float* __restrict__ key_bias, const float* __restrict__ dctx,
+__global__ __launch_bounds__(64 * NW, 2) void attn_bwd_split_kernel(const float* __restrict__ qkv, const float* __restrict__ key_bias, const float* __restrict__ dctx,
                                                                  const float* __restrict__ lse, const float* __restrict__ delta, float* __restrict__ dqkv,
                                                                  bf16_t* __restrict__ dqkv_hi, long dqkv_lo, int S_pad, int heads, int CK, float scale) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -316,8 +346,7 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_split_kernel(const float* __
       const int i0 = ch * CK, ni = min(CK, S_pad - i0);
       if (nchunks > 1 || round == 0) {
         __syncthreads();
-        as_stage(Xh, Xl, I1g + (long)i0 * I1ld, I1ld, ni, tid, 64 * NW);
-        as_stage(Yh, Yl, I2g + (long)i0 * I2ld, I2ld, ni, tid, 64 * NW);
+        as_stage2<4>(Xh, Xl, I1g + (long)i0 * I1ld, I1ld, Yh, Yl, I2g + (long)i0 * I2ld, I2ld, ni, tid, 64 * NW);
         __syncthreads();
       }
       if (!active) continue;
@@ -368,7 +397,7 @@ extern "C" int climb_attn_bwd_split(const float* qkv, const float* key_bias, con
   const int CK = as_chunk(S_pad);
   if (CK > AS_MAXKEYS) return CLIMB_EUNSUPPORTED;
   const size_t lds = (size_t)4 * CK * AS_PITCH + (size_t)3 * S_pad * sizeof(float);
-  const int nw = as_waves(S_pad / 32);
+  const int nw = g_as_nw_bwd ? g_as_nw_bwd : as_waves(S_pad / 32);
   static size_t lds_set[3] = {0, 0, 0};
   const float scale = 1.0f / sqrtf((float)head_dim);
 #define ASB(NW_, IDX_)                                                                                                                            \

@@ -349,6 +349,7 @@ void climb_skinny_set_probe(int v);
 int climb_nt256_get_grid();
 void climb_attn_set_1pp_grid(int v);
 void climb_ln_set_rpw(int v);
+void climb_attn_split_set(int key, int v);
 // current value of a library option (only the ones a caller has to put back: 9 = persistent NT grid); -1 = not readable
 int climb_tn_get_stagger();
 extern "C" int climb_get_option(int key) { return key == 9 ? climb_nt256_get_grid() : (key == 22 ? climb_tn_get_stagger() : -1); }
@@ -373,6 +374,7 @@ extern "C" int climb_set_option(int key, int value) {
   if (key == 20 && value >= 0) { climb_attn_set_1pp_grid(value); return CLIMB_OK; }
   if (key == 21 && value >= 1 && value <= 3) { climb_ln_set_rpw(value); return CLIMB_OK; }
   if (key == 22 && value >= 0 && value <= 116) { climb_tn_set_stagger(value); return CLIMB_OK; }
+  if (key >= 23 && key <= 25) { climb_attn_split_set(key, value); return CLIMB_OK; }          // split-operand attention: rows per LDS chunk, waves per workgroup (fwd / bwd)
   if (key == 6 && (value == 4 || value == 8)) { g_tn_waves = value; return CLIMB_OK; }
   if (key == 3 && value > 0) { g_tn_target = value; return CLIMB_OK; }
   return CLIMB_EINVAL;

@@ -661,7 +661,7 @@ def test_houlsby_adapters_vs_oracle_restatement(precision, tol):
 
 
 # ------------------------------------------------------------------------------------------------ ViLT-BERT (row F4)
-@pytest.mark.parametrize("precision,tol", [("fp32", TOL), (H16, 6e-2)])      # bf16: 24 layers of bf16 operands instead of 12 (measured: pooled 4.9e-2)
+@pytest.mark.parametrize("precision,tol", [(p_, TOL) for p_ in PARITY_MODES] + [(H16, 6e-2)])      # bf16: 24 layers of bf16 operands instead of 12 (measured: pooled 4.9e-2)
 def test_viltbert_vs_reference(golden_dir, precision, tol):
     """REF/modeling/viltbert.py: a frozen BERT-base's last hidden state replaces ViLT's word-embedding lookup.  Golden = the reference's
     own ViltBertContinualLearner (eval mode) on seeded weights; the BERT features are also checked against the CPU oracle."""
