@@ -261,9 +261,9 @@ def main():
         try:        # HBM bytes per launch / per step from the committed PMC passes (rocprofv3 cannot be driven from inside the timed run);
             # the file names the hash of the kernel sources it was measured on: a stale figure is reported as null, not repeated
             # (tests/test_host_logic.py::test_committed_traffic_figures_belong_to_this_tree keeps a late edit from doing that unnoticed)
-            tj = latest_traffic()
-            if tj.get("csrc_sha16") == csrc_hash() and args.precision in ("bf16", "fp16") and B == 64:
-                traffic = tj[dominant]["hbm_bytes_per_launch"]
+            tj = latest_traffic(args.precision)
+            if tj.get("csrc_sha16") == csrc_hash() and args.precision in ("bf16", "fp16", "bf16x3") and B == 64:
+                traffic = tj["gemm_bf16_nt"]["hbm_bytes_per_launch"]
                 if tj.get("step_sha16", step_hash()) == step_hash():
                     hbm_step = tj.get("hbm_bytes_per_step")
         except Exception:
@@ -503,9 +503,10 @@ def step_hash():
     return h.hexdigest()[:16]
 
 
-def latest_traffic():
+def latest_traffic(precision="bf16"):
     import glob
-    return json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_traffic.json")))[-1]))      # the latest round's passes
+    pat = "r[0-9][0-9]_traffic.json" if precision in ("bf16", "fp16") else f"r[0-9][0-9]_traffic_{precision}.json"      # (r06: the split-operand mode has its own passes)
+    return json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", pat)))[-1]))      # the latest round's passes
 
 
 def self_launch(n):

@@ -11,8 +11,10 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
-src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
+prec = sys.argv[2] if len(sys.argv) > 2 else "bf16"          # r06: `python tools/summarize_profile.py r06 bf16x3` summarises the split-operand mode's passes
+src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}" + ("" if prec == "bf16" else f"_{prec}"))
 dst = os.path.join(ROOT, "profiles")
+out_tag = tag if prec == "bf16" else f"{tag}_{prec}"          # (only the bf16 passes write rNN_traffic.json, the file bench.py's `roofline.traffic` reads)
 
 
 def short(name):
@@ -52,7 +54,7 @@ for t0, t1, k in inside:
     a[0] += 1
     a[1] += t1 - t0
 tot_ns = sum(a[1] for a in agg.values())
-with open(os.path.join(dst, f"{tag}_bf16_bs64_kernel_stats.csv"), "w") as f:
+with open(os.path.join(dst, f"{tag}_{prec}_bs64_kernel_stats.csv"), "w") as f:
     f.write("kernel,calls_per_step,avg_us,total_ms_per_step,percent\n")
     for k, (n, ns) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
         f.write(f"\"{k}\",{n / steps:.1f},{ns / n / 1e3:.2f},{ns / steps / 1e6:.4f},{100.0 * ns / tot_ns:.2f}\n")
@@ -84,7 +86,7 @@ for k in sorted(set(fetch) | set(write)):
     f_kb, w_kb = sum(fv) / len(fv), sum(wv) / len(wv)
     rows.append((k, len(fv) / steps_f, f_kb, w_kb, int((2 * f_kb + w_kb) * 1024)))
 rows.sort(key=lambda r: -r[4] * r[1])
-with open(os.path.join(dst, f"{tag}_hbm_traffic_per_kernel.csv"), "w") as f:
+with open(os.path.join(dst, f"{out_tag}_hbm_traffic_per_kernel.csv"), "w") as f:
     f.write("kernel,launches_per_step,FETCH_SIZE_KB_avg,WRITE_SIZE_KB_avg,hbm_bytes_per_launch_corrected,hbm_GB_per_step\n")
     for k, n, a, b, c in rows:
         f.write(f"\"{k}\",{n:.1f},{a:.1f},{b:.1f},{c},{c * n / 1e9:.3f}\n")
@@ -94,14 +96,15 @@ nt_avg = sum(n * c for n, c in nt) / max(1e-9, sum(n for n, _ in nt))
 import bench
 json.dump({"csrc_sha16": bench.csrc_hash(), "step_sha16": bench.step_hash(),
            "gemm_bf16_nt": {"hbm_bytes_per_launch": int(nt_avg), "launches_per_step": round(sum(n for n, _ in nt), 1),
-           "source": f"profiles/{tag}_hbm_traffic_per_kernel.csv: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes, FETCH_SIZE doubled (gfx950 "
+           "source": f"profiles/{out_tag}_hbm_traffic_per_kernel.csv: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes, FETCH_SIZE doubled (gfx950 "
                      "correction), averaged over every bf16 NT launch (all tile variants) of the passes' whole steps"},
            "hbm_bytes_per_step": int(step_bytes), "kernel_ms_per_step": round(total_ms, 3), "launches_per_step": round(launches_per_step, 1),
-           "steps_in_window": {"stats": steps, "fetch": steps_f, "write": steps_w}}, open(os.path.join(dst, f"{tag}_traffic.json"), "w"), indent=1)
+           "steps_in_window": {"stats": steps, "fetch": steps_f, "write": steps_w}},
+          open(os.path.join(dst, f"{tag}_traffic.json" if prec == "bf16" else f"{tag}_traffic_{prec}.json"), "w"), indent=1)
 # 3. MFMA / LDS counters for the GEMM kernels
 mf, dur = read_counters("pmc_mfma")
 ld, _ = read_counters("pmc_lds")
-with open(os.path.join(dst, f"{tag}_gemm_bf16_pmc_summary.csv"), "w") as f:
+with open(os.path.join(dst, f"{out_tag}_gemm_bf16_pmc_summary.csv"), "w") as f:
     f.write("kernel,launches,avg_duration_us_under_pmc,SQ_VALU_MFMA_BUSY_CYCLES,SQ_BUSY_CYCLES,SQ_WAVE_CYCLES,SQ_LDS_BANK_CONFLICT,SQ_LDS_IDX_ACTIVE,SQ_WAIT_INST_ANY,mfma_util_est\n")
     for k in sorted(mf):
         if "gemm_bf16" not in k and "attn" not in k and "tn_grouped" not in k:
