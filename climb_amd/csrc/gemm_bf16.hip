@@ -47,8 +47,8 @@ __device__ __forceinline__ void nt_store(const u32x4 (&r)[4], unsigned char* __r
 // 128 x 128 tile; waves arranged (8/MJ/2) x 2, each owning MJ*32 rows x 64 columns: MJ = 1 -> 8 waves (twice the waves per CU
 // hiding LDS-DMA / L2 latency for the same LDS footprint, at 1.5x the fragment reads per MFMA); MJ = 2 -> 4 waves.
 // (16 waves of 32 x 32 measured the same as 8 within noise on the multi-round shapes: 60 / 105 / 100 us against 62 / 103 / 102.)
-// SPLIT (r06, split.hip): A / B are the hi planes of (hi, lo) pairs, the lo planes a_lo / b_lo elements behind; the reduction walks three phases of
-// K / 64 k-tiles -- A {hi, hi, lo} against B {hi, lo, hi} (K % 64 == 0)
+// SPLIT (r06, split.hip): A / B are the hi planes of (hi, lo) pairs, the lo planes a_lo / b_lo elements behind; the reduction walks 3 K / 64 k-tiles --
+// the three products A {hi, hi, lo} x B {hi, lo, hi} of one k-tile after each other (K % 64 == 0)
 template <typename TO, int EPI, bool GLDS, int MJ, bool SPLIT = false>
 __global__ __launch_bounds__(512 / MJ)
 void gemm_bf16_nt_kernel(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ B, long ldb, TO* __restrict__ C, long ldc, int M, int N,
@@ -74,9 +74,9 @@ void gemm_bf16_nt_kernel(const bf16_t* __restrict__ A, long lda, const bf16_t* _
   const int nk = SPLIT ? 3 * ksp : (K + GB_BK - 1) / GB_BK;
   AuxRegs<EPI, 8 * MJ> ax;
   nt_aux_prefetch<EPI, 2, MJ>(ax, m0 + wm * (32 * MJ), n0 + wn * 64, M, N, aux, ldaux, aux2, ldaux2);
-#define KOFF(kt_) (SPLIT ? ((kt_) - ((kt_) >= 2 * ksp ? 2 * ksp : ((kt_) >= ksp ? ksp : 0))) * GB_BK : (kt_) * GB_BK)
-#define KPA(kt_) (SPLIT && (kt_) >= 2 * ksp ? A + a_lo : A)
-#define KPB(kt_) (SPLIT && (kt_) >= ksp && (kt_) < 2 * ksp ? B + b_lo : B)
+#define KOFF(kt_) (SPLIT ? ((kt_) / 3) * GB_BK : (kt_) * GB_BK)
+#define KPA(kt_) (SPLIT && (kt_) % 3 == 2 ? A + a_lo : A)
+#define KPB(kt_) (SPLIT && (kt_) % 3 == 1 ? B + b_lo : B)
   if constexpr (GLDS) {
     nt_glds<NW>(A, lda, m0, KOFF(0), M, smem);
     nt_glds<NW>(B, ldb, n0, KOFF(0), N, smem + GB_BM * GB_BK * 2);

@@ -81,7 +81,7 @@ struct Nt4Uni {             // wave-uniform state
   // DMA stream
   Nt4Walk dw;
   int dkt, dleft, nk;
-  int ksp;                       // r06, split operands: k-tiles per PHASE (nk = 3 ksp: A hi.B hi, A hi.B lo, A lo.B hi); unused otherwise
+  int ksp;                       // r06, split operands: logical k-tiles (nk = 3 ksp: A hi.B hi, A hi.B lo, A lo.B hi of each); unused otherwise
   unsigned alo, blo;             // ... and the byte distance from an operand's hi plane to its lo plane
   unsigned curA, curB;           // byte offset of the stream's k-tile: tile rows + k
   unsigned nxtA, nxtB;           // the NEXT window's (computed under this window's MFMAs, committed before its barrier)
@@ -144,7 +144,9 @@ __device__ __forceinline__ void nt4_dma(const Nt4Uni& u, const Nt4Lane& l, unsig
 // MFMA: the r04 kernel ran this bookkeeping there, a dozen scalar instructions and four taken branches (k-tile wrap, last tile, the walk's while loop), and
 // the measurement builds of option 18 put the pure MFMA stream of a launch at 43 cycles per MFMA instead of 32.  Now it is branch-free (selects), computes
 // the NEXT window's offsets in a filler position of slot 20 (under the MFMAs), and nt4_window_end commits them BEFORE the barrier.
-// r06 SPLIT: the stream's k-tile index d runs over three phases of ksp tiles; phase ph reads k-tile d - ph * ksp of A's {hi, hi, lo} and B's {hi, lo, hi} plane.
+// r06 SPLIT: the stream's k-tile index d runs over 3 ksp tiles, k-tile d / 3 of A's {hi, hi, lo} and B's {hi, lo, hi} plane for d % 3 = 0, 1, 2: the three
+// products of one k-tile follow each other, so the second fetch of an A hi / B hi tile hits the XCD's L2 (phase-major order -- all hi.hi tiles, then
+// all hi.lo ... -- fetched every plane from the fabric once per phase: 2 x 124 MB per launch against 45 MB of planes, profiles/r06_bf16x3_*).
 template <bool SPLIT = false>
 __device__ __forceinline__ void nt4_dma_next(Nt4Uni& u) {
   const int d1 = u.dkt + 1;
@@ -156,10 +158,10 @@ __device__ __forceinline__ void nt4_dma_next(Nt4Uni& u) {
   u.dw.tml = adv ? w.tml : u.dw.tml;
   u.dw.tn = adv ? w.tn : u.dw.tn;
   if constexpr (SPLIT) {
-    const bool p1 = u.dkt >= u.ksp, p2 = u.dkt >= 2 * u.ksp;
-    const unsigned kk = (unsigned)(u.dkt - (p2 ? 2 * u.ksp : (p1 ? u.ksp : 0))) * 128u;
-    u.nxtA = (unsigned)u.dw.m0() * u.lda2 + kk + (p2 ? u.alo : 0u);
-    u.nxtB = (unsigned)u.dw.n0() * u.ldb2 + kk + ((p1 && !p2) ? u.blo : 0u);
+    const unsigned kq = (unsigned)u.dkt / 3u, ph = (unsigned)u.dkt - 3u * kq;
+    const unsigned kk = kq * 128u;
+    u.nxtA = (unsigned)u.dw.m0() * u.lda2 + kk + (ph == 2u ? u.alo : 0u);
+    u.nxtB = (unsigned)u.dw.n0() * u.ldb2 + kk + (ph == 1u ? u.blo : 0u);
   } else {
     u.nxtA = (unsigned)u.dw.m0() * u.lda2 + (unsigned)u.dkt * 128u;
     u.nxtB = (unsigned)u.dw.n0() * u.ldb2 + (unsigned)u.dkt * 128u;

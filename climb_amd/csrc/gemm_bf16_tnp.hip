@@ -25,8 +25,8 @@ __device__ __forceinline__ int tnp_aswz(int row) { return (row & 3) << 2; }
 __device__ __forceinline__ int tnp_bswz(int row) { return ((row >> 1) & 1) << 2; }
 
 // SPLIT (r06, split.hip): the operands are (hi, lo) plane pairs stacked along the token dimension ([2 M, .]: the lo plane follows the hi plane), and the
-// reduction walks 3 M / 64 VIRTUAL tiles -- A {hi, hi, lo} against B {hi, lo, hi}: virtual tile v = t0 + t reads row tile v - (v >= mt ? mt : 0) of A
-// and v - (v >= 2 mt ? 2 mt : 0) of B (mt = M / 64).
+// reduction walks 3 M / 64 VIRTUAL tiles -- virtual tile v = t0 + t is product v % 3 of token tile v / 3: A {hi, hi, lo} against B {hi, lo, hi}, i.e. row tile
+// v / 3 (+ mt for the lo plane; mt = M / 64) -- the three products of a token tile follow each other, so the repeated hi images come from the XCD's L2.
 template <int NI, bool SPLIT = false>
 struct TnpStage {
   unsigned a_off[4];       // per lane: byte offset (from A + first token row of the split) of its 4 DMA sources of the A image
@@ -48,9 +48,9 @@ __device__ __forceinline__ void tnp_issue(const TnpStage<NI, SPLIT>& sg, const u
         unsigned char* buf = smem + (t & 1) * BUF;
         int ta = t, tb = t;
         if constexpr (SPLIT) {
-          const int v = sg.t0 + t;
-          ta = v - (v >= sg.mt ? sg.mt : 0);
-          tb = v - (v >= 2 * sg.mt ? 2 * sg.mt : 0);
+          const unsigned v = (unsigned)(sg.t0 + t), m = v / 3u, ph = v - 3u * m;
+          ta = (int)m + (ph == 2u ? sg.mt : 0);
+          tb = (int)m + (ph == 1u ? sg.mt : 0);
         }
         if constexpr (unit < 2) {
 #pragma unroll
@@ -475,8 +475,16 @@ __global__ __launch_bounds__(512) void gemm_bf16_tn_grouped_kernel(const TnGroup
     if (grp == 1) __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     int T = 0;
-    // (SPLIT: the column sums of A are those of its hi and lo planes once each -- the second phase re-reads the hi plane and is left out)
-    auto bias_at = [&](int t_) { return do_bias && (t_ % nbk) == tb && !(SPLIT && kt0 + t_ >= sg.mt && kt0 + t_ < 2 * sg.mt); };
+    // (SPLIT: the column sums of A are those of its hi and lo planes once each -- product 1 of a token tile re-reads the hi plane and is left out; token
+    // tiles, not virtual tiles, are dealt to the k-tile columns)
+    auto bias_at = [&](int t_) {
+      if constexpr (SPLIT) {
+        const unsigned v = (unsigned)(kt0 + t_), m = v / 3u;
+        return do_bias && (int)(m % (unsigned)nbk) == tk && (v - 3u * m) != 1u;
+      } else {
+        return do_bias && (t_ % nbk) == tb;
+      }
+    };
     for (; T + 2 < nk; ++T) tnp_ktile<NI, 0>(acc, a, bsum, bias_at(T), sg, A, a_tile, B, b_tile, smem, T, aoff, boff);
     tnp_ktile<NI, 1>(acc, a, bsum, bias_at(T), sg, A, a_tile, B, b_tile, smem, T, aoff, boff);
     tnp_ktile<NI, 2>(acc, a, bsum, bias_at(T + 1), sg, A, a_tile, B, b_tile, smem, T + 1, aoff, boff);
@@ -761,7 +769,7 @@ extern "C" int climb_gemm_bf16_tn_grouped(const void* probs, const void* items, 
 }
 
 // r06 (split.hip): the grouped launch over split operands.  A problem's A / B name the hi planes of (hi, lo) pairs stacked along the token dimension (the
-// lo plane directly behind the hi plane: [2 Mt, .]), its M field = 3 Mt (the three phases the planner cuts like any reduction) and `reserved` = Mt / 64.
+// lo plane directly behind the hi plane: [2 Mt, .]), its M field = 3 Mt (three products per token tile: 3 Mt / 64 reduction tiles the planner cuts like any reduction) and `reserved` = Mt / 64.
 // Whole 256 x 256 tiles only (no ragged problems); dbias += the column sums of A hi + A lo.
 extern "C" int climb_gemm_split_tn_grouped(const void* probs, const void* items, const void* first, int nwg, void* stream) {
   if (!probs || !items || !first || nwg <= 0) return CLIMB_EINVAL;

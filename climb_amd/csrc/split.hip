@@ -1,7 +1,7 @@
 // Split-operand arithmetic (r06): the parity-grade fast mode.  Every GEMM operand is a PAIR of 16-bit planes, x ~= hi + lo with hi = rn16(x) and
 // lo = rn16(x - hi), and a product is three MFMA passes, hi.hi + hi.lo + lo.hi, accumulated in fp32 -- with bf16 planes 16 significant bits per
 // operand (2^-17 relative rounding) at fp32's range, at a third of the 16-bit MFMA rate instead of the 1/16 of v_mfma_f32_32x32x2_f32.  The GEMM
-// kernels are the throughput mode's (gemm_bf16_nt4.hip, gemm_bf16.hip, gemm_bf16_tnp.hip) walking a reduction of three phases; this file holds
+// kernels are the throughput mode's (gemm_bf16_nt4.hip, gemm_bf16.hip, gemm_bf16_tnp.hip) walking a reduction of three products per k-tile; this file holds
 // the passes that PRODUCE the planes from fp32 tensors and the C entry points of the split GEMMs.
 //
 // Layout: a split tensor is [2][rows][ld] 16-bit, the hi plane first; the lo plane of a tensor of `rows` rows lies rows * ld elements behind
@@ -47,7 +47,7 @@ extern "C" int climb_gemm_bf16_tn(const void* A, long lda, const void* B, long l
 static inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 // C[M,N] (fp32) = epi(A B^T + bias), A = (hi, lo) planes [M,K] (lda; the lo plane a_lo elements behind), B likewise [N,K]: the reduction runs over three
-// phases of K -- A hi.B hi, A hi.B lo, A lo.B hi.  epi: 0 none, 2 + aux (fp32 residual [M,N]).  K % 64 == 0.
+// products per k-tile -- A hi.B hi, A hi.B lo, A lo.B hi.  epi: 0 none, 2 + aux (fp32 residual [M,N]).  K % 64 == 0.
 extern "C" int climb_gemm_split_nt(const void* A, long lda, long a_lo, const void* B, long ldb, long b_lo, float* C, long ldc, int M, int N, int K, const float* bias,
                                    int epi, const float* aux, long ldaux, void* stream) {
   if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || (K % GB_BK) || (N % 4) || (lda % 8) || (ldb % 8) || (ldc % 4) || (a_lo % 8) || (b_lo % 8) || !al16(A) || !al16(B) || !al16(C))

@@ -234,7 +234,7 @@ int climb_gemm_split_nt(const void* A, long lda, long a_lo, const void* B, long 
  * the path of shapes climb_gemm_split_tn_grouped does not take. */
 int climb_gemm_split_tn(const void* A, long lda, long a_lo, const void* B, long ldb, long b_lo, float* C, long ldc, int M, int N, int K, float* dbias, void* stream);
 /* climb_gemm_bf16_tn_grouped over split operands: a problem's A / B name the hi planes of pairs whose lo plane DIRECTLY follows ([2 Mt, .]); its M field
- * (and the M handed to climb_tn_grouped_plan) = 3 Mt, the three phases of the reduction, and its `reserved` field = Mt / 64.  N % 256 == K % 256 == 0. */
+ * (and the M handed to climb_tn_grouped_plan) = 3 Mt (three products per 64-token tile), and its `reserved` field = Mt / 64.  N % 256 == K % 256 == 0. */
 int climb_gemm_split_tn_grouped(const void* probs, const void* items, const void* first, int nwg, void* stream);
 
 /* HF:322-351 on split operands (csrc/attention_split.hip): the fp32 entry points' contract -- qkv / dctx fp32, lse and delta as above -- with every product as
