@@ -256,3 +256,99 @@ def test_attention_split_fwd_bwd(S_pad, valid):
     dq2 = torch.empty_like(dq_s)
     _lib.call("climb_attn_bwd_split", qd, bd, dd, lse, delta, None, dq2, M * 3 * H, B, S_pad, heads, d, _st())
     assert torch.equal(dq2, dq_s)
+
+
+# ------------------------------------------------------------------------------------------------ the bf16x3 ENGINE on every step path, against the fp32 mode
+def _both_modes(tasks=("vqa", "nlvr2")):
+    from tests.test_gpu_parity import make_model
+    a, _ = make_model(list(tasks), 42, precision="fp32")
+    b, _ = make_model(list(tasks), 42, precision="bf16x3")
+    return a, b
+
+
+def _grad_err(ga, gb):
+    worst = (0.0, None)
+    for n in ga:
+        if n.endswith("attention.key.bias"):          # identically zero in exact arithmetic: rounding noise on both sides
+            continue
+        assert n in gb, n
+        e = float((gb[n].double() - ga[n].double()).abs().max() / (ga[n].double().abs().max() + 1e-30))
+        worst = max(worst, (e, n))
+    assert set(ga) == set(gb)
+    return worst
+
+
+@pytest.mark.parametrize("path", ["autograd", "ewc", "frozen9", "accumulate", "frozen_encoder", "hipgraph", "optimizer_steps"])
+def test_bf16x3_engine_on_every_step_path_against_the_fp32_mode(path):
+    """The split-operand mode shares the fp32 mode's host code; this runs it down the paths the fixture tests do not take -- the reference-style
+    autograd path (model(...) -> torch loss -> loss.backward()), the EWC penalty, a frozen prefix (the backward stops at layer 9), gradient
+    accumulation without zero_grad (the Fisher pass's pattern), a frozen encoder, the captured hipGraph step and three AdamW steps (plane refresh
+    after every update) -- and compares every gradient (or parameter) with the exact-fp32 mode's: <= 3e-4 of each tensor's scale."""
+    import types
+    from oracle import vilt_oracle as vo
+    from tests.test_gpu_parity import _ewc_state, enc_to_inputs, grads_of
+    _dev()
+    ma, mb = _both_modes()
+    enc = vo.synthetic_encodings(3, seed=5, ragged_text=True)
+    images, texts = enc_to_inputs(enc)
+    target = vo.synthetic_vqa_targets(3, seed=5)
+    out = []
+    for model in (ma, mb):
+        model.train()
+        if path == "autograd":
+            model.zero_grad()
+            o = model(task_key="vqa", images=images, texts=texts)
+            loss = torch.nn.BCEWithLogitsLoss(reduction="mean")(o[1], target.to(o[1].device)) * target.shape[1]
+            loss.backward()
+            out.append((float(loss), o[1].detach().float().cpu(), grads_of(model)))
+        elif path == "ewc":
+            from climb_amd.cl_algorithms import EWC
+            ewc = EWC(types.SimpleNamespace(ewc_fisher_sample_percentage=0.01, ewc_loss_weight=100.0))
+            P = {n: p.detach().cpu() for n, p in model.named_parameters()}
+            fisher, star = _ewc_state(P, 5)
+            ewc.set_task_state("nlvr2", model, fisher, star)
+            loss, (_, logits), task, eloss = model.fused_forward_backward("vqa", images, texts, target, ewc)
+            out.append((float(loss) + float(eloss), logits.detach().float().cpu(), grads_of(model)))
+        elif path == "frozen9":
+            model.get_encoder().freeze_bottom_k_layers(9)
+            loss, (_, logits), _, _ = model.fused_forward_backward("vqa", images, texts, target)
+            G = grads_of(model)
+            assert all(".layer.8." not in n and "embeddings" not in n for n in G)
+            out.append((float(loss), logits.detach().float().cpu(), G))
+        elif path == "frozen_encoder":
+            model.get_encoder().freeze_all_weights()
+            loss, (_, logits), _, _ = model.fused_forward_backward("vqa", images, texts, target)
+            G = grads_of(model)
+            assert all(n.startswith("task_layer.") for n in G) and G
+            out.append((float(loss), logits.detach().float().cpu(), G))
+        elif path == "accumulate":
+            model.fused_forward_backward("vqa", images, texts, target)
+            loss, (_, logits), _, _ = model.fused_forward_backward("vqa", images, texts, target)          # no zero_grad: sums, like .grad
+            out.append((float(loss), logits.detach().float().cpu(), grads_of(model)))
+        elif path == "hipgraph":
+            for _ in range(2):
+                model._host.drop_grads()
+                loss, (_, logits), _, _ = model.graphed_forward_backward("vqa", images, texts, target)
+            torch.cuda.synchronize()
+            out.append((float(loss), logits.detach().float().cpu(), grads_of(model)))
+        else:
+            opt = model.create_optimizer({"lr": 1e-3, "weight_decay": 1e-2, "adam_epsilon": 1e-8})
+            opt.zero_grad()
+            for _ in range(3):
+                loss, (_, logits), _, _ = model.fused_forward_backward("vqa", images, texts, target, optimizer=opt)
+                opt.step()
+                opt.zero_grad()
+            out.append((float(loss), logits.detach().float().cpu(), {n: p.detach().float().cpu() for n, p in model.named_parameters()}))
+    (la, za, ga), (lb, zb, gb) = out
+    assert abs(la - lb) <= 2e-4 * abs(la), (la, lb)
+    assert _rel(zb, za) < 2e-4
+    assert torch.equal(zb.argmax(-1), za.argmax(-1))
+    if path == "optimizer_steps":
+        # Adam's first steps move every element by ~lr whatever its gradient's size: compare the parameters at the scale of lr
+        worst = max(float((gb[n] - ga[n]).abs().max()) for n in ga if not n.endswith("attention.key.bias"))
+        print(f"{path}: worst parameter difference after three steps {worst:.2e}")
+        assert worst < 2e-4          # 3 steps x lr 1e-3: a flipped update direction would be 2e-3
+    else:
+        worst = _grad_err(ga, gb)
+        print(f"{path}: worst per-tensor gradient difference {worst[0]:.2e} ({worst[1]})")
+        assert worst[0] < 3e-4
