@@ -182,6 +182,8 @@ class Workspace:
             self.so = [buf((M, r), adt) for _ in range(L)]
             self.dz = buf((M, r), adt)
             self.dy = buf((M, H), adt)
+            if sp:
+                self.dy_s = opbuf(M, H)          # d(sub-layer output) as GEMM operand planes
         self.ones = torch.ones((max(B, 8),), dtype=f32, device=dev)
         self.dw_plans = {}           # grouped weight-gradient launches: problem / item tables in HBM, built once per set of GEMMs
         self.red_plans = {}          # batched column reductions: segment tables in HBM
@@ -218,6 +220,7 @@ class ViltEngine:
         # "bf16x3" (r06): the fp32 code path with every encoder GEMM on split (hi, lo) bf16 operands, three MFMA products per k-step (csrc/split.hip)
         assert precision in ("fp32", "bf16", "fp16", "bf16x3")
         self.split = precision == "bf16x3"
+        self._force_f32 = False         # split mode, inside an adapter's bottleneck: its skinny products (0.1 % of a layer's FLOPs) run on the exact-fp32 GEMM
         self.h16 = None if precision == "fp32" else ("bf16" if self.split else precision)
         if self.h16 is not None:
             _lib.select_h16(self.h16)
@@ -405,7 +408,7 @@ class ViltEngine:
                   aux2=None, ldaux2=0):
         # split-K (atomic partial sums) only in the throughput mode: the fp32 parity mode stays run-to-run deterministic
         self._timed_call("gemm_f32", 2.0 * M * N * K, "climb_gemm_f32", A, sam, sak, Bm, sbn, sbk, C, ldc, M, N, K, bias, epi, aux, ldaux, aux_out,
-                         ldauxo, beta, aux2, ldaux2, 1 if self.precision == "bf16" else 0, _stream())
+                         ldauxo, beta, aux2, ldaux2, 1 if (self.precision == "bf16" or self.split) else 0, _stream())
 
     def _rank_update(self, dY, lddy, X, ldx, wname, M, N, K):
         """grad(W)[N, K] += dY[M, N]^T X[M, K] for M = batch rows (csrc/heads.hip); exact fp32"""
@@ -429,9 +432,9 @@ class ViltEngine:
         _lib.call("climb_split_f32", src, C, dst, C, M * C, M, C, mode, aux, C, _stream())
 
     def linear_fwd(self, X, wname, bname, Y, M, N, K, epi=EPI_NONE, aux=None, aux_out=None, aux2=None, out_f32=False):
-        if self.split:
+        if self.split and not self._force_f32:
             if epi not in (EPI_NONE, EPI_RESID):
-                raise NotImplementedError("bf16x3: adapters / fused activation epilogues are not built for split operands")
+                raise NotImplementedError("bf16x3: fused activation epilogues are not built for split operands")
             self._split_nt(X, K, M * K, self.sp(wname), K, self.layout.total, Y, N, M, N, K, self.p(bname) if bname else None, epi, aux, N)
         elif self.precision == "fp32":
             self._gemm_f32(X, K, 1, self.p(wname), K, 1, Y, N, M, N, K, self.p(bname) if bname else None, epi, aux, N, aux_out, N, 0.0, aux2, N)
@@ -440,9 +443,9 @@ class ViltEngine:
 
     def linear_dx(self, dY, wname, dX, M, N, K, epi=EPI_NONE, aux=None):
         """dX[M,K] = dY[M,N] @ W[N,K]   (epi DGELU multiplies by gelu'(aux[M,K]))"""
-        if self.split:
+        if self.split and not self._force_f32:
             if epi not in (EPI_NONE, EPI_RESID):
-                raise NotImplementedError("bf16x3: adapters / fused activation epilogues are not built for split operands")
+                raise NotImplementedError("bf16x3: fused activation epilogues are not built for split operands")
             self._split_nt(dY, N, M * N, self.spt(wname), N, self._shadow_t.numel() // 2, dX, K, M, K, N, None, epi, aux, K)
         elif self.precision == "fp32":
             self._gemm_f32(dY, N, 1, self.p(wname), 1, K, dX, K, M, K, N, None, epi, aux, K)
@@ -456,7 +459,7 @@ class ViltEngine:
             if want_b:
                 self.bias_grad(dY, self.adt, bname, M, N, ws)
             return
-        if self.split:          # (shapes the grouped launch does not take: three ordinary weight-gradient launches; the bias gradient rides in two of them)
+        if self.split and not self._force_f32:          # (shapes the grouped launch does not take: three ordinary weight-gradient launches; the bias gradient rides in two of them)
             self._timed_call("gemm_split_tn", 2.0 * M * N * K, "climb_gemm_split_tn", dY, N, M * N, X, K, M * K, self.g(wname), K, M, N, K,
                              self.g(bname) if want_b else None, _stream())
         elif self.precision == "fp32":
@@ -758,8 +761,6 @@ class ViltEngine:
         r = self.layout.adapters[ad] if ad is not None else 0
         prune = self.cls_only_last and ad is None
         odt = self.odt
-        if self.split and ad is not None:
-            raise NotImplementedError("bf16x3: adapters are not built for split operands")
         for i in range(cfg["layers"]):
             l = f"{ENC}encoder.layer.{i}."
             x = ws.x[i]
@@ -782,8 +783,12 @@ class ViltEngine:
                                  None, 0, ws.uc, Fd)
                 self._lin_fwd_ld(ws.ac, Fd, l + "output.dense.weight", l + "output.dense.bias", ws.xLc, H, B, H, Fd, EPI_RESID, ws.h1c, H, out_f32=True)
                 continue
-            if self.split:
+            if self.split and ad is None:
                 self.linear_fwd_resid(ws.ctx_s[i], l + "attention.output.dense.weight", l + "attention.output.dense.bias", ws.h1[i], M, H, H, x)
+            elif self.split:          # h1 = x + y + up(silu(down(y))), y = Wo ctx + bo in fp32
+                a_ = f"{l}attention.output.adapters.{ad}."
+                self.linear_fwd(ws.ctx_s[i], l + "attention.output.dense.weight", l + "attention.output.dense.bias", ws.ya[i], M, H, H)
+                self.adapter_fwd(a_, ws.ya[i], x, ws.za[i], ws.sa[i], ws.h1[i], M, H, r)
             elif ad is None:
                 self.linear_fwd_resid(ws.ctx[i], l + "attention.output.dense.weight", l + "attention.output.dense.bias", ws.h1[i], M, H, H, x)
             else:   # h1 = x + y + up(silu(down(y))),  y = Wo ctx + bo
@@ -1183,7 +1188,7 @@ class ViltEngine:
                 else:
                     dy = self.adapter_backward(ws, f"{l}attention.output.adapters.{ad}.", ws.sa[i], ws.za[i], ws.ya[i], M, H, r,
                                                dhc(i), ws.dz_l[2 * i] if G else ws.dz, dw)
-                    dw(dy, ws.ctx[i], l + "attention.output.dense.weight", M, H, H, l + "attention.output.dense.bias", ws)
+                    dw(dy, ws.ctx_s[i] if self.split else ws.ctx[i], l + "attention.output.dense.weight", M, H, H, l + "attention.output.dense.bias", ws)
                 self.linear_dx(dy, l + "attention.output.dense.weight", ws.dctx, M, H, H)
             dqkv = dqkv_(i)
             if self.split:          # d(qkv) leaves the kernel as the operand planes of the two QKV gradient GEMMs (nothing else reads it)
@@ -1258,6 +1263,14 @@ class ViltEngine:
     def adapter_fwd(self, a_: str, y, resid, z_pre, s_act, out, M, H, r):
         """out = resid + y + up(silu(down(y))), saving z = down(y) and s = silu(z) for the backward.  16-bit mode: one launch
         (`climb_adapter_fwd_bf16`) where the shape allows, else -- and always in the fp32 mode -- the two skinny GEMMs."""
+        if self.split:          # y, z, s are fp32 here: the bottleneck's two skinny products on the exact-fp32 GEMM (the fp32 mode's launches)
+            self._force_f32 = True
+            try:
+                self.linear_fwd(y, a_ + "adapter_down.0.weight", a_ + "adapter_down.0.bias", s_act, M, r, H, EPI_SILU, None, z_pre)
+                self.linear_fwd(s_act, a_ + "adapter_up.weight", a_ + "adapter_up.bias", out, M, H, r, EPI_RESID2, resid, None, y, out_f32=True)
+            finally:
+                self._force_f32 = False
+            return
         if self.precision != "fp32" and H % 128 == 0 and r % 16 == 0 and r <= 64 and _FUSED_ADAPTER:
             _lib.call("climb_adapter_fwd_bf16", y, H, resid, H, self.sp(a_ + "adapter_down.0.weight"), self.p(a_ + "adapter_down.0.bias"),
                       self.sp(a_ + "adapter_up.weight"), self.p(a_ + "adapter_up.bias"), z_pre, s_act, r, out, H, M, H, r, _stream())
@@ -1269,6 +1282,16 @@ class ViltEngine:
         """Backward of out = resid + y + up(silu(down(y))) given d(out) in ws.dres (fp32) / `dout_c` (operand dtype).
         Accumulates the adapter's parameter gradients (`dw`: now, or recorded for the group's launch -- then `dout_c` and `dz` are per-layer
         buffers that stay valid until it) and returns d(y) = d(out) + down^T(silu'(z) * up^T d(out))."""
+        if self.split and not self._force_f32:
+            # the fp32 mode's launches on the fp32 residual gradient (exact-fp32 GEMM, immediate weight gradients), then d(y) as the operand planes the
+            # sub-layer's input- and weight-gradient GEMMs read
+            self._force_f32 = True
+            try:
+                self.adapter_backward(ws, a_, s_act, z_pre, y_in, M, H, r, ws.dres, ws.dz, self.linear_dw)
+            finally:
+                self._force_f32 = False
+            self.split_of(ws.dy, ws.dy_s, M, H)
+            return ws.dy_s
         dout_c = ws.dres_c if dout_c is None else dout_c
         dz = ws.dz if dz is None else dz
         dw = self.dw_async if dw is None else dw
