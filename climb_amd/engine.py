@@ -257,6 +257,8 @@ class ViltEngine:
         self._shadow_t = None
         self._shadow_version = -1
         self._shadow_stale = False
+        self._t_fresh = self._t_updated = None
+        self._t_sub = {}
         self._ewc_ws = None
         self._bce_ws = None
         self._head_ws: Dict[tuple, dict] = {}
