@@ -47,10 +47,26 @@ __global__ __launch_bounds__(256) void adapter_kernel(const bf16_t* __restrict__
   unsigned char* turn = smem + big + AD_ROWS * 64 * 2 + wid * 4096;
   // ---- stage the y tile (rows past M re-read the last row: computed, never stored)
   const int chunks = H / 8;                                        // 16-byte chunks per row
-  for (int idx = tid; idx < AD_ROWS * chunks; idx += 256) {
-    const int row = idx / chunks, c = idx - row * chunks;
-    const int gr = m0 + row < M ? m0 + row : M - 1;
-    *reinterpret_cast<ad_u32x4*>(smem + row * ystride + c * 16) = *reinterpret_cast<const ad_u32x4*>(y + (long)gr * ldy + c * 8);
+  // (r06) six loads in flight per thread before the first LDS write: one load per loop iteration made the 12 chunks a thread stages 12 serial round trips
+  for (int i0 = tid; i0 < AD_ROWS * chunks; i0 += 256 * 6) {
+    ad_u32x4 v[6];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+      const int idx = i0 + q * 256;
+      if (idx < AD_ROWS * chunks) {
+        const int row = idx / chunks, c = idx - row * chunks;
+        const int gr = m0 + row < M ? m0 + row : M - 1;
+        v[q] = *reinterpret_cast<const ad_u32x4*>(y + (long)gr * ldy + c * 8);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+      const int idx = i0 + q * 256;
+      if (idx < AD_ROWS * chunks) {
+        const int row = idx / chunks, c = idx - row * chunks;
+        *reinterpret_cast<ad_u32x4*>(smem + row * ystride + c * 16) = v[q];
+      }
+    }
   }
   __syncthreads();
   // ---- down-projection: wave w owns k in [w H/4, (w+1) H/4)
