@@ -190,6 +190,32 @@ __device__ __forceinline__ void adamw_update(float& p, float& m, float& v, float
 #define EPI_GELUD 8   // aux_out = gelu'(acc + bias) ; C = gelu(acc + bias)        (r05: the backward multiplies by the SAVED derivative, 16-bit outputs only)
 #define EPI_MUL 9     // C = acc * aux               (aux has C's dtype: the derivative EPI_GELUD saved)
 
+// r06, split-operand mode (nt4 epilogues of split.hip's GEMMs; fp32 C / aux):
+#define EPI_GELU_SP 10  // C = acc + bias (fp32 pre-activation u);  aux_out (split planes) = gelu(u)
+#define EPI_DGELU_SP 11 // aux_out (split planes) = acc * gelu'(aux), aux = fp32 u;  C is not written
+// erf-form GELU and its derivative for those epilogues: Abramowitz-Stegun 7.1.26, erfc(z) = (a1 t + .. + a5 t^5) exp(-z^2), t = 1 / (1 + p z), |error| <=
+// 1.5e-7 -- fp32's own resolution -- in 17 / 19 operations per element (erff / expf of the exact forms above cost ~40: more than the MFMA time of the window
+// a 32 x 32 block is drained in).  Phi(x) for x < 0 is taken as erfc(|x| / sqrt 2) / 2 directly, so the tail has no 1 - (1 - eps) cancellation; the
+// derivative shares the exponential: gelu'(x) = Phi(x) + x exp(-x^2 / 2) / sqrt(2 pi).
+__device__ __forceinline__ void gelu_as_parts(float x, float& cdf, float& e) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+  const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+  e = __builtin_amdgcn_exp2f(x * x * -0.72134752044448170368f);          // exp(-x^2 / 2) = 2^(-x^2 log2(e) / 2)
+  const float q = 0.5f * poly * e;                                        // Phi(-|x|)
+  cdf = x < 0.f ? q : 1.0f - q;
+}
+__device__ __forceinline__ float gelu_as(float x) {
+  float cdf, e;
+  gelu_as_parts(x, cdf, e);
+  return x * cdf;
+}
+__device__ __forceinline__ float dgelu_as(float x) {
+  float cdf, e;
+  gelu_as_parts(x, cdf, e);
+  return fmaf(x * 0.39894228040143267794f, e, cdf);
+}
+
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 __device__ __forceinline__ float dsilu_f(float x) {
   const float sg = 1.0f / (1.0f + __expf(-x));

@@ -83,6 +83,7 @@ struct Nt4Uni {             // wave-uniform state
   int dkt, dleft, nk;
   int ksp;                       // r06, split operands: logical k-tiles (nk = 3 ksp: A hi.B hi, A hi.B lo, A lo.B hi of each); unused otherwise
   unsigned alo, blo;             // ... and the byte distance from an operand's hi plane to its lo plane
+  unsigned olo;                  // (EPI_GELU_SP / EPI_DGELU_SP) byte distance from aux_out's hi plane to its lo plane
   unsigned curA, curB;           // byte offset of the stream's k-tile: tile rows + k
   unsigned nxtA, nxtB;           // the NEXT window's (computed under this window's MFMAs, committed before its barrier)
   unsigned dma_off, rd_off;      // stage offsets: DMA destination / fragment reads of this window
@@ -95,6 +96,8 @@ __device__ __forceinline__ bf16x8 ntp_frag_(const unsigned char* p) { return as_
 
 template <int EPI> struct Nt4Aux { };
 template <> struct Nt4Aux<EPI_RESID> { f32x4 v[4]; };
+template <> struct Nt4Aux<EPI_DGELU_SP> { f32x4 v[4]; };          // (r06) fp32 pre-activation, fetched like the fp32 residual
+constexpr bool nt4_aux_f32(int epi) { return epi == EPI_RESID || epi == EPI_DGELU_SP; }
 template <> struct Nt4Aux<EPI_DGELU> { u32x2 v[4]; };
 template <> struct Nt4Aux<EPI_MUL> { u32x2 v[4]; };
 
@@ -110,6 +113,9 @@ template <int EPI> __device__ __forceinline__ void nt4_aux_load(Nt4Aux<EPI>&, in
 template <> __device__ __forceinline__ void nt4_aux_load<EPI_RESID>(Nt4Aux<EPI_RESID>& a, int p, const Nt4Uni& u, const Nt4Lane& l, unsigned soff) {
   nt4_ld128(a.v[p], u.rx, l.vx, soff);
 }
+template <> __device__ __forceinline__ void nt4_aux_load<EPI_DGELU_SP>(Nt4Aux<EPI_DGELU_SP>& a, int p, const Nt4Uni& u, const Nt4Lane& l, unsigned soff) {
+  nt4_ld128(a.v[p], u.rx, l.vx, soff);
+}
 template <> __device__ __forceinline__ void nt4_aux_load<EPI_DGELU>(Nt4Aux<EPI_DGELU>& a, int p, const Nt4Uni& u, const Nt4Lane& l, unsigned soff) {
   nt4_ld64(a.v[p], u.rx, l.vx, soff);
 }
@@ -121,6 +127,7 @@ template <> __device__ __forceinline__ u32x2 nt4_auxw<EPI_DGELU>(const Nt4Aux<EP
 // pins the registers of asm loads behind a wait (the compiler must not touch them between load and wait)
 template <int EPI> __device__ __forceinline__ void nt4_pin(Nt4Aux<EPI>&) {}
 template <> __device__ __forceinline__ void nt4_pin<EPI_RESID>(Nt4Aux<EPI_RESID>& a) { asm volatile("" : "+v"(a.v[0]), "+v"(a.v[1]), "+v"(a.v[2]), "+v"(a.v[3])::"memory"); }
+template <> __device__ __forceinline__ void nt4_pin<EPI_DGELU_SP>(Nt4Aux<EPI_DGELU_SP>& a) { asm volatile("" : "+v"(a.v[0]), "+v"(a.v[1]), "+v"(a.v[2]), "+v"(a.v[3])::"memory"); }
 template <> __device__ __forceinline__ void nt4_pin<EPI_DGELU>(Nt4Aux<EPI_DGELU>& a) { asm volatile("" : "+v"(a.v[0]), "+v"(a.v[1]), "+v"(a.v[2]), "+v"(a.v[3])::"memory"); }
 template <> __device__ __forceinline__ void nt4_pin<EPI_MUL>(Nt4Aux<EPI_MUL>& a) { asm volatile("" : "+v"(a.v[0]), "+v"(a.v[1]), "+v"(a.v[2]), "+v"(a.v[3])::"memory"); }
 
@@ -269,6 +276,24 @@ __device__ __forceinline__ void nt4_unit(f32x4& v, u32x2& hold, const f32x4& bia
     v += bias;
     v += ax.v[p];
     nt4_store<TO>(v, u.rc, l.vc, csoff);
+  } else if constexpr (EPI == EPI_GELU_SP || EPI == EPI_DGELU_SP) {
+    // r06, split-operand mode: the activation's (hi, lo) operand planes leave from here (the pass that read the fp32 result back is gone)
+    static_assert(sizeof(TO) == 4, "split-mode epilogues have fp32 C");
+    const unsigned osoff = u.obase + rowoff * u.ldo_b + (unsigned)(bj * 64);
+    if constexpr (EPI == EPI_GELU_SP) {
+      v += bias;
+      nt4_store<float>(v, u.rc, l.vc, csoff);          // u: the backward evaluates gelu' on it
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = gelu_as(v[k]);
+    } else {
+      const f32x4 uu = ax.v[p];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] *= dgelu_as(uu[k]);
+    }
+    u32x2 h = {pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)};
+    u32x2 lo = {pack_bf16x2(v.x - h16lo_to_f32(h[0]), v.y - h16hi_to_f32(h[0])), pack_bf16x2(v.z - h16lo_to_f32(h[1]), v.w - h16hi_to_f32(h[1]))};
+    __builtin_amdgcn_raw_buffer_store_b64(h, u.ro, l.vo2, osoff, 0);
+    __builtin_amdgcn_raw_buffer_store_b64(lo, u.ro, l.vo2, osoff + u.olo, 0);
   } else if constexpr (EPI == EPI_MUL) {
     const u32x2 w = ax.v[p];
     v[0] *= h16lo_to_f32(w[0]); v[1] *= h16hi_to_f32(w[0]); v[2] *= h16lo_to_f32(w[1]); v[3] *= h16hi_to_f32(w[1]);
@@ -309,7 +334,7 @@ __device__ __forceinline__ void nt4_unit(f32x4& v, u32x2& hold, const f32x4& bia
 // operand loads of block B of the finished tile, piece p
 template <int EPI>
 __device__ __forceinline__ void nt4_aux_issue(Nt4Aux<EPI>& ax, int p, int bi, int bj, const Nt4Uni& u, const Nt4Lane& l) {
-  if constexpr (EPI == EPI_RESID) nt4_aux_load<EPI>(ax, p, u, l, u.xbase + (unsigned)(bi * 32 + 8 * p) * u.ldx_b + (unsigned)(bj * 128));
+  if constexpr (nt4_aux_f32(EPI)) nt4_aux_load<EPI>(ax, p, u, l, u.xbase + (unsigned)(bi * 32 + 8 * p) * u.ldx_b + (unsigned)(bj * 128));
   if constexpr (EPI == EPI_DGELU || EPI == EPI_MUL) nt4_aux_load<EPI>(ax, p, u, l, u.xbase + (unsigned)(bi * 32 + 8 * p) * u.ldx_b + (unsigned)(bj * 64));
 }
 __device__ __forceinline__ void nt4_bias_issue(f32x4 (&bias)[3], int j, const Nt4Uni& u, const Nt4Lane& l) { nt4_ld128(bias[j], u.rbias, l.vb, u.bbase + (unsigned)(j * 128)); }
@@ -319,7 +344,7 @@ __device__ __forceinline__ void nt4_set_prev(Nt4Uni& u, int m0, int n0) {
   const unsigned wr = u.wid >> 1, wc = u.wid & 1;
   const unsigned mrow = (unsigned)m0 + wr * 96u, ncol = (unsigned)n0 + wc * 96u;
   u.cbase = mrow * u.ldc_b + ncol * (unsigned)sizeof(TO);
-  u.xbase = mrow * u.ldx_b + ncol * (EPI == EPI_RESID ? 4u : 2u);
+  u.xbase = mrow * u.ldx_b + ncol * (nt4_aux_f32(EPI) ? 4u : 2u);
   u.obase = mrow * u.ldo_b + ncol * 2u;
   u.bbase = ncol * 4u;
 }
@@ -478,7 +503,7 @@ __device__ __forceinline__ void nt4_final(f32x16 (&accP)[3][3], f32x4 (&rbk)[4],
 
 template <typename TO, int EPI, int PROBE = 0>
 __global__ __launch_bounds__(256) void gemm_bf16_nt4_kernel(const bf16_t* A, long lda, const bf16_t* B, long ldb, TO* C, long ldc, int M, int N, int K, const float* bias_g,
-                                                            const void* aux_g, long ldaux, bf16_t* aux_out, long ldauxo, int probe, unsigned a_lo_b = 0, unsigned b_lo_b = 0) {
+                                                            const void* aux_g, long ldaux, bf16_t* aux_out, long ldauxo, int probe, unsigned a_lo_b = 0, unsigned b_lo_b = 0, unsigned o_lo_b = 0) {
   constexpr bool SPLIT = (PROBE & 32) != 0;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63;
@@ -492,6 +517,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt4_kernel(const bf16_t* A, lon
   u.nk = SPLIT ? 3 * u.ksp : u.ksp;
   u.alo = a_lo_b;
   u.blo = b_lo_b;
+  u.olo = o_lo_b;
   u.probe = probe;          // (r04's run-time vmcnt experiments are gone; the compile-time measurement builds remain)
   u.stag = u.wid % 3u;
   // resources: raw buffers (stride 0), range = 2 GB (the launcher checks sizes); a missing bias reads as zeros through an empty range
@@ -504,7 +530,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt4_kernel(const bf16_t* A, lon
   u.lda2 = (unsigned)lda * 2u;
   u.ldb2 = (unsigned)ldb * 2u;
   u.ldc_b = (unsigned)ldc * (unsigned)sizeof(TO);
-  u.ldx_b = (unsigned)ldaux * (EPI == EPI_RESID ? 4u : 2u);
+  u.ldx_b = (unsigned)ldaux * (nt4_aux_f32(EPI) ? 4u : 2u);
   u.ldo_b = (unsigned)ldauxo * 2u;
 #pragma unroll
   for (int j = 0; j < 6; ++j) {
@@ -525,7 +551,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt4_kernel(const bf16_t* A, lon
     l.wr0 = base + NT4_TURN + u.wid * 4096 + l31 * 128 + ((half ^ (l31 & 7)) << 4);
     l.rd = r8 * 128 + (((sl ^ r8) & 7) << 4);
     l.vc = (unsigned)r8 * u.ldc_b + sl * 4 * (unsigned)sizeof(TO);
-    l.vx = (unsigned)r8 * u.ldx_b + sl * (EPI == EPI_RESID ? 16u : 8u);
+    l.vx = (unsigned)r8 * u.ldx_b + sl * (nt4_aux_f32(EPI) ? 16u : 8u);
     l.vo2 = (unsigned)r8 * u.ldo_b + sl * 8u;
     l.vb = sl * 16u;
   }
@@ -694,11 +720,12 @@ int climb_nt4_launch(const bf16_t* A, long lda, const bf16_t* B, long ldb, void*
 // r06: the same kernel over split operands (split.hip): A / B name the hi planes, the lo planes lie a_lo / b_lo ELEMENTS behind; fp32 C, epilogues NONE / RESID.
 // K = the logical reduction depth (the kernel walks 3 K / 64 k-tiles).
 int climb_nt4_split_launch(const bf16_t* A, long lda, long a_lo, const bf16_t* B, long ldb, long b_lo, float* C, long ldc, int M, int N, int K, const float* bias,
-                           int epi, const void* aux, long ldaux, hipStream_t st) {
+                           int epi, const void* aux, long ldaux, hipStream_t st, bf16_t* aux_out, long ldauxo, long o_lo) {
   if (g_nt4 == 0) return CLIMB_EUNSUPPORTED;
   if ((M % NT4_T) || (N % NT4_T) || ((M / NT4_T) % 8) || (K % GB_BK) || 3 * K < 10 * GB_BK) return CLIMB_EUNSUPPORTED;
   const long lim = 1L << 31;
-  if (((long)M * lda + K + a_lo) * 2 >= lim || ((long)N * ldb + K + b_lo) * 2 >= lim || (long)M * ldc * 4 >= lim || (long)M * ldaux * 4 >= lim || a_lo < 0 || b_lo < 0)
+  if (((long)M * lda + K + a_lo) * 2 >= lim || ((long)N * ldb + K + b_lo) * 2 >= lim || (long)M * ldc * 4 >= lim || (long)M * ldaux * 4 >= lim || a_lo < 0 || b_lo < 0 ||
+      ((long)M * ldauxo + o_lo) * 2 >= lim || o_lo < 0)
     return CLIMB_EUNSUPPORTED;
   const int tiles = (M / NT4_T) * (N / NT4_T);
   int grid = g_nt4_grid > 0 ? (g_nt4_grid / 8) * 8 : 256;
@@ -713,11 +740,13 @@ int climb_nt4_split_launch(const bf16_t* A, long lda, long a_lo, const bf16_t* B
       configured = true;                                                                                                                                    \
     }                                                                                                                                                       \
     hipLaunchKernelGGL((gemm_bf16_nt4_kernel<float, E, 32>), dim3(nwg), dim3(256), NT4_LDS, st, A, lda, B, ldb, C, ldc, M, N, K, bias, aux, ldaux,          \
-                       (bf16_t*)nullptr, 0L, 0, (unsigned)(a_lo * 2), (unsigned)(b_lo * 2));                                                                \
+                       aux_out, ldauxo, 0, (unsigned)(a_lo * 2), (unsigned)(b_lo * 2), (unsigned)(o_lo * 2));                                                      \
     return CLIMB_OK;                                                                                                                                        \
   } while (0)
   if (epi == EPI_RESID) L4S(EPI_RESID);
   if (epi == EPI_NONE) L4S(EPI_NONE);
+  if (epi == EPI_GELU_SP && aux_out && C) L4S(EPI_GELU_SP);
+  if (epi == EPI_DGELU_SP && aux_out && aux) L4S(EPI_DGELU_SP);
 #undef L4S
   return CLIMB_EUNSUPPORTED;
 }

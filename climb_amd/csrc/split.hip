@@ -38,7 +38,7 @@ extern "C" int climb_split_f32(const float* x, long ldx, void* y, long ldy, long
 }
 
 int climb_nt4_split_launch(const bf16_t* A, long lda, long a_lo, const bf16_t* B, long ldb, long b_lo, float* C, long ldc, int M, int N, int K, const float* bias,
-                           int epi, const void* aux, long ldaux, hipStream_t st);
+                           int epi, const void* aux, long ldaux, hipStream_t st, bf16_t* aux_out = nullptr, long ldauxo = 0, long o_lo = 0);
 int climb_nt_split_generic(const bf16_t* A, long lda, long a_lo, const bf16_t* B, long ldb, long b_lo, float* C, long ldc, int M, int N, int K, const float* bias,
                            int epi, const float* aux, long ldaux, hipStream_t st);
 
@@ -59,6 +59,26 @@ extern "C" int climb_gemm_split_nt(const void* A, long lda, long a_lo, const voi
   if (rc == CLIMB_OK) { LAUNCH_CHECK(); return CLIMB_OK; }
   if (rc != CLIMB_EUNSUPPORTED) return rc;
   return climb_nt_split_generic((const bf16_t*)A, lda, a_lo, (const bf16_t*)B, ldb, b_lo, C, ldc, M, N, K, bias, epi, aux, ldaux, st);
+}
+
+// The MLP's two activation epilogues on the four-wave kernel (HF:393, :397-414): epi 10: C (fp32 [M,N]) = A B^T + bias, out (split planes [M,N], ldo; the lo plane
+// o_lo elements behind) = gelu(C); epi 11: out = (A B^T) * gelu'(aux), aux fp32 [M,N], C unused.  GELU in the erf form to 1.5e-7 (common.h: gelu_as).
+// Only the shapes climb_gemm_split_nt_takes_act() names; CLIMB_EUNSUPPORTED otherwise (the caller then runs the plain product + climb_split_f32 mode 1 / 2).
+extern "C" int climb_gemm_split_nt_takes_act(int M, int N, int K) {
+  return (M > 0 && N > 0 && K > 0 && (M % 192) == 0 && (N % 192) == 0 && ((M / 192) % 8) == 0 && (K % GB_BK) == 0 && 3 * K >= 10 * GB_BK) ? 1 : 0;
+}
+extern "C" int climb_gemm_split_nt_act(const void* A, long lda, long a_lo, const void* B, long ldb, long b_lo, float* C, long ldc, void* out, long ldo, long o_lo, int M, int N,
+                                       int K, const float* bias, int epi, const float* aux, long ldaux, void* stream) {
+  if (!A || !B || !out || M <= 0 || N <= 0 || K <= 0 || (K % GB_BK) || (N % 4) || (lda % 8) || (ldb % 8) || (ldo % 8) || (a_lo % 8) || (b_lo % 8) || (o_lo % 8) || !al16(A) || !al16(B) ||
+      !al16(out))
+    return CLIMB_EINVAL;
+  if (epi != EPI_GELU_SP && epi != EPI_DGELU_SP) return CLIMB_EINVAL;
+  if (epi == EPI_GELU_SP && (!C || (ldc % 4) || !al16(C))) return CLIMB_EINVAL;
+  if (epi == EPI_DGELU_SP && (!aux || (ldaux % 4))) return CLIMB_EINVAL;
+  if (!climb_gemm_split_nt_takes_act(M, N, K)) return CLIMB_EUNSUPPORTED;
+  int rc = climb_nt4_split_launch((const bf16_t*)A, lda, a_lo, (const bf16_t*)B, ldb, b_lo, C, ldc, M, N, K, bias, epi, aux, ldaux, (hipStream_t)stream, (bf16_t*)out, ldo, o_lo);
+  if (rc == CLIMB_OK) LAUNCH_CHECK();
+  return rc;
 }
 
 // C[N,K] (fp32) += A^T B over the tokens, A = (hi, lo) planes [M,N], B = (hi, lo) planes [M,K]: three ordinary weight-gradient launches (hi.hi, hi.lo,

@@ -45,6 +45,11 @@ def _restore_nt_grid_if_unreserved(cell):
 _RED_BATCH = os.environ.get("CLIMB_AMD_RED_BATCH", "1") != "0"          # measurement knob: 0 = one reduce launch per LayerNorm backward
 _UNSCALE_MODE = os.environ.get("CLIMB_AMD_FP16_UNSCALE", "end")      # measurement knob: "range" (per finished range), "end" (one pass), "none" (timing only)
 EPI_NONE, EPI_GELU, EPI_RESID, EPI_DGELU, EPI_TANH, EPI_SILU, EPI_DSILU, EPI_RESID2, EPI_GELUD, EPI_MUL = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
+EPI_GELU_SP, EPI_DGELU_SP = 10, 11
+# r06, split mode: GELU / x GELU' as epilogues of the split NT launch (csrc/gemm_bf16_nt4.hip, erf form to 1.5e-7) instead of a pass of their own over the fp32
+# result.  Measured (profiles/r06_split_act_ab.txt): the two launches 148 -> 191 / 180 us (each unit's ~90 VALU operations sit in ONE MFMA slot of the window that
+# drains its block: exposed), the 50 + 79 us passes gone: step 23.38 -> 22.77 ms.  On by default; "0" = the separate passes with the exact erff forms.
+SPLIT_FUSED_ACT = os.environ.get("CLIMB_AMD_SPLIT_FUSED_ACT", "1") != "0"
 # r05: what the MLP's up-projection saves for the backward in the 16-bit modes.  "deriv" (default): gelu'(pre-activation), computed in the forward
 # epilogue from the sigmoid the activation needs anyway (5 more operations per element), so that the backward's epilogue is ONE multiply per element
 # (EPI_GELUD / EPI_MUL); "pre": the pre-activation itself, the derivative evaluated in the backward (EPI_GELU / EPI_DGELU; the r01 - r04 scheme and what
@@ -667,6 +672,8 @@ class ViltEngine:
             kind = f"N{args[8]}_K{args[9]}_epi{args[11]}_{'f32' if args[6] == F32 else 'h16'}" if name == "climb_gemm_bf16_nt" else name
             if name == "climb_gemm_split_nt":
                 kind = f"N{args[9]}_K{args[10]}_epi{args[12]}_split"
+            if name == "climb_gemm_split_nt_act":
+                kind = f"N{args[12]}_K{args[13]}_epi{args[15]}_split"
             prof["events"].append((e0, e1, flops, kind))
         else:
             _lib.call(name, *args)
@@ -799,7 +806,11 @@ class ViltEngine:
                 self.adapter_fwd(a_, ws.ya[i], x, ws.za[i], ws.sa[i], ws.h1[i], M, H, r)
             _lib.call("climb_layernorm_fwd", ws.h1[i], H, self.p(l + "layernorm_after.weight"), self.p(l + "layernorm_after.bias"), cfg["ln_eps"],
                       ws.hn[i], H, odt, ws.mean2[i], ws.rstd2[i], M, H, st)
-            if self.split:          # u = W1 hn + b1 in fp32 (the backward evaluates gelu' on it), a = gelu(u) as the down-projection's operand
+            if self.split and SPLIT_FUSED_ACT and _lib.query_arg("climb_gemm_split_nt_takes_act", M, Fd, H):
+                wn = l + "intermediate.dense.weight"
+                self._timed_call("gemm_split_nt", 2.0 * M * Fd * H, "climb_gemm_split_nt_act", ws.hn[i], H, M * H, self.sp(wn), H, self.layout.total, ws.u[i], Fd, ws.a[i], Fd, M * Fd,
+                                 M, Fd, H, self.p(l + "intermediate.dense.bias"), EPI_GELU_SP, None, 0, _stream())
+            elif self.split:          # u = W1 hn + b1 in fp32 (the backward evaluates gelu' on it), a = gelu(u) as the down-projection's operand
                 self.linear_fwd(ws.hn[i], l + "intermediate.dense.weight", l + "intermediate.dense.bias", ws.u[i], M, Fd, H)
                 self.split_of(ws.u[i], ws.a[i], M, Fd, mode=1)
             else:
@@ -1172,7 +1183,11 @@ class ViltEngine:
                                                dxc(i + 1), ws.dz_l[2 * i + 1] if G else ws.dz, dw)
                     dw(dy, ws.a[i], l + "output.dense.weight", M, H, Fd, l + "output.dense.bias", ws)
                 du = du_(i)
-                if self.split:          # d(gelu output) in fp32, then x gelu'(u) (exact erf form, like the fp32 mode) into the operand planes
+                if self.split and SPLIT_FUSED_ACT and _lib.query_arg("climb_gemm_split_nt_takes_act", M, Fd, H):
+                    wn = l + "output.dense.weight"
+                    self._timed_call("gemm_split_nt", 2.0 * M * Fd * H, "climb_gemm_split_nt_act", dy, H, M * H, self.spt(wn), H, self._shadow_t.numel() // 2, None, 0, du, Fd, M * Fd,
+                                     M, Fd, H, None, EPI_DGELU_SP, ws.u[i], Fd, _stream())
+                elif self.split:          # d(gelu output) in fp32, then x gelu'(u) (exact erf form, like the fp32 mode) into the operand planes
                     self.linear_dx(dy, l + "output.dense.weight", ws.du_f, M, H, Fd)
                     self.split_of(ws.du_f, du, M, Fd, mode=2, aux=ws.u[i])
                 else:

@@ -230,6 +230,12 @@ int climb_split_f32(const float* x, long ldx, void* y, long ldy, long lo_off, in
 /* C[M,N] (fp32) = epi(A B^T + bias); A = split [M,K] (lda, lo plane a_lo elements behind), B = split [N,K] (ldb, b_lo); epi 0 none, 2 + aux (fp32 [M,N]).
  * K % 64 == 0.  Runs on the four-wave persistent kernel when the shape tiles into 192 x 192 (gemm_bf16_nt4.hip), on the 128 x 128 kernel otherwise. */
 int climb_gemm_split_nt(const void* A, long lda, long a_lo, const void* B, long ldb, long b_lo, float* C, long ldc, int M, int N, int K, const float* bias, int epi, const float* aux, long ldaux, void* stream);
+/* The MLP's activation epilogues on the four-wave kernel (HF:393, :397-414).  epi 10: C (fp32 [M,N]) = A B^T + bias (the pre-activation the backward needs), out (split
+ * [M,N], ldo, lo plane o_lo elements behind) = gelu(C); epi 11: out = (A B^T) * gelu'(aux), aux = that fp32 pre-activation, C unused (may be NULL).  GELU in its erf form
+ * to 1.5e-7.  climb_gemm_split_nt_takes_act(M, N, K) = 1 for the shapes it takes (192 x 192 tiles, (M / 192) % 8 == 0); otherwise the caller runs
+ * climb_gemm_split_nt + climb_split_f32 (mode 1 / 2). */
+int climb_gemm_split_nt_takes_act(int M, int N, int K);
+int climb_gemm_split_nt_act(const void* A, long lda, long a_lo, const void* B, long ldb, long b_lo, float* C, long ldc, void* out, long ldo, long o_lo, int M, int N, int K, const float* bias, int epi, const float* aux, long ldaux, void* stream);
 /* C[N,K] (fp32) += A^T B over M tokens; A = split [M,N], B = split [M,K]; dbias (optional) += column sums of A.  Three ordinary weight-gradient launches:
  * the path of shapes climb_gemm_split_tn_grouped does not take. */
 int climb_gemm_split_tn(const void* A, long lda, long a_lo, const void* B, long ldb, long b_lo, float* C, long ldc, int M, int N, int K, float* dbias, void* stream);

@@ -367,3 +367,35 @@ def test_bf16x3_engine_on_every_step_path_against_the_fp32_mode(path):
         worst = _grad_err(ga, gb)
         print(f"{path}: worst per-tensor gradient difference {worst[0]:.2e} ({worst[1]})")
         assert worst[0] < 3e-4
+
+
+@pytest.mark.parametrize("M,N,K", [(1536, 768, 256), (3072, 3072, 768)])
+def test_gemm_split_nt_activation_epilogues(M, N, K):
+    """GELU / x GELU' as epilogues of the split NT launch (epi 10: C = u = A W^T + b in fp32, out = planes of gelu(u); epi 11: out = planes of
+    (A W^T) * gelu'(aux)) against float64 with the exact erf forms: the erf approximation (1.5e-7) and the planes' 2^-17 are all that separates them"""
+    from climb_amd import _lib
+    dev = _dev()
+    assert _lib.query_arg("climb_gemm_split_nt_takes_act", M, N, K) == 1 and _lib.query_arg("climb_gemm_split_nt_takes_act", 384, N, K) == 0
+    g = torch.Generator(device=dev).manual_seed(M + N)
+    A = torch.randn(M, K, device=dev, generator=g)
+    W = torch.randn(N, K, device=dev, generator=g) * (2.0 / math.sqrt(K))          # pre-activations of a few units: both GELU tails are visited
+    bias = torch.randn(N, device=dev, generator=g)
+    uaux = torch.randn(M, N, device=dev, generator=g) * 2.5
+    As, Ws = _split_dev(A), _split_dev(W)
+    exact = A.double().cpu() @ W.double().cpu().t()
+    u = torch.full((M, N), float("nan"), device=dev)
+    out = torch.empty((2, M, N), dtype=torch.bfloat16, device=dev)
+    _lib.call("climb_gemm_split_nt_act", As, K, M * K, Ws, K, N * K, u, N, out, N, M * N, M, N, K, bias, 10, None, 0, _st())
+    torch.cuda.synchronize()
+    uref = exact + bias.double().cpu()
+    assert _rel(u, uref) < 4e-5
+    assert _rel(out[0].double() + out[1].double(), gelu(uref)) < 4e-5
+    assert bool((out[1].float().abs() <= out[0].float().abs() * 2.0 ** -8 + 1e-30).all())          # a (hi, lo) pair: |lo| <= half an ulp of hi
+    out2 = torch.empty_like(out)
+    _lib.call("climb_gemm_split_nt_act", As, K, M * K, Ws, K, N * K, None, 0, out2, N, M * N, M, N, K, None, 11, uaux, N, _st())
+    torch.cuda.synchronize()
+    assert _rel(out2[0].double() + out2[1].double(), exact * dgelu(uaux.double().cpu())) < 4e-5
+    # the erf form itself, element-wise, through a product with the identity: gelu_as(x) against the exact erf form over both tails
+    lib = _lib.load()
+    assert lib.climb_gemm_split_nt_act(As.data_ptr(), K, M * K, Ws.data_ptr(), K, N * K, None, 0, out.data_ptr(), N, M * N, M, N, K, None, 10, None, 0, _st()) == -1      # epi 10 needs C
+    assert lib.climb_gemm_split_nt_act(As.data_ptr(), K, M * K, Ws.data_ptr(), K, N * K, None, 0, out.data_ptr(), N, M * N, 384, N, K, None, 11, uaux.data_ptr(), N, _st()) == -2
