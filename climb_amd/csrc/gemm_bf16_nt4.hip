@@ -196,6 +196,7 @@ __device__ __forceinline__ void nt4_dma_advance(Nt4Uni& u) {
 template <typename TO> __device__ __forceinline__ void nt4_store(const f32x4& v, const __amdgpu_buffer_rsrc_t& r, unsigned voff, unsigned soff);
 template <> __device__ __forceinline__ void nt4_store<float>(const f32x4& v, const __amdgpu_buffer_rsrc_t& r, unsigned voff, unsigned soff) {
   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, 0);
+  asm volatile("s_nop 0" ::"v"(v));          // r06: v's registers stay live over one wait state (tools/check_store_hazard.py: the compiler adds none behind a store with an SGPR offset)
 }
 template <> __device__ __forceinline__ void nt4_store<bf16_t>(const f32x4& v, const __amdgpu_buffer_rsrc_t& r, unsigned voff, unsigned soff) {
   u32x2 h = {pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)};

@@ -388,7 +388,7 @@ struct TnGroupOpt {          // 56 bytes, parallel to the problems; include/clim
 // theta* and F are laid out like the encoder range of the flat parameter buffer: element e of p <-> star[e - flat], fisher[e - flat].  The term is
 // added to the tile sum in fp32 before the update, and lam F (theta - theta*)^2 of the elements this launch updates is added to *loss (atomics).
 struct TnEwc { const float* flat; const float* star; const float* fisher; float* loss; float lam; int pad; };
-struct TnAdam { AdamGroup g; float gscale; int grad_dirty; TnEwc ewc; };
+struct TnAdam { AdamGroup g; float gscale; int grad_dirty; TnEwc ewc; unsigned s_lo_b, st_lo_b; };      // (SPLIT: byte distance from the hi to the lo plane of the straight / transposed shadow)
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
 // 4 x 4 transpose inside every quad of lanes: register i of lane b <-> register b of lane i (two exchange steps through DPP quad permutes)
 __device__ __forceinline__ float tn_dpp_quad(float x, bool hi) {
@@ -596,16 +596,34 @@ __global__ __launch_bounds__(512) void gemm_bf16_tn_grouped_kernel(const TnGroup
           }
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
+            // Every register-side step (packs, the transposes back) BEFORE the 16-byte stores, and wait states behind them: a VALU write to a data
+            // register of a buffer_store_dwordx4 in the slot right after it reached memory instead of the stored value (r06, measured: m / v elements
+            // holding the transpose's select of two p values, 80 of 589 824 in one matrix; the compiler's hazard table exempts stores with an SGPR offset).
             const unsigned so = se0 + (unsigned)((j * 32 + 8 * q) * (int)ldc + p * 32);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, pv[q]), rp, le * 4u, so * 4u, 0);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, mv[q]), rm, le * 4u, so * 4u, 0);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, vv[q]), rv, le * 4u, so * 4u, 0);
+            const unsigned sto = st0 + (unsigned)((p * 32) * (int)O.ldt + j * 32 + 8 * q) * 2u;
             u32x2_t w = {pack_bf16x2(pv[q][0], pv[q][1]), pack_bf16x2(pv[q][2], pv[q][3])};
-            __builtin_amdgcn_raw_buffer_store_b64(w, rs, le * 2u, so * 2u, 0);
             float t4[4] = {pv[q][0], pv[q][1], pv[q][2], pv[q][3]};
             tn_quad_transpose(t4, l31);          // back: four consecutive n of this lane's k
             u32x2_t wt = {pack_bf16x2(t4[0], t4[1]), pack_bf16x2(t4[2], t4[3])};
-            __builtin_amdgcn_raw_buffer_store_b64(wt, rt, lt, st0 + (unsigned)((p * 32) * (int)O.ldt + j * 32 + 8 * q) * 2u, 0);
+            u32x2_t wl = {0u, 0u}, wlt = {0u, 0u};
+            if constexpr (SPLIT) {          // r06: the lo planes of both shadows (lo = rn16(w - hi), split.hip), the same two layouts
+              float l4[4] = {pv[q][0] - h16lo_to_f32(w[0]), pv[q][1] - h16hi_to_f32(w[0]), pv[q][2] - h16lo_to_f32(w[1]), pv[q][3] - h16hi_to_f32(w[1])};
+              wl = (u32x2_t){pack_bf16x2(l4[0], l4[1]), pack_bf16x2(l4[2], l4[3])};
+              tn_quad_transpose(l4, l31);
+              wlt = (u32x2_t){pack_bf16x2(l4[0], l4[1]), pack_bf16x2(l4[2], l4[3])};
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, pv[q]), rp, le * 4u, so * 4u, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, mv[q]), rm, le * 4u, so * 4u, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, vv[q]), rv, le * 4u, so * 4u, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(w, rs, le * 2u, so * 2u, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(wt, rt, lt, sto, 0);
+            if constexpr (SPLIT) {
+              __builtin_amdgcn_raw_buffer_store_b64(wl, rs, le * 2u, so * 2u + ad.s_lo_b, 0);
+              __builtin_amdgcn_raw_buffer_store_b64(wlt, rt, lt, sto + ad.st_lo_b, 0);
+            }
+            asm volatile("s_nop 3");
+            __builtin_amdgcn_sched_barrier(0);
           }
         }
       if constexpr (EWC) {
@@ -786,6 +804,31 @@ extern "C" int climb_gemm_split_tn_grouped(const void* probs, const void* items,
   return CLIMB_OK;
 }
 
+// ... and with the optimizer in its epilogue (climb_gemm_bf16_tn_grouped_adamw's contract: opts, adam, grad_dirty): a fused whole tile writes p, m, v and the hi AND lo
+// planes of both shadows -- s_lo / st_lo = elements from the hi to the lo plane of the straight / transposed shadow ([2][total] buffers).
+extern "C" int climb_gemm_split_tn_grouped_adamw(const void* probs, const void* items, const void* first, int nwg, const void* opts, const float* adam, int grad_dirty,
+                                                 long s_lo, long st_lo, void* stream) {
+  if (!probs || !items || !first || nwg <= 0 || !opts || !adam || s_lo <= 0 || st_lo <= 0 || s_lo * 2 >= (1L << 32) || st_lo * 2 >= (1L << 32)) return CLIMB_EINVAL;
+  constexpr int LDS = 2 * (NTP_A_BYTES + 4 * NTP_B_UNIT);
+  static bool configured = false;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_tn_grouped_kernel<false, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) return (int)e;
+    configured = true;
+  }
+  TnAdam ad;
+  ad.g = AdamGroup{adam[0], adam[1], adam[2], adam[3], adam[4], adam[5], adam[6], 0.f};
+  ad.gscale = adam[7];
+  ad.grad_dirty = grad_dirty;
+  ad.ewc = TnEwc{nullptr, nullptr, nullptr, nullptr, 0.f, 0};
+  ad.s_lo_b = (unsigned)(s_lo * 2);
+  ad.st_lo_b = (unsigned)(st_lo * 2);
+  hipLaunchKernelGGL((gemm_bf16_tn_grouped_kernel<false, true, false, true>), dim3(nwg), dim3(512), LDS, (hipStream_t)stream, (const TnGroupProblem*)probs,
+                     (const TnGroupItem*)items, (const int*)first, (const TnGroupOpt*)opts, ad);
+  LAUNCH_CHECK();
+  return CLIMB_OK;
+}
+
 // The same launch with the optimizer in the epilogue of the problems whose TnGroupOpt says `fused` (see above).  opts: device array parallel to
 // probs; adam: HOST array of 8 floats { lr, weight decay, beta1, beta2, eps, 1 - beta1^t, 1 - beta2^t, gradient scale }; grad_dirty != 0: the
 // gradient buffer (the problems' C) is not zero and is added to the tile sums before the update (it is never written for fused problems).
@@ -822,6 +865,7 @@ static int tn_grouped_adamw_launch(const void* probs, const void* items, const v
   ad.gscale = adam[7];
   ad.grad_dirty = grad_dirty;
   ad.ewc = ewc ? *ewc : TnEwc{nullptr, nullptr, nullptr, nullptr, 0.f, 0};
+  ad.s_lo_b = ad.st_lo_b = 0;
   if (ewc) {
     if (ragged || grad_dirty) return CLIMB_EUNSUPPORTED;          // (the engine never defers a ragged plan, and folds the term only into a step whose gradient buffer is clean)
     hipLaunchKernelGGL((gemm_bf16_tn_grouped_kernel<false, true, true>), dim3(nwg), dim3(512), LDS, (hipStream_t)stream, (const TnGroupProblem*)probs,

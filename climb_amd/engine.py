@@ -596,11 +596,34 @@ class ViltEngine:
             return
         st = _stream()
         table, tn = self._t_table, self._t_n
-        if self.split:          # both planes of the straight shadow in one pass over the master weights, then the two planes' transposes
+        if self.split:
             tot, tt = self.layout.total, self._shadow_t.numel() // 2
-            _lib.call("climb_split_f32", self.flat, tot, self._shadow, tot, tot, 1, tot, 0, None, 0, st)
-            _lib.call("climb_transpose_bf16_batched", self._shadow, self._shadow_t, table, tn, 96, st)
-            _lib.call("climb_transpose_bf16_batched", self._shadow[tot:], self._shadow_t[tt:], table, tn, 96, st)
+            if self._shadow_stale == "transpose-only" and self._t_updated is not None:
+                # the optimizer ran in the weight-gradient epilogue and wrote the planes of `_t_fresh` there: what is left are the GEMM weights the FLAT pass
+                # updated (it writes no planes) -- the patch projection, a problem with stream-K tiles -- re-split one by one, and their transposes
+                import numpy as np
+                fresh, upd = frozenset(self._t_fresh or ()), frozenset(self._t_updated)
+                key = ("split", fresh, upd)
+                sub = self._t_sub.get(key)
+                if sub is None:
+                    todo = [(name, N, K) for name, N, K in self._linear_weight_names() if name not in fresh and any(c in upd for c in self._covered(name, N * K))]
+                    pw = ENC + "embeddings.patch_embeddings.projection.weight"
+                    flat_only = [pw] if (pw in upd and pw not in fresh) else []
+                    rows = np.array([(self.layout.offset[name], self._t_off[name], N, K) for name, N, K in todo], dtype=np.int64).reshape(-1, 4)
+                    if len(self._t_sub) >= 16:
+                        self._t_sub.pop(next(iter(self._t_sub)))
+                    sub = self._t_sub[key] = (torch.from_numpy(rows).to(self.device), len(todo), [(self.layout.offset[n], N * K) for n, N, K in todo] +
+                                              [(self.layout.offset[n], self.layout.numel(n)) for n in flat_only])
+                stab, sn, spans = sub
+                for o, n in spans:
+                    _lib.call("climb_split_f32", self.flat[o:o + n], n, self._shadow[o:], n, tot, 1, n, 0, None, 0, st)
+                if sn:
+                    _lib.call("climb_transpose_bf16_batched", self._shadow, self._shadow_t, stab, sn, 96, st)
+                    _lib.call("climb_transpose_bf16_batched", self._shadow[tot:], self._shadow_t[tt:], stab, sn, 96, st)
+            else:          # both planes of the straight shadow in one pass over the master weights, then the two planes' transposes
+                _lib.call("climb_split_f32", self.flat, tot, self._shadow, tot, tot, 1, tot, 0, None, 0, st)
+                _lib.call("climb_transpose_bf16_batched", self._shadow, self._shadow_t, table, tn, 96, st)
+                _lib.call("climb_transpose_bf16_batched", self._shadow[tot:], self._shadow_t[tt:], table, tn, 96, st)
             self._t_fresh = None
             self._t_updated = None
             self._shadow_version = ver
@@ -984,7 +1007,7 @@ class ViltEngine:
             if len(ws.dw_plans) >= 16:           # requires_grad patterns / group sizes seen on this shape: bounded
                 ws.dw_plans.pop(next(iter(ws.dw_plans)))
             ws.dw_plans[key] = plan
-        if self.defer_dw and self.grad_ready_hook is None and self.loss_scale == 1.0 and not plan["ragged"] and not sp:
+        if self.defer_dw and self.grad_ready_hook is None and self.loss_scale == 1.0 and not plan["ragged"]:
             self._dw_deferred.append((ws, plan))          # FusedAdamW.step() (or materialize_dw()) launches it
         else:
             self._launch_dw_plan(plan)
@@ -1023,7 +1046,11 @@ class ViltEngine:
                 if len(plan["opts"]) >= 8:
                     plan["opts"].pop(next(iter(plan["opts"])))
                 plan["opts"][key] = opts
-            if ewc is not None:          # (never with a non-zero gradient buffer or a ragged plan: FusedAdamW.step() / _dw_flush)
+            if plan.get("split"):          # (r06) the same epilogue writing the hi AND lo planes of both shadows; no EWC fold in this mode (FusedAdamW.step())
+                assert ewc is None
+                self._timed_call("gemm_split_tn", plan["flops"], "climb_gemm_split_tn_grouped_adamw", plan["probs"], plan["items"], plan["first"], plan["nwg"], opts,
+                                 row.ctypes.data, 1 if self._grad_extra else 0, self.layout.total, self._shadow_t.numel() // 2, _stream())
+            elif ewc is not None:          # (never with a non-zero gradient buffer or a ragged plan: FusedAdamW.step() / _dw_flush)
                 self._timed_call("gemm_bf16_tn", plan["flops"], "climb_gemm_bf16_tn_grouped_adamw_ewc", plan["probs"], plan["items"], plan["first"], plan["nwg"],
                                  plan["ragged"], opts, row.ctypes.data, 0, self.flat, ewc["star"], ewc["fisher"], ewc["lam"], ewc["loss"], _stream())
             else:

@@ -112,7 +112,7 @@ class FusedAdamW(torch.optim.Optimizer):
             # their epilogue for the tensors of the most common (group, step) combination; the flat pass below skips what was updated there
             names = [n for _, plan in eng._dw_deferred for n, w in zip(plan["names"], plan["whole"]) if w]          # (a fused QKV problem is named by its query weight)
             slots = [int(seg_group[idx[n]]) for n in names]
-            if shadow is not None and any(sl >= 0 for sl in slots):
+            if (shadow is not None or getattr(eng, "split", False)) and any(sl >= 0 for sl in slots):          # (split mode: the epilogue writes the operand planes itself)
                 slot0 = max(set(sl for sl in slots if sl >= 0), key=slots.count)
                 row = table[slot0].copy()
                 row[7] = 1.0          # gradient scale
@@ -177,7 +177,8 @@ class FusedAdamW(torch.optim.Optimizer):
         eng._grad_clean = clean
         # (r06) which tensors changed at all: the transposed shadows of everything else stay as they are (a frozen base under adapters)
         updated = set(fused) | {n for si, n in enumerate(self._seg_names) if seg_group[si] >= 0}
-        eng.params_updated(shadow_fresh=shadow is not None, t_fresh=fused, updated=updated)
+        # (split mode: the flat pass writes no planes -- the shadows are "fresh" exactly where the epilogue wrote them; refresh_shadow() re-splits the rest)
+        eng.params_updated(shadow_fresh=(shadow is not None) or (getattr(eng, "split", False) and bool(fused)), t_fresh=fused, updated=updated)
         return loss
 
     # ---- checkpointing: the moments and per-parameter step counts live in flat buffers outside `self.state`, so the inherited

@@ -242,6 +242,9 @@ int climb_gemm_split_tn(const void* A, long lda, long a_lo, const void* B, long 
 /* climb_gemm_bf16_tn_grouped over split operands: a problem's A / B name the hi planes of pairs whose lo plane DIRECTLY follows ([2 Mt, .]); its M field
  * (and the M handed to climb_tn_grouped_plan) = 3 Mt (three products per 64-token tile), and its `reserved` field = Mt / 64.  N % 256 == K % 256 == 0. */
 int climb_gemm_split_tn_grouped(const void* probs, const void* items, const void* first, int nwg, void* stream);
+/* ... with AdamW in its epilogue (climb_gemm_bf16_tn_grouped_adamw's contract for opts / adam / grad_dirty): a whole tile of a fused problem writes p, m, v and the
+ * hi AND lo planes of the straight and the transposed shadow; s_lo / st_lo = elements from the hi to the lo plane of those two buffers */
+int climb_gemm_split_tn_grouped_adamw(const void* probs, const void* items, const void* first, int nwg, const void* opts, const float* adam, int grad_dirty, long s_lo, long st_lo, void* stream);
 
 /* HF:322-351 on split operands (csrc/attention_split.hip): the fp32 entry points' contract -- qkv / dctx fp32, lse and delta as above -- with every product as
  * three bf16 MFMA passes over (hi, lo) planes formed on the way into LDS / registers.  The forward writes ctx as fp32 (may be NULL) and / or as split planes

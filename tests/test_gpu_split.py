@@ -430,3 +430,45 @@ def test_gemm_split_nt_activation_epilogues(M, N, K):
     lib = _lib.load()
     assert lib.climb_gemm_split_nt_act(As.data_ptr(), K, M * K, Ws.data_ptr(), K, N * K, None, 0, out.data_ptr(), N, M * N, M, N, K, None, 10, None, 0, _st()) == -1      # epi 10 needs C
     assert lib.climb_gemm_split_nt_act(As.data_ptr(), K, M * K, Ws.data_ptr(), K, N * K, None, 0, out.data_ptr(), N, M * N, 384, N, K, None, 11, uaux.data_ptr(), N, _st()) == -2
+
+
+def test_bf16x3_optimizer_in_the_weight_gradient_epilogue_is_the_same_training_step(monkeypatch):
+    """r06: the split mode's grouped weight-gradient launch with AdamW in its epilogue (p, m, v and the hi / lo planes of both shadows written there, the flat
+    pass skipping those matrices, the planes of what the flat pass updates re-split one by one) against the same steps with the plain launch + the flat pass over
+    every parameter + a full plane refresh (CLIMB_AMD_FUSED_ADAMW=0): same parameters after four steps (the update is one shared function; only the stream-K
+    tiles' atomic order differs), same loss on the way -- which a stale operand plane would break from the second step on."""
+    from oracle import vilt_oracle as vo
+    from tests.test_gpu_parity import enc_to_inputs, make_model
+    _dev()
+    res = {}
+    for fused in ("1", "0"):
+        monkeypatch.setenv("CLIMB_AMD_FUSED_ADAMW", fused)
+        model, _ = make_model(["vqa"], 42, precision="bf16x3")
+        model.train()
+        opt = model.create_optimizer({"lr": 1e-4, "weight_decay": 1e-2, "adam_epsilon": 1e-8})
+        opt.zero_grad()
+        eng = model._host.engine()
+        losses, used = [], []
+        for s in range(4):
+            enc = vo.synthetic_encodings(2, seed=300 + s)
+            images, texts = enc_to_inputs(enc)
+            loss, _, _, _ = model.fused_forward_backward("vqa", images, texts, vo.synthetic_vqa_targets(2, seed=300 + s), optimizer=opt)
+            used.append(bool(eng._dw_deferred))
+            opt.step()
+            opt.zero_grad()
+            losses.append(float(loss))
+        assert all(used) == (fused == "1"), used          # the launch was held back for the optimizer exactly when asked
+        res[fused] = (losses, {n: p.detach().float().cpu() for n, p in model.named_parameters()})
+        del model, opt
+    la, lb = res["1"][0], res["0"][0]
+    assert all(math.isfinite(x) for x in la + lb), (la, lb)
+    assert all(bool(torch.isfinite(t).all()) for r in res.values() for t in r[1].values())
+    assert max(abs(a - b) / abs(b) for a, b in zip(la, lb)) < 1e-5, (la, lb)
+    diffs = {n: float((res["1"][1][n] - res["0"][1][n]).abs().max()) for n in res["0"][1]}
+    # the key projection's bias has a zero gradient in exact arithmetic (softmax is shift-invariant): Adam turns its rounding noise into +-lr steps,
+    # whose signs follow the summation order (tests/test_gpu_parity.py::test_ten_steps_config1) -- bounded by four full steps, everything else tightly
+    worst_kb = max(v for n, v in diffs.items() if n.endswith("attention.key.bias"))
+    worst = max((v, n) for n, v in diffs.items() if not n.endswith("attention.key.bias"))
+    print(f"fused vs flat AdamW in bf16x3: worst parameter difference after four steps {worst[0]:.2e} ({worst[1]}); key biases {worst_kb:.2e}")
+    assert worst_kb < 4 * 1e-4 * 1.3
+    assert worst[0] < 2.5e-4          # 4 steps x lr 1e-4: an element may flip one +-lr step where its gradient is at the atomics' noise level

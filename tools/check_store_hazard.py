@@ -1,0 +1,78 @@
+"""Store-data hazard report for every kernel of the library (r06).
+
+Measured on gfx950 (tools/probe/split_fused_nan3.py, DESIGN.md section 0 "findings"): a VALU instruction that writes one of the data registers of a
+`buffer_store_dwordx4` in the issue slot RIGHT AFTER it can reach memory instead of the stored value -- the AdamW epilogue of the split grouped
+weight-gradient launch stored `m` / `v` elements holding the select of two `p` values that the quad transpose had just written into the same register
+(80 + 304 of 589 824 elements of one matrix, in lanes 12-15 / 28-31 of a half-wave, not every launch).  The compiler's hazard table inserts the wait
+state only for MUBUF stores WITHOUT an SGPR offset operand (the pre-gfx9 rule); the epilogues here use the SGPR offset for the uniform part of
+every address.  One instruction of distance was enough in every case seen (the write two slots behind the same store never showed).
+
+Usage: python tools/check_store_hazard.py [file.hip ...]; compiles each file to gfx950 assembly and lists every MUBUF store of more than 64 bits
+with an SGPR offset whose data registers are written by the next vector instruction, and exits non-zero if there is one.  (Found and fixed in r06:
+the grouped weight-gradient launch's optimizer epilogues -- 32 places in the split instantiation, 1 and 5 in the 16-bit and EWC ones, now every register-side
+step precedes the 16-byte stores and a wait state follows them -- and the persistent NT kernel's fp32 store, whose first data register the next
+accumulator read-back landed in: no wrong element was ever seen there, the store now keeps its registers live over one `s_nop`.)"""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+from concurrent.futures import ThreadPoolExecutor
+
+CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "climb_amd", "csrc")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+NOT_VALU = ("buffer_", "ds_", "global_", "flat_", "s_", "scratch_")
+KNOWN = ()
+
+
+def scan(path):
+    with tempfile.TemporaryDirectory() as tmp:
+        out = os.path.join(tmp, "k.s")
+        r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "--cuda-device-only", "-S", path, "-o", out],
+                           capture_output=True, text=True)
+        if r.returncode:
+            raise RuntimeError(r.stderr[-2000:])
+        kern, ins = None, []
+        for l in open(out):
+            l = l.strip()
+            if not l or l.startswith((";", ".")):
+                continue
+            lab = re.match(r"(\S+):(\s|$)", l)
+            if lab:
+                if lab.group(1).startswith("_Z"):
+                    kern = lab.group(1)
+                continue
+            ins.append((kern, l))
+    found = []
+    for i, (k, l) in enumerate(ins[:-1]):
+        m = re.match(r"buffer_store_dwordx[34] v\[(\d+):(\d+)\], \S+ s\[\d+:\d+\], s\d+", l)
+        if not m:
+            continue
+        regs = set(range(int(m.group(1)), int(m.group(2)) + 1))
+        nx = ins[i + 1][1]
+        if nx.startswith(NOT_VALU):
+            continue
+        mm = re.match(r"(\S+)\s+(?:v\[(\d+):(\d+)\]|v(\d+))", nx)
+        if not mm:
+            continue
+        dst = set(range(int(mm.group(2)), int(mm.group(3)) + 1)) if mm.group(2) else {int(mm.group(4))}
+        if dst & regs:
+            found.append((os.path.basename(path), k, l, nx, mm.group(1)))
+    return found
+
+
+def main(files):
+    bad = 0
+    with ThreadPoolExecutor(max_workers=min(8, len(files))) as ex:
+        for res in ex.map(scan, files):
+            for f, k, st, nx, op in res:
+                known = (f, op) in KNOWN
+                print(f"{'known ' if known else 'HAZARD'}  {f}  {(k or '?')[:70]}\n        {st}\n        {nx}")
+                bad += 0 if known else 1
+    print("no store-data hazards outside the known list" if not bad else f"{bad} store-data hazard(s)")
+    return bad
+
+
+if __name__ == "__main__":
+    fs = sys.argv[1:] or [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".hip")]
+    sys.exit(1 if main(fs) else 0)
