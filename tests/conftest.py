@@ -1,6 +1,13 @@
 import os
 import sys
 
+# torch's default is one intra-op thread per core pair -- 128 on the GPU box -- in THIS process and in every child the suite starts (two-rank runs, the
+# subprocess suites of tests/_background.py): ten such pools on one box spend their time spinning at barriers (r06, measured: driver scenarios 7 -> 80 s when
+# the children ran beside them).  The CPU work here is the oracle on batches of 2 - 4: 16 threads is where bench.py's cpu_baseline leg runs it too.
+_THREADS = str(min(16, os.cpu_count() or 16))
+os.environ.setdefault("OMP_NUM_THREADS", _THREADS)
+os.environ.setdefault("MKL_NUM_THREADS", _THREADS)
+
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -11,6 +18,36 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _gpu_here():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+def pytest_collection_modifyitems(config, items):
+    """the tests that only wait for a child suite (tests/_background.py) run last: their children get the whole run to finish in"""
+    from tests import _background
+    items.sort(key=lambda it: getattr(it, "originalname", it.name) in _background.SPECS)          # (stable: everything else keeps its order)
+
+
+def pytest_collection_finish(session):
+    from tests import _background
+    if os.environ.get("CLIMB_AMD_BACKGROUND_CHILD") or session.config.option.collectonly:
+        return
+    names = [getattr(it, "originalname", it.name) for it in session.items]
+    todo = [n for n in names if n in _background.SPECS]
+    if todo and len(names) > len(todo) and _gpu_here():          # (selected alone, a test starts its child itself)
+        for n in todo:
+            _background.start(n)
+
+
+def pytest_sessionfinish(session, exitstatus):
+    from tests import _background
+    _background.stop_all()
 
 
 @pytest.fixture(scope="session")

@@ -85,12 +85,19 @@ def test_evaluation_shards_are_exact_and_replicated_mode_sees_whole_batches():
     assert shard_of([5, 6, 7], 0, 1) == ([5, 6, 7], 1.0)
 
 
+_PORTS_GIVEN, _PORTS_LOCK = set(), __import__("threading").Lock()
+
+
 def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
+    with _PORTS_LOCK:          # (tests/test_gpu_driver.py starts four runs from four threads: never the same port twice in one session)
+        while True:
+            s = socket.socket()
+            s.bind(("127.0.0.1", 0))
+            p = s.getsockname()[1]
+            s.close()
+            if p not in _PORTS_GIVEN:
+                _PORTS_GIVEN.add(p)
+                return p
 
 
 def run_ranks(world, argv, timeout=1500, env_extra=None):

@@ -9,16 +9,16 @@ import sys
 
 import pytest
 
+from tests import _background
+
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_reference_fixtures_with_the_last_layer_on_cls_rows_only():
     # (r06: the suite's time budget -- the split mode has no row pruning, and the variable-resolution / EWC steps add nothing to what prunes here)
-    sel = "(single_image or nlvr2_two_images or vcr_four or replay_step or bf16_mode_step) and not bf16x3"
-    env = dict(os.environ, CLIMB_AMD_CLS_ONLY_LAST="1")
-    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_parity.py", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider", "-k", sel],
-                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=2400)
+    # selection and environment: tests/_background.py (the child is started when collection ends; this test waits for it)
+    r = _background.result("test_reference_fixtures_with_the_last_layer_on_cls_rows_only")
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout and "failed" not in r.stdout
     print(r.stdout.strip().splitlines()[-1])

@@ -137,20 +137,50 @@ def _rel(a, b):
     return float((a - b).norm() / (b.norm() + 1e-300))
 
 
+@pytest.fixture(scope="module")
+def dp_runs(dp_tree, tmp_path_factory):
+    """The four driver runs the two tests below compare -- {EWC, ER} x {one process, two ranks} -- started TOGETHER (r06, the suite's time budget: each is a
+    child process tree of its own that keeps the GPU busy a few percent of the time; one after the other they were 85 s of waiting).  fp32 arithmetic, 2 epochs
+    per task: the same paths in a fraction of the time.  Checkpoints are removed when the module is done."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from concurrent.futures import ThreadPoolExecutor
+    from tests.test_dp_training import _scenario
+    tmp = tmp_path_factory.mktemp("dp_runs")
+    env = {"CLIMB_AMD_PRECISION": "fp32"}
+    keys = [(name, world) for name in ("ewc", "experience_replay") for world in (1, 2)]
+    with ThreadPoolExecutor(max_workers=len(keys)) as ex:
+        futs = {k: ex.submit(_scenario, k[1], k[0], dp_tree, tmp, abi="hip", env_extra=env, extra=["--pin", "--epochs", "2"]) for k in keys}
+        runs = {}
+        for k, f in futs.items():
+            try:
+                runs[k] = f.result()
+            except BaseException as e:          # (reported by the test that needs this run)
+                runs[k] = e
+    yield runs
+    for dp, _, fs in os.walk(str(tmp)):
+        for f in fs:
+            q = os.path.join(dp, f)
+            try:
+                if not os.path.islink(q) and os.path.getsize(q) > (4 << 20):
+                    os.remove(q)
+            except OSError:
+                pass
+
+
 @pytest.mark.parametrize("name", ["ewc", "experience_replay"])
-def test_two_rank_data_parallel_driver_run_equals_the_single_process_run(name, dp_tree, tmp_path, golden_dir):
+def test_two_rank_data_parallel_driver_run_equals_the_single_process_run(name, dp_runs, golden_dir):
     """BASELINE.json configs[3] / configs[4] AS data-parallel jobs, on the real engine: two processes (gloo on device tensors; both on the
     box's one GPU) run the four-task EWC / ER driver scenario with rank-sharded loaders, the reducer the trainers attach, all-reduced
     evaluation, the replicated + broadcast Fisher pass, sharded replay batches and rank-0 checkpoints (fp32 arithmetic so that the
     comparison with ONE process on the global batches is tight).  Required: the reference driver's call sequence on every rank, replicas
     bit-identical at the end, the single-process results.json, and -- EWC -- theta* / Fisher of every finished task equal to the
     single-process ones up to fp32 summation order (global batch k of the two-rank run IS batch k of the single-process run)."""
-    if not torch.cuda.is_available():
-        pytest.skip("needs a GPU")
-    from tests.test_dp_training import _files, _pinned, _same, _scenario
-    env = {"CLIMB_AMD_PRECISION": "fp32"}
-    out1, rep1 = _scenario(1, name, dp_tree, tmp_path, abi="hip", env_extra=env, extra=["--pin", "--epochs", "2"])      # 2 epochs per task: the same paths in a fraction of the time
-    out2, rep2 = _scenario(2, name, dp_tree, tmp_path, abi="hip", env_extra=env, extra=["--pin", "--epochs", "2"])
+    from tests.test_dp_training import _files, _pinned, _same
+    for world in (1, 2):
+        if isinstance(dp_runs[(name, world)], BaseException):
+            raise dp_runs[(name, world)]
+    (out1, rep1), (out2, rep2) = dp_runs[(name, 1)], dp_runs[(name, 2)]
     golden = json.load(open(os.path.join(golden_dir, "driver_calls.json")))["scenarios"][name]
     for rep in rep2 + rep1:
         assert rep["calls"] == golden["calls"]

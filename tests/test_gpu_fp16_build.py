@@ -5,13 +5,16 @@
     fp16 operands with a scaled loss gradient -- logits and gradient norms inside north_star's 1e-3, every argmax equal to the reference's;
   * the step-level parity tests of tests/test_gpu_parity.py in that mode (autograd path, gradient accumulation, EWC, hipGraph, training curve).
 The rest of tests/test_gpu_parity.py (ViLT-BERT, adapters, two-rank data parallel, odd batch sizes, 384 x 640, the miniature driver, freezing)
-passes the same way -- `CLIMB_AMD_H16=fp16 python -m pytest tests/test_gpu_parity.py -m gpu`, 42 tests -- and is left out here only for time."""
+passes the same way -- `CLIMB_AMD_H16=fp16 python -m pytest tests/test_gpu_parity.py -m gpu`, 42 tests -- and is left out here only for time.
+The two pytest children are started when collection ends and waited for here (tests/_background.py)."""
 import json
 import os
 import subprocess
 import sys
 
 import pytest
+
+from tests import _background
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -24,7 +27,7 @@ def _run(args, timeout=1500):
 
 
 def test_fp16_build_passes_the_kernel_suite():
-    r = _run(["-m", "pytest", "tests/test_gpu_kernels.py", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider"])
+    r = _background.result("test_fp16_build_passes_the_kernel_suite")          # python -m pytest tests/test_gpu_kernels.py -m gpu with CLIMB_AMD_H16=fp16
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout
 
@@ -45,7 +48,7 @@ def test_fp16_mode_passes_the_step_level_parity_tests():
     reference-style autograd path (loss scale chosen from torch's d(logits)), the Fisher pass (gradient accumulation across backwards
     without zero_grad: earlier sums are pre-scaled), EWC, hipGraph replay, and 30 optimizer steps tracking the fp32 loss curve."""
     # (r06: the suite's time budget -- the full-size step on this build is test_fp16_step_against_the_reference_at_batch_64 above)
-    sel = "training_curve or reference_style_autograd or fisher_accumulating or ewc_penalty or hipgraph"
-    r = _run(["-m", "pytest", "tests/test_gpu_parity.py", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider", "-k", sel], timeout=2400)
+    # selection (tests/_background.py): "training_curve or reference_style_autograd or fisher_accumulating or ewc_penalty or hipgraph"
+    r = _background.result("test_fp16_mode_passes_the_step_level_parity_tests")
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout

@@ -860,7 +860,10 @@ def test_full_size_fp32_vs_reference(golden_dir, fname, precision):
 #   vqa_b64  pooled 2.24e-2 logits 5.96e-3 loss 4.0e-5 grad norms 5.3e-3 argmax 63 / 64;  nlvr2_b32  2.43e-2 7.07e-3 7.8e-4 3.8e-3 32 / 32;  vcr_b16  2.33e-2 7.45e-3 6.0e-4 3.3e-3 16 / 16
 BF16_FULL = {"vqa_b64.npz": dict(pooled=2.9e-2, logits=7.8e-3, loss=1e-4, grad_norm_max=7e-3),
              "nlvr2_b32.npz": dict(pooled=3.2e-2, logits=9.2e-3, loss=1.1e-3, grad_norm_max=5e-3),
-             "vcr_b16.npz": dict(pooled=3.1e-2, logits=9.7e-3, loss=8e-4, grad_norm_max=4.4e-3)}
+             # (vcr: the one fixture whose 16-bit step is not bit-reproducible -- its M = 64-row head GEMMs take the split-K path, whose fp32 atomics order the 16-bit
+             # roundings downstream differently from run to run (tools/probe/vcr_determinism.py; the fp32 mode forbids itself split-K and repeats bit for bit):
+             # the worst gradient-norm error moved between 3.2e-3 and 4.9e-3 over 12 runs (tools/probe/vcr_full_repeat.py) -- limit = the largest seen x 1.3)
+             "vcr_b16.npz": dict(pooled=3.1e-2, logits=9.7e-3, loss=8e-4, grad_norm_max=6.4e-3)}
 
 
 @pytest.mark.parametrize("fname", FULL_SIZE)
@@ -1022,6 +1025,7 @@ def test_optimizer_in_the_weight_gradient_epilogue_is_the_same_training_step(con
             assert (n_fused, n_plain) == ((3, 1 if config == "accumulate" else 0) if fused else (0, 4 if config == "accumulate" else 3)), launches
         assert not torch.equal(w0, model.get_encoder().vilt.encoder.layer[10].intermediate.dense.weight.detach())
         assert bool(torch.isfinite(eng.flat).all()) and bool(torch.isfinite(opt._m).all()) and bool(torch.isfinite(opt._v).all())
+        assert bool((opt._v >= 0).all()), "negative second moment (r06: the store-data hazard of tools/check_store_hazard.py would show here first)"
         assert torch.equal(eng._shadow, eng.flat.to(torch.bfloat16)), "16-bit shadow is not the image of the fp32 parameters"
         for name, N, K in eng._linear_weight_names():
             t = eng._shadow_t[eng._t_off[name]:eng._t_off[name] + N * K].view(K, N)

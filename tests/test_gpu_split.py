@@ -443,7 +443,7 @@ def test_bf16x3_optimizer_in_the_weight_gradient_epilogue_is_the_same_training_s
     res = {}
     for fused in ("1", "0"):
         monkeypatch.setenv("CLIMB_AMD_FUSED_ADAMW", fused)
-        model, _ = make_model(["vqa"], 42, precision="bf16x3")
+        model, P = make_model(["vqa"], 42, precision="bf16x3")
         model.train()
         opt = model.create_optimizer({"lr": 1e-4, "weight_decay": 1e-2, "adam_epsilon": 1e-8})
         opt.zero_grad()
@@ -458,17 +458,36 @@ def test_bf16x3_optimizer_in_the_weight_gradient_epilogue_is_the_same_training_s
             opt.zero_grad()
             losses.append(float(loss))
         assert all(used) == (fused == "1"), used          # the launch was held back for the optimizer exactly when asked
+        # the optimizer state is sane (the first build of this epilogue stored stray register values into m / v: negative second moments, NaN two steps later)
+        assert bool(torch.isfinite(eng.flat).all()) and bool(torch.isfinite(opt._m).all()) and bool(torch.isfinite(opt._v).all())
+        assert bool((opt._v >= 0).all()), "negative second moment"
+        # ... and the operand planes ARE the split of the fp32 parameters, in both layouts, for every GEMM weight (epilogue-written or re-split)
+        eng.refresh_shadow()
+        torch.cuda.synchronize()
+        tot, tt = eng.layout.total, eng._shadow_t.numel() // 2
+        names = [(n, N * K, N, K) for n, N, K in eng._linear_weight_names()]
+        pw = next(n for n in eng.layout.offset if n.endswith("patch_embeddings.projection.weight"))
+        names.append((pw, eng.layout.numel(pw), None, None))
+        for n, numel, N, K in names:
+            o = eng.layout.offset[n]
+            w = eng.flat[o:o + numel]
+            hi = w.to(torch.bfloat16)
+            lo = (w - hi.float()).to(torch.bfloat16)
+            assert torch.equal(eng._shadow[o:o + numel], hi) and torch.equal(eng._shadow[tot + o:tot + o + numel], lo), f"operand planes of {n}"
+            if N is not None:
+                t = eng._t_off[n]
+                assert torch.equal(eng._shadow_t[t:t + numel].view(K, N), hi.view(N, K).t()), f"transposed hi plane of {n}"
+                assert torch.equal(eng._shadow_t[tt + t:tt + t + numel].view(K, N), lo.view(N, K).t()), f"transposed lo plane of {n}"
         res[fused] = (losses, {n: p.detach().float().cpu() for n, p in model.named_parameters()})
         del model, opt
     la, lb = res["1"][0], res["0"][0]
     assert all(math.isfinite(x) for x in la + lb), (la, lb)
-    assert all(bool(torch.isfinite(t).all()) for r in res.values() for t in r[1].values())
     assert max(abs(a - b) / abs(b) for a, b in zip(la, lb)) < 1e-5, (la, lb)
+    # parameters: an element whose gradient sits at the summation order's noise level takes +-lr steps of either sign (Adam normalises; the zero-gradient
+    # key biases and the rows of unused word embeddings are all of that kind) -- at most four lr steps apart; a weight matrix as a whole moves the same way
     diffs = {n: float((res["1"][1][n] - res["0"][1][n]).abs().max()) for n in res["0"][1]}
-    # the key projection's bias has a zero gradient in exact arithmetic (softmax is shift-invariant): Adam turns its rounding noise into +-lr steps,
-    # whose signs follow the summation order (tests/test_gpu_parity.py::test_ten_steps_config1) -- bounded by four full steps, everything else tightly
-    worst_kb = max(v for n, v in diffs.items() if n.endswith("attention.key.bias"))
-    worst = max((v, n) for n, v in diffs.items() if not n.endswith("attention.key.bias"))
-    print(f"fused vs flat AdamW in bf16x3: worst parameter difference after four steps {worst[0]:.2e} ({worst[1]}); key biases {worst_kb:.2e}")
-    assert worst_kb < 4 * 1e-4 * 1.3
-    assert worst[0] < 2.5e-4          # 4 steps x lr 1e-4: an element may flip one +-lr step where its gradient is at the atomics' noise level
+    worst = max((v, n) for n, v in diffs.items())
+    rel = max((float((res["1"][1][n] - res["0"][1][n]).norm() / (res["0"][1][n] - P[n].float()).norm()), n) for n in diffs if res["0"][1][n].numel() >= 768 * 768 and "word_embeddings" not in n)
+    print(f"fused vs flat AdamW in bf16x3 after four steps: worst element {worst[0]:.2e} ({worst[1]}); worst matrix, relative to its update {rel[0]:.2e} ({rel[1]})")
+    assert worst[0] < 4 * 1e-4 * 1.3
+    assert rel[0] < 0.05
