@@ -1047,7 +1047,8 @@ class ViltEngine:
                     plan["opts"].pop(next(iter(plan["opts"])))
                 plan["opts"][key] = opts
             if plan.get("split"):          # (r06) the same epilogue writing the hi AND lo planes of both shadows; no EWC fold in this mode (FusedAdamW.step())
-                assert ewc is None
+                if ewc is not None:
+                    raise RuntimeError("the split mode's optimizer epilogue carries no EWC term: FusedAdamW.step() folds it into the flat pass")
                 self._timed_call("gemm_split_tn", plan["flops"], "climb_gemm_split_tn_grouped_adamw", plan["probs"], plan["items"], plan["first"], plan["nwg"], opts,
                                  row.ctypes.data, 1 if self._grad_extra else 0, self.layout.total, self._shadow_t.numel() // 2, _stream())
             elif ewc is not None:          # (never with a non-zero gradient buffer or a ragged plan: FusedAdamW.step() / _dw_flush)

@@ -100,7 +100,7 @@ class FusedAdamW(torch.optim.Optimizer):
                 fold = None
             else:
                 eng._ewc_fold = None
-                fold_flat = os.environ.get("CLIMB_AMD_EWC_FOLD", "2") == "2"
+                fold_flat = os.environ.get("CLIMB_AMD_EWC_FOLD", "2") == "2" or getattr(eng, "split", False)          # (the split epilogue has no EWC instantiation)
                 if fold_flat:
                     # the term rides in the FLAT pass for every encoder element: the weight gradients are written by the plain launch and the optimizer
                     # is not carried in its epilogue this step (measured, tools/ewc_ab.py: the epilogue is exposed time -- two more operands there cost
