@@ -36,7 +36,7 @@ def pytest_collection_modifyitems(config, items):
 
 def pytest_collection_finish(session):
     from tests import _background
-    if os.environ.get("CLIMB_AMD_BACKGROUND_CHILD") or session.config.option.collectonly:
+    if os.environ.get("CLIMB_AMD_BACKGROUND_CHILD") or os.environ.get("PYTEST_XDIST_WORKER") or session.config.option.collectonly:          # (xdist workers each collect everything: their tests start their own child)
         return
     names = [getattr(it, "originalname", it.name) for it in session.items]
     todo = [n for n in names if n in _background.SPECS]
